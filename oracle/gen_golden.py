@@ -1,0 +1,384 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in tests/golden/ by RUNNING THE REFERENCE ITSELF
+(/root/reference/neo_mpc_planner2/mpc_optimization_server.py imported under
+oracle/ros_stubs.py).  Development container only: /root/reference does not exist
+on the GPU box, and no reference source is stored in the fixtures -- only inputs
+and the reference's outputs.
+
+    python oracle/gen_golden.py            # rewrites tests/golden/*.npz
+
+Fixture sets: G1 objective/f_constraint values, G2 yaw extraction,
+G3 cold-start SLSQP solves (ftol 1e-3 and 1e-12), G4 stateful optimizer() episodes,
+G5 warm-start shift, G6 SciPy forward-difference gradients.
+"""
+import contextlib
+import io
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import scipy
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ros_stubs  # noqa: E402
+from oracle.mpc_oracle import README_PARAMS, PY_DEFAULT_PARAMS  # noqa: E402
+from neo_mpc_planner2_amd import synthetic  # noqa: E402
+from neo_mpc_planner2_amd.abi import PROBLEM_DTYPE  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+PARAM_KEYS = sorted(README_PARAMS.keys())
+
+
+def versions():
+    return dict(scipy=scipy.__version__, numpy=np.__version__,
+                python="%d.%d.%d" % sys.version_info[:3])
+
+
+def params_vec(p):
+    return np.array([float(p[k]) for k in PARAM_KEYS], dtype=np.float64)
+
+
+RECT_FOOTPRINT = ((0.35, 0.25), (-0.35, 0.25), (-0.35, -0.25), (0.35, -0.25))
+
+
+def footprint_world(prob_row, base=RECT_FOOTPRINT):
+    """published footprint = base polygon placed at the current pose (global frame)."""
+    x0, y0 = prob_row["cur_xy"]
+    q = prob_row["cur_q"]
+    yaw = math.atan2(2.0 * (q[3] * q[2] + q[0] * q[1]), 1.0 - 2.0 * (q[1] * q[1] + q[2] * q[2]))
+    c, s = math.cos(yaw), math.sin(yaw)
+    return [(x0 + px * c - py * s, y0 + px * s + py * c) for (px, py) in base]
+
+
+class Ref:
+    """One reference node instance, configured like a launch file would."""
+
+    def __init__(self, mod, params, cmap):
+        ros_stubs.Node.overrides = dict(params)
+        ros_stubs.Costmap2d.pending = cmap
+        self.mod = mod
+        self.srv = mod.MpcOptimizationServer()
+        self.set_footprint([])
+
+    def set_footprint(self, pts):
+        msg = ros_stubs.PolygonStamped()
+        msg.polygon.points = [ros_stubs.Point32(px, py) for (px, py) in pts]
+        self.srv.footprint_callback(msg)
+
+    def request(self, row):
+        req = ros_stubs.Optimizer.Request()
+        req.current_pose.pose.position.x = float(row["cur_xy"][0])
+        req.current_pose.pose.position.y = float(row["cur_xy"][1])
+        o = req.current_pose.pose.orientation
+        o.x, o.y, o.z, o.w = (float(v) for v in row["cur_q"])
+        req.carrot_pose.pose.position.x = float(row["carrot_xy"][0])
+        req.carrot_pose.pose.position.y = float(row["carrot_xy"][1])
+        o = req.carrot_pose.pose.orientation
+        o.x, o.y, o.z, o.w = (float(v) for v in row["carrot_q"])
+        req.goal_pose.position.x, req.goal_pose.position.y, req.goal_pose.position.z = \
+            (float(v) for v in row["goal_xyz"])
+        o = req.goal_pose.orientation
+        o.x, o.y, o.z, o.w = (float(v) for v in row["goal_q"])
+        req.current_vel.linear.x, req.current_vel.linear.y, req.current_vel.angular.z = \
+            (float(v) for v in row["cur_vel"])
+        req.control_interval = float(row["control_interval"])
+        return req
+
+    def load(self, row):
+        """Put a request's fields where objective() reads them (py:350-355)."""
+        req = self.request(row)
+        s = self.srv
+        s.current_pose, s.carrot_pose = req.current_pose, req.carrot_pose
+        s.current_velocity, s.goal_pose = req.current_vel, req.goal_pose
+        s.control_interval = req.control_interval
+
+
+def gen_g1(mod):
+    """objective() / f_constraint() values, including the quirk cases of SURVEY §8a."""
+    rng = np.random.default_rng(101)
+    groups = []
+    for n_steps, count in ((3, 160), (8, 48), (32, 48)):
+        base = README_PARAMS if n_steps != 8 else PY_DEFAULT_PARAMS
+        params = dict(base, control_steps=n_steps, prediction_horizon=0.8)
+        if n_steps == 32:
+            params["w_footprint"] = 2000
+        cmap = synthetic.make_costmap(200, seed=7 + n_steps)
+        ref = Ref(mod, params, cmap)
+        probs = synthetic.make_problems(count, 200, seed=200 + n_steps)
+        vmax = params["max_vel_x"]
+        u = rng.uniform(-vmax, vmax, size=(count, 3 * n_steps))
+        u[: count // 8] *= 1.6                       # outside the bounds too (objective is defined there)
+        # quirk cases -------------------------------------------------------------
+        for j in range(0, 12):                       # kink: u_i == v_cur exactly (py:253-254)
+            i = j % n_steps
+            u[j, 3 * i:3 * i + 3] = probs["cur_vel"][j]
+        for j in range(12, 24):                      # |angle errors| > pi, not wrapped (py:251, 267)
+            probs["carrot_q"][j] = synthetic.yaw_quat(np.array(3.1))
+            probs["goal_q"][j] = synthetic.yaw_quat(np.array(-3.1))
+            u[j, 2::3] = -vmax
+        for j in range(24, 36):                      # non-unit / non-planar quaternions (py:160-180)
+            probs["cur_q"][j] = rng.normal(size=4)
+            probs["goal_q"][j] = rng.normal(size=4)
+            probs["carrot_q"][j] = rng.normal(size=4)
+        # lethal cells: park some robots on a lethal / inscribed cell (py:257-258)
+        cells = cmap[0]
+        lethal = np.argwhere(cells == 254)
+        inscr = np.argwhere(cells == 253)
+        for j in range(36, 48):
+            src = lethal if j % 2 == 0 else inscr
+            my, mx = src[rng.integers(len(src))]
+            probs["cur_xy"][j] = (cmap[2] + (mx + 0.5) * cmap[1], cmap[3] + (my + 0.5) * cmap[1])
+            u[j] *= 0.02
+        for j in range(count - 8, count):            # out-of-bounds positions (build's contract: 1.0)
+            probs["cur_xy"][j] = (cmap[2] - 0.3 + 0.1 * j, cmap[3] + 0.01)
+        fvals = np.zeros(count)
+        cvals = np.zeros((count, n_steps))
+        fp = np.zeros((count, 4, 2))
+        fcost = np.zeros(count)
+        for j in range(count):
+            pts = footprint_world(probs[j])
+            fp[j] = pts
+            ref.set_footprint(pts if (n_steps == 32 or j % 3 == 0) else [])
+            if not (n_steps == 32 or j % 3 == 0):
+                fp[j] = np.nan
+            ref.load(probs[j])
+            fvals[j] = ref.srv.objective(u[j].copy())
+            cvals[j] = [ref.srv.f_constraint(u[j], index=i) for i in range(n_steps)]
+            fcost[j] = ref.srv.costmap_ros.getFootprintCost(ref.srv.footprint)
+        groups.append((n_steps, params, cmap, probs, u, fp, fvals, cvals, fcost))
+    out = dict(versions=np.array(repr(versions())), param_keys=np.array(PARAM_KEYS))
+    for (n_steps, params, cmap, probs, u, fp, fvals, cvals, fcost) in groups:
+        k = "n%d_" % n_steps
+        out[k + "params"] = params_vec(params)
+        out[k + "cells"] = cmap[0]
+        out[k + "map_meta"] = np.array(cmap[1:], dtype=np.float64)
+        out[k + "problems"] = probs.view(np.uint8).reshape(len(probs), -1)
+        out[k + "u"] = u
+        out[k + "footprint"] = fp
+        out[k + "objective"] = fvals
+        out[k + "constraint"] = cvals
+        out[k + "footprint_cost"] = fcost
+    np.savez_compressed(os.path.join(OUT, "g1_objective.npz"), **out)
+    print("G1:", sum(len(g[3]) for g in groups), "cases")
+
+
+def gen_g2(mod):
+    rng = np.random.default_rng(102)
+    q = rng.normal(size=(256, 4))
+    q[:128] /= np.linalg.norm(q[:128], axis=1, keepdims=True)
+    q[250] = (0, 0, 0, 1)
+    q[251] = (0, 0, 1, 0)
+    q[252] = (0, 0, math.sqrt(0.5), math.sqrt(0.5))
+    q[253] = (0, 0, 0, 0)
+    srv = Ref(mod, README_PARAMS, None).srv
+    rpy = np.array([srv.euler_from_quaternion(*row) for row in q])
+    yaws = rng.uniform(-7, 7, size=64)
+    quats = np.array([srv.quaternion_from_euler(0, 0, yy) for yy in yaws])   # (w, x, y, z)
+    np.savez_compressed(os.path.join(OUT, "g2_yaw.npz"), versions=np.array(repr(versions())),
+                        q_xyzw=q, rpy=rpy, yaws=yaws, quat_wxyz=quats)
+    print("G2: 256 + 64 cases")
+
+
+def gen_g3(mod):
+    """Cold-start solves through the reference's own objective/bounds/constraints."""
+    from scipy.optimize import minimize
+    count = 128
+    params = dict(README_PARAMS)
+    cmap = synthetic.make_costmap(200, seed=3)
+    zero = (np.zeros((200, 200), np.uint8),) + cmap[1:]
+    probs = synthetic.make_problems(count, 200, seed=303)
+    res = {k: [] for k in ("x_loose", "f_loose", "nit_loose", "nfev_loose", "status_loose",
+                           "x_tight", "f_tight", "nit_tight", "nfev_tight", "status_tight")}
+    refs = (Ref(mod, params, zero), Ref(mod, params, cmap))
+    has_map = np.zeros(count, dtype=np.int32)
+    t0 = time.time()
+    for j in range(count):
+        ref = refs[j % 2]
+        has_map[j] = j % 2
+        ref.load(probs[j])
+        s = ref.srv
+        for tag, ftol, maxiter in (("loose", 1e-3, 100), ("tight", 1e-12, 500)):
+            r = minimize(s.objective, np.zeros(9), method="SLSQP", bounds=s.bnds,
+                         constraints=s.cons, options={"ftol": ftol, "disp": False,
+                                                      "maxiter": maxiter})
+            res["x_" + tag].append(r.x)
+            res["f_" + tag].append(r.fun)
+            res["nit_" + tag].append(r.nit)
+            res["nfev_" + tag].append(r.nfev)
+            res["status_" + tag].append(r.status)
+    print("G3: %d solves x2 in %.1fs" % (count, time.time() - t0))
+    np.savez_compressed(os.path.join(OUT, "g3_solves.npz"), versions=np.array(repr(versions())),
+                        param_keys=np.array(PARAM_KEYS), params=params_vec(params),
+                        cells=cmap[0], map_meta=np.array(cmap[1:]), has_map=has_map,
+                        problems=probs.view(np.uint8).reshape(count, -1),
+                        **{k: np.array(v) for k, v in res.items()})
+
+
+class FakeClock:
+    def __init__(self):
+        self.t = 1000.0
+
+    def time(self):
+        return self.t
+
+
+def gen_g4(mod):
+    """8 episodes x 50 sequential optimizer() calls through the reference wrapper."""
+    n_ep, n_calls = 8, 50
+    params = dict(README_PARAMS)
+    cmap = synthetic.make_costmap(200, seed=4)
+    cells, res, ox, oy = cmap
+    clock = FakeClock()
+    mod.time.time = clock.time                    # py:369 uses the wall clock
+    rng = np.random.default_rng(404)
+    dt_tick = 1.0 / 30.0
+    rec = dict(problems=[], delta_t=[], raw_x=[], success=[], out=[], init_guess=[],
+               last_control=[], collision=[], collision_footprint=[], waiting_time=[],
+               footprint=[])
+    from scipy.optimize import minimize as sp_min
+    for ep in range(n_ep):
+        ref = Ref(mod, params, cmap)
+        s = ref.srv
+        seed_probs = synthetic.make_problems(1, 200, seed=440 + ep)
+        row = seed_probs[0].copy()
+        # episodes 2, 5: start 0.45 m in front of a lethal disc so the predicted path hits it
+        if ep in (2, 5):
+            lethal = np.argwhere(cells == 254)
+            my, mx = lethal[rng.integers(len(lethal))]
+            lx, ly = ox + (mx + 0.5) * res, oy + (my + 0.5) * res
+            row["cur_xy"] = (lx - 0.45, ly)
+            row["cur_q"] = synthetic.yaw_quat(np.array(0.0))
+            row["carrot_xy"] = (0.4, 0.0)
+        use_fp = ep in (1, 5, 6)
+        yaw = math.atan2(2.0 * row["cur_q"][3] * row["cur_q"][2], 1.0 - 2.0 * row["cur_q"][2] ** 2)
+        pos = np.array(row["cur_xy"])
+        vel = np.zeros(3)
+        # capture the raw solver output: wrap scipy's minimize seen by the reference module
+        captured = {}
+
+        def wrapped(fun, x0, **kw):
+            r = sp_min(fun, x0, **kw)
+            captured["x"] = np.array(r.x, dtype=np.float64).copy()
+            captured["success"] = bool(r.success)
+            return r
+        mod.minimize = wrapped
+        for k in range(n_calls):
+            if k == 25 and ep % 2 == 1:           # new goal mid-episode (py:358-361)
+                g = synthetic.make_problems(1, 200, seed=900 + ep)[0]
+                row["goal_xyz"], row["goal_q"] = g["goal_xyz"], g["goal_q"]
+            if k % 10 == 0 and k > 0:             # the carrot moves along the plan
+                c = synthetic.make_problems(1, 200, seed=1300 + 17 * ep + k)[0]
+                row["carrot_xy"], row["carrot_q"] = c["carrot_xy"], c["carrot_q"]
+            row["cur_xy"] = pos
+            row["cur_q"] = synthetic.yaw_quat(np.array(yaw))
+            row["cur_vel"] = vel
+            row["control_interval"] = dt_tick
+            step = dt_tick if k % 7 else 0.9       # irregular wall-clock gaps exercise the 3 s latch
+            if k == 0:
+                step = 0.0
+            clock.t += step
+            delta_t = clock.t - s.last_time       # what py:370 will compute
+            pts = footprint_world(row) if use_fp else []
+            ref.set_footprint(pts)
+            with contextlib.redirect_stdout(io.StringIO()):   # the reference print()s on collisions
+                resp = s.optimizer(ref.request(row), ros_stubs.Optimizer.Response())
+            out = np.array([resp.output_vel.twist.linear.x, resp.output_vel.twist.linear.y,
+                            resp.output_vel.twist.angular.z], dtype=np.float64)
+            prow = row.copy()
+            prow["delta_t"] = delta_t
+            rec["problems"].append(np.frombuffer(prow.tobytes(), dtype=np.uint8).copy())
+            rec["delta_t"].append(delta_t)
+            rec["raw_x"].append(captured["x"])
+            rec["success"].append(captured["success"])
+            rec["out"].append(out)
+            rec["init_guess"].append(np.array(s.initial_guess, dtype=np.float64).copy())
+            rec["last_control"].append(np.array(s.last_control, dtype=np.float64))
+            rec["collision"].append(bool(s.collision))
+            rec["collision_footprint"].append(bool(s.collision_footprint))
+            rec["waiting_time"].append(float(s.waiting_time))
+            fpa = np.full((4, 2), np.nan)
+            if use_fp:
+                fpa[:] = pts
+            rec["footprint"].append(fpa)
+            # the build's own integrator advances the robot
+            vel = out.copy()
+            yaw += vel[2] * dt_tick
+            pos = pos + dt_tick * np.array([vel[0] * math.cos(yaw) - vel[1] * math.sin(yaw),
+                                            vel[0] * math.sin(yaw) + vel[1] * math.cos(yaw)])
+    shape = (n_ep, n_calls)
+    np.savez_compressed(
+        os.path.join(OUT, "g4_episodes.npz"), versions=np.array(repr(versions())),
+        param_keys=np.array(PARAM_KEYS), params=params_vec(params), cells=cells,
+        map_meta=np.array(cmap[1:]),
+        problems=np.array(rec["problems"]).reshape(shape + (PROBLEM_DTYPE.itemsize,)),
+        delta_t=np.array(rec["delta_t"]).reshape(shape),
+        raw_x=np.array(rec["raw_x"]).reshape(shape + (9,)),
+        success=np.array(rec["success"]).reshape(shape),
+        out=np.array(rec["out"]).reshape(shape + (3,)),
+        init_guess=np.array(rec["init_guess"]).reshape(shape + (9,)),
+        last_control=np.array(rec["last_control"]).reshape(shape + (3,)),
+        collision=np.array(rec["collision"]).reshape(shape),
+        collision_footprint=np.array(rec["collision_footprint"]).reshape(shape),
+        waiting_time=np.array(rec["waiting_time"]).reshape(shape),
+        footprint=np.array(rec["footprint"]).reshape(shape + (4, 2)))
+    n_col = int(np.sum(rec["collision"]))
+    n_fp = int(np.sum(rec["collision_footprint"]))
+    print("G4: %d episodes x %d calls; collision-latched calls %d, footprint-collision calls %d"
+          % (n_ep, n_calls, n_col, n_fp))
+
+
+def gen_g5(mod):
+    rng = np.random.default_rng(105)
+    out = dict(versions=np.array(repr(versions())))
+    for n_steps in (1, 3, 8):
+        srv = Ref(mod, dict(README_PARAMS, control_steps=n_steps), None).srv
+        init = rng.normal(size=(16, 3 * n_steps))
+        guess = rng.normal(size=(16, 3 * n_steps))
+        res = np.array([srv.initial_guess_update(a.copy(), b.copy()) for a, b in zip(init, guess)])
+        out["n%d_init" % n_steps], out["n%d_guess" % n_steps] = init, guess
+        out["n%d_result" % n_steps] = res
+    np.savez_compressed(os.path.join(OUT, "g5_shift.npz"), **out)
+    print("G5: 3 x 16 cases")
+
+
+def gen_g6(mod):
+    """SciPy's forward-difference gradient of the reference objective (zero costmap)."""
+    from scipy.optimize._numdiff import approx_derivative
+    rng = np.random.default_rng(106)
+    out = dict(versions=np.array(repr(versions())), param_keys=np.array(PARAM_KEYS))
+    for n_steps in (3, 8):
+        params = dict(README_PARAMS, control_steps=n_steps)
+        zero = (np.zeros((200, 200), np.uint8), 0.05, -5.0, -5.0)
+        ref = Ref(mod, params, zero)
+        probs = synthetic.make_problems(32, 200, seed=600 + n_steps)
+        u = rng.uniform(-0.6, 0.6, size=(32, 3 * n_steps))
+        grads = np.zeros_like(u)
+        for j in range(32):
+            ref.load(probs[j])
+            grads[j] = approx_derivative(ref.srv.objective, u[j], method="2-point",
+                                         abs_step=math.sqrt(np.finfo(float).eps))
+        k = "n%d_" % n_steps
+        out[k + "params"] = params_vec(params)
+        out[k + "problems"] = probs.view(np.uint8).reshape(32, -1)
+        out[k + "u"], out[k + "grad"] = u, grads
+    np.savez_compressed(os.path.join(OUT, "g6_fd_gradient.npz"), **out)
+    print("G6: 2 x 32 cases")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    mod = ros_stubs.load_reference()
+    gen_g1(mod)
+    gen_g2(mod)
+    gen_g3(mod)
+    gen_g4(mod)
+    gen_g5(mod)
+    gen_g6(mod)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,122 @@
+"""The Python oracle (oracle/mpc_oracle.py) against vectors produced by the reference
+itself (tests/golden/, generator oracle/gen_golden.py).  Tiers P1 and P5 of SURVEY §8c."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import mpc_oracle as orc
+from tests import util
+
+
+@pytest.mark.parametrize("n_steps", [3, 8, 32])
+def test_g1_objective_and_constraint(n_steps):
+    g = util.load("g1_objective.npz")
+    k = "n%d_" % n_steps
+    params = util.params_from(g["param_keys"], g[k + "params"])
+    assert params["control_steps"] == n_steps
+    cmap = util.oracle_costmap(g[k + "cells"], g[k + "map_meta"])
+    probs = util.problems_from(g[k + "problems"])
+    worst = 0.0
+    for j in range(len(probs)):
+        prob = util.oracle_problem(probs[j], g[k + "footprint"][j])
+        f = orc.objective(g[k + "u"][j], prob, params, cmap)
+        ref = g[k + "objective"][j]
+        worst = max(worst, abs(f - ref) / max(1.0, abs(ref)))
+        assert abs(f - ref) <= 1e-12 * max(1.0, abs(ref)), (j, f, ref)
+        assert cmap.footprint_cost(prob.footprint) == g[k + "footprint_cost"][j]
+        for i in range(n_steps):
+            c = orc.f_constraint(g[k + "u"][j], i, params)
+            assert abs(c - g[k + "constraint"][j, i]) <= 1e-15
+    assert worst <= 1e-12
+
+
+def test_g1_covers_the_quirks():
+    """the fixture must actually exercise the lethal branch, the kink and OOB cells."""
+    g = util.load("g1_objective.npz")
+    assert (g["n3_objective"] > 300.0).any()          # a 1000*c^2/N lethal term (py:257-258)
+    assert (g["n32_footprint_cost"] == 1.0).any()     # w_footprint term active (py:262-263)
+    probs = util.problems_from(g["n3_problems"])
+    assert (g["n3_u"][0, 0:3] == probs["cur_vel"][0]).all()
+
+
+def test_g2_yaw():
+    g = util.load("g2_yaw.npz")
+    for q, rpy in zip(g["q_xyzw"], g["rpy"]):
+        assert orc.yaw_from_quaternion(*q) == rpy[2]
+    for yaw, q in zip(g["yaws"], g["quat_wxyz"]):
+        assert np.allclose(orc.quaternion_from_yaw(yaw), q, rtol=0, atol=1e-16)
+
+
+@pytest.mark.parametrize("n_steps", [1, 3, 8])
+def test_g5_shift(n_steps):
+    g = util.load("g5_shift.npz")
+    for a, b, r in zip(g["n%d_init" % n_steps], g["n%d_guess" % n_steps], g["n%d_result" % n_steps]):
+        assert (orc.initial_guess_update(a.copy(), b.copy(), n_steps) == r).all()
+
+
+def test_g3_slsqp_restated_objective_reproduces_reference_solves():
+    """SciPy SLSQP on the RESTATED objective walks the same iterates as on the
+    reference's objective (same SciPy version)."""
+    import scipy
+    g = util.load("g3_solves.npz")
+    if scipy.__version__ not in str(g["versions"]):
+        pytest.skip("fixture made with another SciPy")
+    params = util.params_from(g["param_keys"], g["params"])
+    cmaps = (util.oracle_costmap(np.zeros_like(g["cells"]), g["map_meta"]),
+             util.oracle_costmap(g["cells"], g["map_meta"]))
+    probs = util.problems_from(g["problems"])
+    for j in range(0, 32):
+        prob = util.oracle_problem(probs[j])
+        r = orc.solve_slsqp(prob, params, cmaps[g["has_map"][j]], np.zeros(9))
+        # 1-ulp differences in f are amplified by SciPy's 1.49e-8 forward-difference step,
+        # so iterates agree to ~1e-7, not to the last bit.
+        assert abs(r.nit - g["nit_loose"][j]) <= 1
+        assert np.allclose(r.x, g["x_loose"][j], rtol=0, atol=1e-5)
+        assert abs(r.fun - g["f_loose"][j]) <= 1e-8 * max(1.0, abs(r.fun))
+
+
+def test_g4_wrapper_episodes_with_injected_solver_output():
+    """P5: given the reference's raw solver output, the restated optimizer() wrapper
+    reproduces responses and state across 8 x 50 sequential calls."""
+    g = util.load("g4_episodes.npz")
+    params = util.params_from(g["param_keys"], g["params"])
+    cmap = util.oracle_costmap(g["cells"], g["map_meta"])
+    probs = util.problems_from(g["problems"])
+    n_ep, n_calls = probs.shape
+    for ep in range(n_ep):
+        state = orc.ServerState(3)
+        for k in range(n_calls):
+            prob = util.oracle_problem(probs[ep, k], g["footprint"][ep, k])
+            inject = (g["raw_x"][ep, k].copy(), bool(g["success"][ep, k]))
+            if k > 0:   # the warm start handed to the solver is the previous call's shift
+                assert (state.initial_guess == g["init_guess"][ep, k - 1]).all() or \
+                    (g["problems"][ep, k] != g["problems"][ep, k]).any()
+            out, _ = orc.optimizer_step(state, prob, params, cmap,
+                                        solver=lambda *a, inject=inject: inject)
+            assert np.allclose(out, g["out"][ep, k], rtol=0, atol=1e-15), (ep, k)
+            assert np.allclose(state.initial_guess, g["init_guess"][ep, k], rtol=0, atol=1e-15)
+            assert np.allclose(state.last_control, g["last_control"][ep, k], rtol=0, atol=1e-15)
+            assert state.collision == bool(g["collision"][ep, k]), (ep, k)
+            assert state.collision_footprint == bool(g["collision_footprint"][ep, k])
+            assert abs(state.waiting_time - g["waiting_time"][ep, k]) <= 1e-12
+
+
+def test_g4_full_episode_with_scipy():
+    """Same episodes, but re-solving with SciPy SLSQP on the restated objective.
+    Only the first calls are compared: SLSQP at ftol=1e-3 stops on an early iterate
+    that is chaotic in 1-ulp perturbations of f (by call 6 the reference path and
+    the restated path differ by 1.6e-3 in the command) -- see DESIGN.md "Parity"."""
+    import scipy
+    g = util.load("g4_episodes.npz")
+    if scipy.__version__ not in str(g["versions"]):
+        pytest.skip("fixture made with another SciPy")
+    params = util.params_from(g["param_keys"], g["params"])
+    cmap = util.oracle_costmap(g["cells"], g["map_meta"])
+    probs = util.problems_from(g["problems"])
+    for ep in (0, 1):
+        state = orc.ServerState(3)
+        for k in range(5):
+            prob = util.oracle_problem(probs[ep, k], g["footprint"][ep, k])
+            out, _ = orc.optimizer_step(state, prob, params, cmap)
+            assert np.allclose(out, g["out"][ep, k], rtol=0, atol=1e-5), (ep, k)
