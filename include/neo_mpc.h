@@ -1,0 +1,186 @@
+/*
+ * neo_mpc.h -- C-ABI of the MI355X-native batched MPC solver (libneo_mpc.so).
+ *
+ * Drop-in boundary for the optimisation inner loop of neobotix/neo_mpc_planner2.
+ * The entry points below are what `NeoMpcPlanner::computeVelocityCommands`
+ * (src/NeoMpcPlanner.cpp:240-252) binds INSTEAD of the blocking ROS2 service call
+ * to the Python node: one `neo_mpc_problem` carries exactly the fields of the
+ * `neo_srvs2/srv/Optimizer` request built at cpp:240-246, one `neo_mpc_command`
+ * the `output_vel` returned at cpp:250-252, `neo_mpc_params` the ROS parameters the
+ * node declares at neo_mpc_planner2/mpc_optimization_server.py:49-75, and
+ * `neo_mpc_state` the state the node keeps between calls (py:115-152).
+ *
+ * Conventions: plain C, no exceptions; every call returns NEO_MPC_OK (0) or a
+ * negative NEO_MPC_ERR_* code and `neo_mpc_last_error()` describes the failure;
+ * the library never retains caller pointers after a call returns; a handle is NOT
+ * thread-safe (the plugin already serialises under `mutex_`, cpp:207), distinct
+ * handles are independent.  There is no CPU fallback: `neo_mpc_create` fails when
+ * no gfx950 device is visible.
+ */
+#ifndef NEO_MPC_H_
+#define NEO_MPC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NEO_MPC_ABI_VERSION 1
+
+/* return codes */
+#define NEO_MPC_OK 0
+#define NEO_MPC_ERR_INVALID_ARGUMENT (-1)
+#define NEO_MPC_ERR_NO_DEVICE (-2)
+#define NEO_MPC_ERR_DEVICE (-3)      /* a HIP runtime call failed */
+#define NEO_MPC_ERR_NO_COSTMAP (-4)  /* solve before set_costmap */
+#define NEO_MPC_ERR_UNSUPPORTED (-5)
+
+/* per-instance solver status (neo_mpc_command.status); 0 <=> SciPy's `x.success` (py:397) */
+#define NEO_MPC_STATUS_CONVERGED 0
+#define NEO_MPC_STATUS_MAX_ITER 1
+
+/* neo_mpc_command.flags */
+#define NEO_MPC_FLAG_RESET 1   /* new goal: warm start / last_control / waiting_time reset (py:358-361) */
+#define NEO_MPC_FLAG_STOPPED 2 /* zero twist because of the collision latch (py:374-377) */
+
+/* neo_mpc_params.compat_flags */
+#define NEO_MPC_COMPAT_ODOM_YAW_GOAL_W 1 /* py:213: odom_yaw takes quaternion w from the goal pose */
+
+#define NEO_MPC_MAX_CONTROL_STEPS 64
+#define NEO_MPC_MAX_FOOTPRINT_POINTS 16
+#define NEO_MPC_MAX_LBFGS_MEMORY 8
+
+/* ROS parameters of the reference node, same names (py:49-75; README.md:53-84), then
+ * this build's solver options. */
+typedef struct neo_mpc_params {
+  double acc_x_limit, acc_y_limit, acc_theta_limit;          /* post-clamp py:385-391 */
+  double min_vel_x, min_vel_y, min_vel_trans, min_vel_theta; /* box bounds py:127-133 (min_vel_trans unused) */
+  double max_vel_x, max_vel_y, max_vel_trans, max_vel_theta; /* max_vel_trans: disc constraint py:157-158 */
+  double w_trans, w_orient, w_control, w_terminal;           /* py:252-253, 268 */
+  double w_costmap, w_footprint;                             /* py:260, 263 */
+  double waiting_time;                                       /* py:70 (initial value only, see py:361, 380) */
+  double low_pass_gain;                                      /* py:367 */
+  double opt_tolerance;                                      /* py:364 (SLSQP ftol) */
+  double prediction_horizon;                                 /* py:137 */
+  int32_t control_steps;                                     /* py:75 */
+  /* --- build-specific --- */
+  int32_t max_iterations; /* <=0: 100, SciPy SLSQP's maxiter */
+  int32_t lbfgs_memory;   /* <=0: 4 */
+  int32_t compat_flags;   /* NEO_MPC_COMPAT_*; neo_mpc_default_params sets all (parity mode) */
+  double step_tolerance;  /* stop when max|du| < this; <=0: 1e-3 * opt_tolerance */
+  double reserved[4];
+} neo_mpc_params;
+
+/* One Optimizer.srv request (cpp:240-246).  256 bytes. */
+typedef struct neo_mpc_problem {
+  double cur_xy[2];        /* current_pose.pose.position.{x,y}, costmap global frame (cpp:244) */
+  double cur_q[4];         /* current_pose.pose.orientation x,y,z,w */
+  double carrot_xy[2];     /* carrot_pose.pose.position.{x,y}, base frame (cpp:242) */
+  double carrot_q[4];      /* carrot_pose.pose.orientation x,y,z,w */
+  double goal_xyz[3];      /* goal_pose.position (cpp:243) */
+  double goal_q[4];        /* goal_pose.orientation x,y,z,w */
+  double cur_vel[3];       /* current_vel linear.x, linear.y, angular.z (cpp:241) */
+  double control_interval; /* 1/controller_frequency (cpp:246) */
+  double delta_t;          /* wall-clock seconds since the previous call (py:369-371) */
+  double footprint_cost;   /* normalised getFootprintCost(published footprint) (py:262, 343); used
+                              when the batch carries no polygons */
+  double reserved[7];
+} neo_mpc_problem;
+
+/* State the reference node keeps between requests (py:115-152).  128 bytes.  The warm
+ * start (`initial_guess`, py:136) is a separate double[3*control_steps] row per instance. */
+typedef struct neo_mpc_state {
+  double last_control[3];      /* py:117 */
+  double old_goal[7];          /* py:146, 402: position xyz + orientation xyzw */
+  double waiting_time;         /* py:103, 361, 378-382 */
+  int32_t has_old_goal;        /* 0 before the first call: py:146 compares PoseStamped with Pose */
+  int32_t collision;           /* py:148 latch */
+  int32_t collision_footprint; /* py:149 */
+  int32_t reserved_i;
+  double reserved[3];
+} neo_mpc_state;
+
+/* Optimizer.srv response (`output_vel.twist`, py:375-377, 389-391) + diagnostics.  48 bytes. */
+typedef struct neo_mpc_command {
+  double vel[3];       /* linear.x, linear.y, angular.z */
+  double cost;         /* objective at the raw solver output (SciPy `x.fun`) */
+  int32_t status;      /* NEO_MPC_STATUS_* */
+  int32_t iterations;  /* `x.nit` */
+  int32_t evaluations; /* objective evaluations per lane */
+  int32_t flags;       /* NEO_MPC_FLAG_* */
+} neo_mpc_command;
+
+/* One batch of independent instances.  All pointers are host pointers for
+ * neo_mpc_solve_batch / neo_mpc_postprocess_batch and device pointers for the
+ * *_device variants.  Optional members may be NULL. */
+typedef struct neo_mpc_batch {
+  size_t count;
+  const neo_mpc_problem* problems; /* [count] */
+  neo_mpc_state* states;           /* [count] in/out */
+  double* warm_start;              /* [count][3*control_steps] in/out (py:136, 397-400) */
+  neo_mpc_command* commands;       /* [count] out */
+  double* solution;                /* optional [count][3*control_steps]: raw solver output `x.x`
+                                      (out for solve, IN for postprocess) */
+  double* predicted_path;          /* optional out [count][control_steps][3]: X, Y, yaw of the
+                                      `local_plan` rollout (py:293-306) */
+  const double* footprints;        /* optional [count][footprint_points][2]: published footprint
+                                      polygon, global frame (py:140-144) */
+  uint32_t footprint_points;       /* 0: use problems[i].footprint_cost */
+  uint32_t reserved;
+} neo_mpc_batch;
+
+typedef struct neo_mpc_handle neo_mpc_handle;
+
+/* library / ABI */
+int neo_mpc_abi_version(void);
+const char* neo_mpc_last_error(void);
+
+/* Fills the defaults the reference node declares (py:49-75) and this build's solver options. */
+int neo_mpc_default_params(neo_mpc_params* params);
+
+/* Replaces `MpcOptimizationServer.__init__` (py:45-152) + the service client creation at
+ * cpp:308.  `device` is the HIP device ordinal.  NULL on failure. */
+neo_mpc_handle* neo_mpc_create(const neo_mpc_params* params, int device);
+void neo_mpc_destroy(neo_mpc_handle* handle);
+
+/* Dynamic reconfigure (`cb_params`, py:405-439).  Unlike the reference every field takes effect. */
+int neo_mpc_set_params(neo_mpc_handle* handle, const neo_mpc_params* params);
+int neo_mpc_get_params(const neo_mpc_handle* handle, neo_mpc_params* params);
+
+/* Replaces the node's `Costmap2d(self)` subscription (py:118): raw nav2 costs, row-major
+ * cells[my*size_x + mx] (e.g. `costmap_->getCharMap()` in the plugin).  The data is copied. */
+int neo_mpc_set_costmap(neo_mpc_handle* handle, const uint8_t* cells, uint32_t size_x,
+                        uint32_t size_y, double resolution, double origin_x, double origin_y);
+/* Same, `d_cells` already in device memory; ingested on `stream` (hipStream_t, may be NULL). */
+int neo_mpc_set_costmap_device(neo_mpc_handle* handle, const uint8_t* d_cells, uint32_t size_x,
+                               uint32_t size_y, double resolution, double origin_x,
+                               double origin_y, void* stream);
+
+/* Replaces `client->async_send_request(request); result.get()` (cpp:248-250), i.e. the whole of
+ * `MpcOptimizationServer.optimizer` (py:349-403), for `count` independent instances.
+ * Synchronous; host buffers are staged through device memory. */
+int neo_mpc_solve_batch(neo_mpc_handle* handle, const neo_mpc_batch* batch);
+/* Same with every pointer in device memory; enqueued on `stream`, returns without waiting. */
+int neo_mpc_solve_batch_device(neo_mpc_handle* handle, const neo_mpc_batch* batch, void* stream);
+
+/* Only the part of `optimizer` after the solve (py:365-403): low-pass, collision check, stop
+ * latch, acceleration clamp, warm-start shift, with `batch->solution` supplying `x.x` and
+ * `success[i]` supplying `x.success` (NULL: all true).  Host pointers. */
+int neo_mpc_postprocess_batch(neo_mpc_handle* handle, const neo_mpc_batch* batch,
+                              const int32_t* success);
+
+/* `MpcOptimizationServer.objective` (py:204-269) evaluated on the device for
+ * u[count][3*control_steps] (not projected); `footprint_cost` from problems[i].  Host pointers. */
+int neo_mpc_objective_batch(neo_mpc_handle* handle, const neo_mpc_problem* problems,
+                            const double* u, double* cost_out, size_t count);
+
+/* Bytes of LDS and costmap reach (cells) the solve kernel uses with the current params/map. */
+int neo_mpc_kernel_info(const neo_mpc_handle* handle, uint32_t* lds_bytes, uint32_t* reach_cells,
+                        uint32_t* tile_in_lds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEO_MPC_H_ */

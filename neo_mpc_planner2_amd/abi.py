@@ -63,3 +63,76 @@ def new_states(count, control_steps, waiting_time=3.0):
     st["waiting_time"] = waiting_time
     warm = np.zeros((count, 3 * control_steps), dtype=np.float64)
     return st, warm
+
+
+# ---------------------------------------------------------------------- ctypes mirrors
+import ctypes as _C  # noqa: E402
+
+
+class NeoMpcParams(_C.Structure):
+    """`neo_mpc_params` (include/neo_mpc.h): the reference node's ROS parameters, same
+    names (mpc_optimization_server.py:49-75), then the build's solver options."""
+    _fields_ = [(n, _C.c_double) for n in (
+        "acc_x_limit", "acc_y_limit", "acc_theta_limit",
+        "min_vel_x", "min_vel_y", "min_vel_trans", "min_vel_theta",
+        "max_vel_x", "max_vel_y", "max_vel_trans", "max_vel_theta",
+        "w_trans", "w_orient", "w_control", "w_terminal", "w_costmap", "w_footprint",
+        "waiting_time", "low_pass_gain", "opt_tolerance", "prediction_horizon")] + [
+        ("control_steps", _C.c_int32), ("max_iterations", _C.c_int32),
+        ("lbfgs_memory", _C.c_int32), ("compat_flags", _C.c_int32),
+        ("step_tolerance", _C.c_double), ("reserved", _C.c_double * 4)]
+
+
+ROS_PARAM_NAMES = tuple(n for n, _ in NeoMpcParams._fields_[:22])
+COMPAT_ODOM_YAW_GOAL_W = 1
+
+
+class NeoMpcBatch(_C.Structure):
+    """`neo_mpc_batch` (include/neo_mpc.h)."""
+    _fields_ = [("count", _C.c_size_t), ("problems", _C.c_void_p), ("states", _C.c_void_p),
+                ("warm_start", _C.c_void_p), ("commands", _C.c_void_p), ("solution", _C.c_void_p),
+                ("predicted_path", _C.c_void_p), ("footprints", _C.c_void_p),
+                ("footprint_points", _C.c_uint32), ("reserved", _C.c_uint32)]
+
+
+def params_struct(params=None, **over):
+    """dict of ROS parameter names (+ solver options) -> NeoMpcParams.  Missing names take
+    the reference node's declared defaults (py:49-75)."""
+    d = dict(
+        acc_x_limit=0.5, acc_y_limit=0.5, acc_theta_limit=0.5,
+        min_vel_x=-0.5, min_vel_y=-0.5, min_vel_trans=0.5, min_vel_theta=-0.5,
+        max_vel_x=0.5, max_vel_y=0.5, max_vel_trans=0.5, max_vel_theta=0.5,
+        w_trans=0.5, w_orient=0.5, w_control=0.5, w_terminal=0.5, w_costmap=0.5,
+        w_footprint=2000.0, waiting_time=3.0, low_pass_gain=0.5, opt_tolerance=1e-5,
+        prediction_horizon=0.5, control_steps=3,
+        max_iterations=100, lbfgs_memory=4, compat_flags=COMPAT_ODOM_YAW_GOAL_W,
+        step_tolerance=0.0)
+    if params:
+        d.update(params)
+    d.update(over)
+    s = NeoMpcParams()
+    for name, ctype in NeoMpcParams._fields_:
+        if name == "reserved":
+            continue
+        setattr(s, name, int(d[name]) if ctype is _C.c_int32 else float(d[name]))
+    return s
+
+
+def batch_struct(problems, states, warm, commands, solution=None, predicted_path=None,
+                 footprints=None, ptr=lambda a: a.ctypes.data):
+    """Build a NeoMpcBatch over arrays (NumPy by default; `ptr` extracts the address)."""
+    b = NeoMpcBatch()
+    b.count = int(problems.shape[0])
+    b.problems = ptr(problems)
+    b.states = ptr(states)
+    b.warm_start = ptr(warm)
+    b.commands = ptr(commands)
+    b.solution = ptr(solution) if solution is not None else None
+    b.predicted_path = ptr(predicted_path) if predicted_path is not None else None
+    if footprints is not None:
+        b.footprints = ptr(footprints)
+        b.footprint_points = int(footprints.shape[1])
+    else:
+        b.footprints = None
+        b.footprint_points = 0
+    return b

@@ -1,0 +1,619 @@
+/*
+ * mpc_oracle.c -- plain-C float64 CPU oracle for the MPC hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may build, load or call this file; the product
+ * (neo_mpc_planner2_amd/, libneo_mpc.so) never does.
+ *
+ * Part 1 restates the REFERENCE's arithmetic (py: = neo_mpc_planner2/
+ * mpc_optimization_server.py of neobotix/neo_mpc_planner2): yaw extraction, objective,
+ * disc constraint, collision check and the optimizer() wrapper.  It is pinned against
+ * outputs of the reference itself through tests/golden/ (oracle/gen_golden.py).
+ * The costmap lookup and SciPy's SLSQP are NOT in the reference (un-vendored
+ * dependencies): the costmap contract here is this build's own ("parity unpinned"
+ * at that boundary), SLSQP is exercised through oracle/mpc_oracle.py + SciPy.
+ *
+ * Part 2 is a scalar CPU mirror of the build's batched solver (the algorithm of
+ * neo_mpc_planner2_amd/csrc/neo_mpc_kernels.hip: L-BFGS / proximal-gradient
+ * projected arc search with 64 candidates per iteration), written independently of
+ * the HIP source so that GPU results can be checked against it on the same inputs.
+ *
+ * POD layouts come from include/neo_mpc.h (declarations only).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/neo_mpc.h"
+
+#define ORC_LANES 64
+#define ORC_MAXN NEO_MPC_MAX_CONTROL_STEPS
+#define ORC_MAXV (3 * ORC_MAXN)
+
+typedef struct orc_map {
+  const uint8_t* cells;
+  int32_t size_x, size_y;
+  double resolution, origin_x, origin_y;
+} orc_map;
+
+/* ------------------------------------------------------------------ costmap contract */
+/* nav2 Costmap2DPublisher translation: raw u8 -> occupancy [-1, 100]. */
+static int orc_occupancy(int raw) {
+  if (raw == 0) return 0;
+  if (raw == 253) return 99;
+  if (raw == 254) return 100;
+  if (raw == 255) return -1;
+  return 1 + (97 * (raw - 1)) / 251;
+}
+
+static void orc_world_to_map(const orc_map* m, double wx, double wy, int64_t* mx, int64_t* my) {
+  *mx = (int64_t)floor((wx - m->origin_x) / m->resolution);
+  *my = (int64_t)floor((wy - m->origin_y) / m->resolution);
+}
+
+static double orc_cost(const orc_map* m, int64_t mx, int64_t my) {
+  if (mx < 0 || my < 0 || mx >= m->size_x || my >= m->size_y) return 1.0;
+  return (double)orc_occupancy(m->cells[my * (int64_t)m->size_x + mx]) / 100.0;
+}
+
+/* max cell cost along the closed polygon outline (Bresenham, end points inclusive). */
+double orc_footprint_cost(const orc_map* m, const double* pts, int npts) {
+  if (npts <= 0) return 0.0;
+  double worst = -1.0;
+  for (int i = 0; i < npts; ++i) {
+    int64_t x0, y0, x1, y1;
+    int j = (i + 1) % npts;
+    orc_world_to_map(m, pts[2 * i], pts[2 * i + 1], &x0, &y0);
+    orc_world_to_map(m, pts[2 * j], pts[2 * j + 1], &x1, &y1);
+    int64_t dx = llabs(x1 - x0), dy = llabs(y1 - y0);
+    int64_t sx = x1 >= x0 ? 1 : -1, sy = y1 >= y0 ? 1 : -1;
+    int64_t err = dx - dy, x = x0, y = y0;
+    for (;;) {
+      double c = orc_cost(m, x, y);
+      if (c > worst) worst = c;
+      if (x == x1 && y == y1) break;
+      int64_t e2 = 2 * err;
+      if (e2 > -dy) { err -= dy; x += sx; }
+      if (e2 < dx) { err += dx; y += sy; }
+    }
+  }
+  return worst;
+}
+
+/* ------------------------------------------------------------------ Part 1: reference restatement */
+/* py:176-178 */
+double orc_yaw(double x, double y, double z, double w) {
+  double t3 = 2.0 * (w * z + x * y);
+  double t4 = 1.0 - 2.0 * (y * y + z * z);
+  return atan2(t3, t4);
+}
+
+/* py:157-158 */
+double orc_constraint(const neo_mpc_params* p, const double* u, int index) {
+  double vx = u[3 * index], vy = u[3 * index + 1];
+  return p->max_vel_trans - sqrt(vx * vx + vy * vy);
+}
+
+static double orc_odom_yaw(const neo_mpc_params* p, const neo_mpc_problem* q) {
+  /* py:213: w taken from the goal pose unless the compat flag is cleared */
+  double w = (p->compat_flags & NEO_MPC_COMPAT_ODOM_YAW_GOAL_W) ? q->goal_q[3] : q->cur_q[3];
+  return orc_yaw(q->cur_q[0], q->cur_q[1], q->cur_q[2], w);
+}
+
+/* py:204-269 */
+double orc_objective(const neo_mpc_params* p, const orc_map* m, const neo_mpc_problem* q,
+                     const double* u, double footprint_cost) {
+  const int n = p->control_steps;
+  const double dt = p->prediction_horizon / n; /* py:137 */
+  double target_yaw = orc_yaw(q->carrot_q[0], q->carrot_q[1], q->carrot_q[2], q->carrot_q[3]);
+  double final_yaw = orc_yaw(q->goal_q[0], q->goal_q[1], q->goal_q[2], q->goal_q[3]);
+  double odom_yaw = orc_odom_yaw(p, q);
+  double total = 0.0, x = 0.0, y = 0.0, z = 0.0;
+  double pos_x = q->cur_xy[0], pos_y = q->cur_xy[1];
+  for (int i = 0; i < n; ++i) {
+    double vx = u[3 * i], vy = u[3 * i + 1], wz = u[3 * i + 2];
+    z += wz * dt;                                              /* py:230 */
+    x += (vx * cos(z) * dt - vy * sin(z) * dt);               /* py:231 */
+    y += (vx * sin(z) * dt + vy * cos(z) * dt);               /* py:232 */
+    odom_yaw += wz * dt;                                       /* py:234 */
+    pos_x += vx * cos(odom_yaw) * dt - vy * sin(odom_yaw) * dt; /* py:235 */
+    pos_y += vx * sin(odom_yaw) * dt + vy * cos(odom_yaw) * dt; /* py:236 */
+    int64_t mx, my;
+    orc_world_to_map(m, pos_x, pos_y, &mx, &my);              /* py:246 */
+    double c = orc_cost(m, mx, my);
+    double costmap_cost = c * c;                               /* py:247 */
+    double ddx = q->carrot_xy[0] - x, ddy = q->carrot_xy[1] - y;
+    double dist = sqrt(ddx * ddx + ddy * ddy);                 /* py:250 */
+    double eth = target_yaw - z;                               /* py:251 */
+    total += ((p->w_trans * (dist * dist)) + (p->w_orient * (eth * eth))) / n; /* py:252 */
+    double e0 = q->cur_vel[0] - vx, e1 = q->cur_vel[1] - vy, e2 = q->cur_vel[2] - wz;
+    total += p->w_control * sqrt(e0 * e0 + e1 * e1 + e2 * e2) / n; /* py:253-254 */
+    if (c == 1.0) total += costmap_cost * 1000 / n;           /* py:257-258 */
+    else total += p->w_costmap * costmap_cost / n;            /* py:260 */
+    if (footprint_cost == 1.0)                                 /* py:262-263 */
+      total += (footprint_cost * footprint_cost) * p->w_footprint / n;
+  }
+  double gdx = q->carrot_xy[0] - q->goal_xyz[0], gdy = q->carrot_xy[1] - q->goal_xyz[1];
+  double gdist = sqrt(gdx * gdx + gdy * gdy);                  /* py:266 */
+  double eth = final_yaw - z;                                  /* py:267 */
+  total += ((p->w_trans * (gdist * gdist)) + (p->w_orient * (eth * eth))) * p->w_terminal;
+  return total;
+}
+
+/* py:312-341: returns 1 when a predicted cell costs >= 0.99 */
+static int orc_collision_check(const neo_mpc_params* p, const orc_map* m, const neo_mpc_problem* q,
+                               const double* x, double* path /* optional [n][3] */) {
+  const int n = p->control_steps;
+  const double dt = p->prediction_horizon / n;
+  double pos_x = q->cur_xy[0], pos_y = q->cur_xy[1];
+  double yaw = orc_yaw(q->cur_q[0], q->cur_q[1], q->cur_q[2], q->cur_q[3]); /* py:317 */
+  int hit = 0;
+  for (int i = 0; i < n; ++i) {
+    yaw += x[3 * i + 2] * dt;
+    pos_x += x[3 * i] * cos(yaw) * dt - x[3 * i + 1] * sin(yaw) * dt;
+    pos_y += x[3 * i] * sin(yaw) * dt + x[3 * i + 1] * cos(yaw) * dt;
+    if (path) { path[3 * i] = pos_x; path[3 * i + 1] = pos_y; path[3 * i + 2] = yaw; }
+    int64_t mx, my;
+    orc_world_to_map(m, pos_x, pos_y, &mx, &my);
+    if (!hit && orc_cost(m, mx, my) >= 0.99) { hit = 1; if (!path) break; }
+  }
+  return hit;
+}
+
+/* py:358-361: returns 1 when the reset was taken */
+static int orc_reset_if_new_goal(const neo_mpc_params* p, const neo_mpc_problem* q,
+                                 neo_mpc_state* st, double* warm) {
+  int same = st->has_old_goal;
+  for (int k = 0; k < 3 && same; ++k) same = (st->old_goal[k] == q->goal_xyz[k]);
+  for (int k = 0; k < 4 && same; ++k) same = (st->old_goal[3 + k] == q->goal_q[k]);
+  if (same) return 0;
+  for (int k = 0; k < 3 * p->control_steps; ++k) warm[k] = 0.0;
+  st->last_control[0] = st->last_control[1] = st->last_control[2] = 0.0;
+  st->waiting_time = 0.0;
+  return 1;
+}
+
+/* py:365-403 given the raw solver output x (modified in place like x.x) */
+static void orc_postprocess(const neo_mpc_params* p, const orc_map* m, const neo_mpc_problem* q,
+                            neo_mpc_state* st, double* warm, double* x, int success,
+                            double footprint_cost, neo_mpc_command* out, double* path) {
+  const int n = p->control_steps;
+  const double g = p->low_pass_gain;
+  if (path) { /* py:293-306 rolls out the UNFILTERED solution (publishLocalPlan precedes py:366) */
+    orc_collision_check(p, m, q, x, path);
+  }
+  for (int i = 0; i < 3; ++i) x[i] = x[i] * g + st->last_control[i] * (1 - g); /* py:366-367 */
+  if (orc_collision_check(p, m, q, x, NULL)) st->collision = 1;               /* py:338-341 */
+  st->collision_footprint = (footprint_cost == 1.0);                          /* py:343-347 */
+  if (st->collision || st->collision_footprint) {                             /* py:374-382 */
+    out->vel[0] = out->vel[1] = out->vel[2] = 0.0;
+    out->flags |= NEO_MPC_FLAG_STOPPED;
+    st->waiting_time += q->delta_t;
+    if (st->waiting_time >= 3.0) { st->collision = 0; st->waiting_time = 0.0; }
+  } else {                                                                    /* py:385-391 */
+    const double acc[3] = {p->acc_x_limit, p->acc_y_limit, p->acc_theta_limit};
+    for (int i = 0; i < 3; ++i) {
+      double t = fmin(x[i], st->last_control[i] + acc[i] * q->control_interval);
+      out->vel[i] = fmax(t, st->last_control[i] - acc[i] * q->control_interval);
+    }
+  }
+  for (int i = 0; i < 3; ++i) st->last_control[i] = out->vel[i];              /* py:393-395 */
+  if (success) {                                                              /* py:397-398, 198-202 */
+    for (int i = 0; i < n - 1; ++i)
+      for (int k = 0; k < 3; ++k) warm[3 * i + k] = x[3 * i + 3 + k];
+    for (int k = 0; k < 3; ++k) warm[3 * (n - 1) + k] = x[k];
+  } else {                                                                    /* py:399-400 */
+    for (int k = 0; k < 3 * n; ++k) warm[k] = x[k];
+  }
+  for (int k = 0; k < 3; ++k) st->old_goal[k] = q->goal_xyz[k];               /* py:402 */
+  for (int k = 0; k < 4; ++k) st->old_goal[3 + k] = q->goal_q[k];
+  st->has_old_goal = 1;
+}
+
+/* ------------------------------------------------------------------ Part 2: CPU mirror of the build's solver */
+typedef struct orc_ctx {
+  int n;
+  double dt, wt_n, wo_n, wc_n, wterm_o;
+  double cx, cy, tyaw, fyaw, c0, s0, X0, Y0, v[3];
+  double konst;          /* terms constant in u: terminal distance + footprint */
+  double term[256];      /* per-step costmap term by raw cell value */
+  double lo[3], hi[3], r;
+  const orc_map* map;
+} orc_ctx;
+
+static void orc_ctx_init(orc_ctx* c, const neo_mpc_params* p, const orc_map* m,
+                         const neo_mpc_problem* q, double footprint_cost) {
+  const int n = p->control_steps;
+  c->n = n;
+  c->dt = p->prediction_horizon / n;
+  c->wt_n = p->w_trans / n;
+  c->wo_n = p->w_orient / n;
+  c->wc_n = p->w_control / n;
+  c->wterm_o = p->w_terminal * p->w_orient;
+  c->cx = q->carrot_xy[0];
+  c->cy = q->carrot_xy[1];
+  c->tyaw = orc_yaw(q->carrot_q[0], q->carrot_q[1], q->carrot_q[2], q->carrot_q[3]);
+  c->fyaw = orc_yaw(q->goal_q[0], q->goal_q[1], q->goal_q[2], q->goal_q[3]);
+  double psi0 = orc_odom_yaw(p, q);
+  c->c0 = cos(psi0);
+  c->s0 = sin(psi0);
+  c->X0 = q->cur_xy[0];
+  c->Y0 = q->cur_xy[1];
+  for (int k = 0; k < 3; ++k) c->v[k] = q->cur_vel[k];
+  double gdx = c->cx - q->goal_xyz[0], gdy = c->cy - q->goal_xyz[1];
+  c->konst = p->w_terminal * p->w_trans * (gdx * gdx + gdy * gdy);
+  if (footprint_cost == 1.0) c->konst += p->w_footprint;
+  for (int raw = 0; raw < 256; ++raw) {
+    double cc = (double)orc_occupancy(raw) / 100.0;
+    c->term[raw] = (cc == 1.0) ? cc * cc * 1000 / n : p->w_costmap * (cc * cc) / n;
+  }
+  c->lo[0] = p->min_vel_x; c->hi[0] = p->max_vel_x;
+  c->lo[1] = p->min_vel_y; c->hi[1] = p->max_vel_y;
+  c->lo[2] = p->min_vel_theta; c->hi[2] = p->max_vel_theta;
+  c->r = p->max_vel_trans;
+  c->map = m;
+}
+
+static double orc_clamp(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* Euclidean projection of (vx, vy) onto box ∩ disc, omega clamped (py:125-134 feasible set). */
+static void orc_project(const orc_ctx* c, double* b) {
+  b[2] = orc_clamp(b[2], c->lo[2], c->hi[2]);
+  const double zx = b[0], zy = b[1], r = c->r;
+  double px = orc_clamp(zx, c->lo[0], c->hi[0]), py = orc_clamp(zy, c->lo[1], c->hi[1]);
+  if (px * px + py * py <= r * r) { b[0] = px; b[1] = py; return; }
+  double nz = sqrt(zx * zx + zy * zy);
+  double qx = zx * (r / nz), qy = zy * (r / nz);
+  if (qx >= c->lo[0] && qx <= c->hi[0] && qy >= c->lo[1] && qy <= c->hi[1]) { b[0] = qx; b[1] = qy; return; }
+  /* both constraints bind: closest circle/box-edge intersection point */
+  double best = INFINITY, bx = px, by = py;
+  for (int e = 0; e < 4; ++e) {
+    double fixed = (e == 0) ? c->lo[0] : (e == 1) ? c->hi[0] : (e == 2) ? c->lo[1] : c->hi[1];
+    if (fabs(fixed) > r) continue;
+    double o = sqrt(r * r - fixed * fixed);
+    for (int s = -1; s <= 1; s += 2) {
+      double ex = (e < 2) ? fixed : s * o, ey = (e < 2) ? s * o : fixed;
+      if (ex < c->lo[0] || ex > c->hi[0] || ey < c->lo[1] || ey > c->hi[1]) continue;
+      double d = (ex - zx) * (ex - zx) + (ey - zy) * (ey - zy);
+      if (d < best) { best = d; bx = ex; by = ey; }
+    }
+  }
+  b[0] = bx; b[1] = by;
+}
+
+static double orc_step_term(const orc_ctx* c, double x, double y) {
+  double X = c->X0 + (c->c0 * x - c->s0 * y), Y = c->Y0 + (c->s0 * x + c->c0 * y);
+  int64_t mx, my;
+  orc_world_to_map(c->map, X, Y, &mx, &my);
+  int raw = 254;
+  if (mx >= 0 && my >= 0 && mx < c->map->size_x && my < c->map->size_y)
+    raw = c->map->cells[my * (int64_t)c->map->size_x + mx];
+  return c->term[raw];
+}
+
+/* the solver's objective (same value as orc_objective up to rounding) */
+static double orc_eval(const orc_ctx* c, const double* u) {
+  double f = 0.0, x = 0.0, y = 0.0, th = 0.0;
+  for (int i = 0; i < c->n; ++i) {
+    double vx = u[3 * i], vy = u[3 * i + 1], w = u[3 * i + 2];
+    th += w * c->dt;
+    double cs = cos(th), sn = sin(th);
+    x += (vx * cs - vy * sn) * c->dt;
+    y += (vx * sn + vy * cs) * c->dt;
+    double dx = c->cx - x, dy = c->cy - y, et = c->tyaw - th;
+    double e0 = c->v[0] - vx, e1 = c->v[1] - vy, e2 = c->v[2] - w;
+    f += c->wt_n * (dx * dx + dy * dy) + c->wo_n * (et * et);
+    f += c->wc_n * sqrt(e0 * e0 + e1 * e1 + e2 * e2);
+    f += orc_step_term(c, x, y);
+  }
+  double et = c->fyaw - th;
+  return f + c->wterm_o * (et * et) + c->konst;
+}
+
+/* gradient of the smooth (tracking + terminal) part, adjoint sweep */
+static void orc_grad_smooth(const orc_ctx* c, const double* u, double* g) {
+  const int n = c->n;
+  double cs[ORC_MAXN], sn[ORC_MAXN], dxs[ORC_MAXN], dys[ORC_MAXN], rx[ORC_MAXN], ry[ORC_MAXN], rt[ORC_MAXN];
+  double x = 0.0, y = 0.0, th = 0.0;
+  for (int i = 0; i < n; ++i) {
+    double vx = u[3 * i], vy = u[3 * i + 1], w = u[3 * i + 2];
+    th += w * c->dt;
+    cs[i] = cos(th); sn[i] = sin(th);
+    dxs[i] = (vx * cs[i] - vy * sn[i]) * c->dt;
+    dys[i] = (vx * sn[i] + vy * cs[i]) * c->dt;
+    x += dxs[i]; y += dys[i];
+    rx[i] = -2.0 * c->wt_n * (c->cx - x);
+    ry[i] = -2.0 * c->wt_n * (c->cy - y);
+    rt[i] = -2.0 * c->wo_n * (c->tyaw - th);
+  }
+  rt[n - 1] += -2.0 * c->wterm_o * (c->fyaw - th);
+  double SX = 0.0, SY = 0.0, ST = 0.0;
+  for (int k = n - 1; k >= 0; --k) {
+    SX += rx[k]; SY += ry[k];
+    ST += rt[k] - dys[k] * SX + dxs[k] * SY;
+    g[3 * k] = c->dt * (cs[k] * SX + sn[k] * SY);
+    g[3 * k + 1] = c->dt * (-sn[k] * SX + cs[k] * SY);
+    g[3 * k + 2] = c->dt * ST;
+  }
+}
+
+/* total gradient gt (smooth + control-norm, minimal-norm subgradient at the kink), reduced
+ * gradient gr = minus the projection of -gt onto the tangent cone of the feasible set at u,
+ * and the active-set description used to restrict the quasi-Newton direction. */
+typedef struct orc_active {
+  uint8_t wfroz[ORC_MAXN]; /* omega at a bound, gradient pushing outward */
+  uint8_t mode[ORC_MAXN];  /* (vx, vy): 0 free, 1 slide along the constraint with normal n, 2 pinned */
+  double nx[ORC_MAXN], ny[ORC_MAXN];
+} orc_active;
+
+static void orc_reduce(const orc_ctx* c, const double* u, const double* gs, double* gt, double* gr,
+                       orc_active* a) {
+  for (int i = 0; i < c->n; ++i) {
+    const double* ui = u + 3 * i;
+    const double* gsi = gs + 3 * i;
+    double e[3] = {ui[0] - c->v[0], ui[1] - c->v[1], ui[2] - c->v[2]};
+    double ne = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    double gi[3];
+    if (ne > 0.0) {
+      for (int k = 0; k < 3; ++k) gi[k] = gsi[k] + c->wc_n * (e[k] / ne);
+    } else {
+      double ng = sqrt(gsi[0] * gsi[0] + gsi[1] * gsi[1] + gsi[2] * gsi[2]);
+      double sh = (ng > c->wc_n) ? 1.0 - c->wc_n / ng : 0.0;
+      for (int k = 0; k < 3; ++k) gi[k] = gsi[k] * sh;
+    }
+    for (int k = 0; k < 3; ++k) { gt[3 * i + k] = gi[k]; gr[3 * i + k] = gi[k]; }
+    /* omega: plain bound */
+    a->wfroz[i] = (ui[2] <= c->lo[2] && gi[2] > 0.0) || (ui[2] >= c->hi[2] && gi[2] < 0.0);
+    if (a->wfroz[i]) gr[3 * i + 2] = 0.0;
+    /* (vx, vy): outward normals of the constraints active at u */
+    double nx[3], ny[3];
+    int na = 0;
+    if (ui[0] <= c->lo[0]) { nx[na] = -1.0; ny[na] = 0.0; ++na; }
+    else if (ui[0] >= c->hi[0]) { nx[na] = 1.0; ny[na] = 0.0; ++na; }
+    if (ui[1] <= c->lo[1]) { nx[na] = 0.0; ny[na] = -1.0; ++na; }
+    else if (ui[1] >= c->hi[1]) { nx[na] = 0.0; ny[na] = 1.0; ++na; }
+    double nv = sqrt(ui[0] * ui[0] + ui[1] * ui[1]);
+    if (nv > 0.0 && nv >= c->r * (1.0 - 1e-12)) { nx[na] = ui[0] / nv; ny[na] = ui[1] / nv; ++na; }
+    const double dx = -gi[0], dy = -gi[1]; /* steepest descent */
+    a->mode[i] = 0; a->nx[i] = 0.0; a->ny[i] = 0.0;
+    int violated = 0;
+    for (int k = 0; k < na; ++k) if (nx[k] * dx + ny[k] * dy > 0.0) violated = 1;
+    if (violated) {
+      double bestn = -1.0;
+      int bestk = -1;
+      for (int k = 0; k < na; ++k) {
+        double dn = nx[k] * dx + ny[k] * dy;
+        if (!(dn > 0.0)) continue;
+        double px = dx - dn * nx[k], py = dy - dn * ny[k];
+        int ok = 1;
+        for (int j = 0; j < na; ++j)
+          if (j != k && nx[j] * px + ny[j] * py > 1e-14 * (fabs(px) + fabs(py))) ok = 0;
+        double pn = px * px + py * py;
+        if (ok && pn > bestn) { bestn = pn; bestk = k; }
+      }
+      if (bestk >= 0) {
+        double dn = nx[bestk] * dx + ny[bestk] * dy;
+        a->mode[i] = 1; a->nx[i] = nx[bestk]; a->ny[i] = ny[bestk];
+        gr[3 * i] = -(dx - dn * nx[bestk]);
+        gr[3 * i + 1] = -(dy - dn * ny[bestk]);
+      } else {
+        a->mode[i] = 2;
+        gr[3 * i] = 0.0; gr[3 * i + 1] = 0.0;
+      }
+    }
+  }
+}
+
+static void orc_apply_active(const orc_ctx* c, const orc_active* a, double* d) {
+  for (int i = 0; i < c->n; ++i) {
+    if (a->wfroz[i]) d[3 * i + 2] = 0.0;
+    if (a->mode[i] == 1) {
+      double dot = d[3 * i] * a->nx[i] + d[3 * i + 1] * a->ny[i];
+      d[3 * i] -= dot * a->nx[i]; d[3 * i + 1] -= dot * a->ny[i];
+    } else if (a->mode[i] == 2) {
+      d[3 * i] = 0.0; d[3 * i + 1] = 0.0;
+    }
+  }
+}
+
+static double orc_dot(const double* a, const double* b, int n) {
+  double s = 0.0;
+  for (int k = 0; k < n; ++k) s += a[k] * b[k];
+  return s;
+}
+
+/* candidate step multipliers: lanes 0..31 scale the proximal-gradient step alpha by
+ * 2^(-12 + l/2); lanes 32..63 are step lengths along the L-BFGS direction. */
+static const double ORC_QN_T[32] = {
+    1.0, 0.84, 1.19, 0.71, 1.41, 0.59, 1.68, 0.5, 2.0, 0.42, 2.38, 0.35, 2.83, 0.25, 4.0, 0.177,
+    0.125, 0.088, 0.0625, 0.044, 0.03125, 0.0156, 0.0078, 0.0039, 0.00195, 0.00098, 4.9e-4, 2.4e-4,
+    1.2e-4, 6e-5, 3e-5, 1.5e-5};
+
+static double orc_lane_scale(int lane) {
+  if (lane >= 32) return ORC_QN_T[lane - 32];
+  double s = ldexp(1.0, -12 + (lane >> 1));
+  return (lane & 1) ? s * 1.4142135623730951 : s;
+}
+
+static void orc_candidate(const orc_ctx* c, int lane, double alpha, const double* u,
+                          const double* gs, const double* d, double* cand) {
+  const double sc = orc_lane_scale(lane);
+  for (int i = 0; i < c->n; ++i) {
+    double b[3];
+    if (lane < 32) {
+      const double a = alpha * sc;
+      double e[3], ne2 = 0.0;
+      for (int k = 0; k < 3; ++k) { e[k] = (u[3 * i + k] - a * gs[3 * i + k]) - c->v[k]; ne2 += e[k] * e[k]; }
+      double ne = sqrt(ne2);
+      double sh = (ne > 0.0) ? fmax(0.0, 1.0 - a * c->wc_n / ne) : 0.0;
+      for (int k = 0; k < 3; ++k) b[k] = c->v[k] + sh * e[k];
+    } else {
+      for (int k = 0; k < 3; ++k) b[k] = u[3 * i + k] + sc * d[3 * i + k];
+    }
+    orc_project(c, b);
+    for (int k = 0; k < 3; ++k) cand[3 * i + k] = b[k];
+  }
+}
+
+/* Returns status; x_out = minimiser estimate, *f_out its objective. */
+int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_problem* q,
+                 double footprint_cost, const double* x0, double* x_out, double* f_out,
+                 int32_t* nit_out, int32_t* nfev_out) {
+  orc_ctx c;
+  orc_ctx_init(&c, p, m, q, footprint_cost);
+  const int n = c.n, nv = 3 * n;
+  const int max_it = p->max_iterations > 0 ? p->max_iterations : 100;
+  int mem = p->lbfgs_memory > 0 ? p->lbfgs_memory : 4;
+  if (mem > NEO_MPC_MAX_LBFGS_MEMORY) mem = NEO_MPC_MAX_LBFGS_MEMORY;
+  const double xtol = p->step_tolerance > 0.0 ? p->step_tolerance : 1e-3 * p->opt_tolerance;
+
+  double u[ORC_MAXV], gs[ORC_MAXV], gt[ORC_MAXV], gr[ORC_MAXV], d[ORC_MAXV];
+  double u_prev[ORC_MAXV], gt_prev[ORC_MAXV], cand[ORC_MAXV], best_c[ORC_MAXV];
+  static _Thread_local double S[NEO_MPC_MAX_LBFGS_MEMORY][ORC_MAXV], Y[NEO_MPC_MAX_LBFGS_MEMORY][ORC_MAXV];
+  double rho[NEO_MPC_MAX_LBFGS_MEMORY];
+  int npairs = 0, head = 0; /* ring: newest at (head-1) mod mem */
+  orc_active act;
+
+  for (int i = 0; i < n; ++i) {
+    double b[3] = {x0[3 * i], x0[3 * i + 1], x0[3 * i + 2]};
+    orc_project(&c, b);
+    u[3 * i] = b[0]; u[3 * i + 1] = b[1]; u[3 * i + 2] = b[2];
+  }
+  double f = orc_eval(&c, u);
+  double alpha = 1.0;
+  int nfev = 1, it = 0, status = NEO_MPC_STATUS_MAX_ITER;
+  for (it = 0; it < max_it; ++it) {
+    orc_grad_smooth(&c, u, gs);
+    orc_reduce(&c, u, gs, gt, gr, &act);
+    if (it > 0) {
+      double* s = S[head];
+      double* y = Y[head];
+      for (int k = 0; k < nv; ++k) { s[k] = u[k] - u_prev[k]; y[k] = gt[k] - gt_prev[k]; }
+      double sy = orc_dot(s, y, nv), ss = orc_dot(s, s, nv), yy = orc_dot(y, y, nv);
+      if (ss > 0.0 && sy > 1e-10 * sqrt(ss * yy)) {
+        rho[head] = 1.0 / sy;
+        head = (head + 1) % mem;
+        if (npairs < mem) ++npairs;
+      }
+    }
+    /* two-loop recursion on the reduced gradient */
+    {
+      double al[NEO_MPC_MAX_LBFGS_MEMORY];
+      for (int k = 0; k < nv; ++k) d[k] = gr[k];
+      for (int j = 0; j < npairs; ++j) {
+        int idx = (head - 1 - j + 2 * mem) % mem;
+        al[j] = rho[idx] * orc_dot(S[idx], d, nv);
+        for (int k = 0; k < nv; ++k) d[k] -= al[j] * Y[idx][k];
+      }
+      double gamma = 1.0;
+      if (npairs > 0) {
+        int idx = (head - 1 + mem) % mem;
+        gamma = 1.0 / (rho[idx] * orc_dot(Y[idx], Y[idx], nv));
+      }
+      for (int k = 0; k < nv; ++k) d[k] *= gamma;
+      for (int j = npairs - 1; j >= 0; --j) {
+        int idx = (head - 1 - j + 2 * mem) % mem;
+        double be = rho[idx] * orc_dot(Y[idx], d, nv);
+        for (int k = 0; k < nv; ++k) d[k] += S[idx][k] * (al[j] - be);
+      }
+      for (int k = 0; k < nv; ++k) d[k] = -d[k];
+      orc_apply_active(&c, &act, d);
+    }
+    /* 64 candidates, lowest objective wins (ties: lowest lane) */
+    double fb = INFINITY;
+    int best = -1;
+    for (int lane = 0; lane < ORC_LANES; ++lane) {
+      orc_candidate(&c, lane, alpha, u, gs, d, cand);
+      double fc = orc_eval(&c, cand);
+      if (fc < fb) { fb = fc; best = lane; memcpy(best_c, cand, sizeof(double) * nv); }
+    }
+    ++nfev;
+    if (!(fb < f)) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
+    double step = 0.0;
+    for (int k = 0; k < nv; ++k) {
+      double ad = fabs(best_c[k] - u[k]);
+      if (ad > step) step = ad;
+      u_prev[k] = u[k]; gt_prev[k] = gt[k]; u[k] = best_c[k];
+    }
+    f = fb;
+    if (best < 32) {
+      alpha *= orc_lane_scale(best);
+      alpha = orc_clamp(alpha, 1e-6, 1e6);
+    }
+    if (step < xtol) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
+  }
+  memcpy(x_out, u, sizeof(double) * nv);
+  *f_out = f;
+  if (nit_out) *nit_out = it;
+  if (nfev_out) *nfev_out = nfev;
+  return status;
+}
+
+/* ------------------------------------------------------------------ batch entry points (ctypes) */
+static orc_map orc_make_map(const uint8_t* cells, int32_t sx, int32_t sy, double res, double ox, double oy) {
+  orc_map m = {cells, sx, sy, res, ox, oy};
+  return m;
+}
+
+static double orc_batch_footprint(const orc_map* m, const neo_mpc_batch* b, size_t i) {
+  if (b->footprints && b->footprint_points > 0)
+    return orc_footprint_cost(m, b->footprints + i * 2 * b->footprint_points, (int)b->footprint_points);
+  return b->problems[i].footprint_cost;
+}
+
+void orc_objective_batch(const neo_mpc_params* p, const uint8_t* cells, int32_t sx, int32_t sy,
+                         double res, double ox, double oy, const neo_mpc_problem* probs,
+                         const double* u, double* f_out, size_t count) {
+  orc_map m = orc_make_map(cells, sx, sy, res, ox, oy);
+  for (size_t i = 0; i < count; ++i)
+    f_out[i] = orc_objective(p, &m, &probs[i], u + i * 3 * p->control_steps, probs[i].footprint_cost);
+}
+
+void orc_footprint_cost_batch(const uint8_t* cells, int32_t sx, int32_t sy, double res, double ox,
+                              double oy, const double* pts, int npts, double* out, size_t count) {
+  orc_map m = orc_make_map(cells, sx, sy, res, ox, oy);
+  for (size_t i = 0; i < count; ++i) out[i] = orc_footprint_cost(&m, pts + i * 2 * npts, npts);
+}
+
+/* wrapper only (P5): batch->solution supplies x.x, success[] supplies x.success */
+void orc_postprocess_batch(const neo_mpc_params* p, const uint8_t* cells, int32_t sx, int32_t sy,
+                           double res, double ox, double oy, const neo_mpc_batch* b,
+                           const int32_t* success) {
+  orc_map m = orc_make_map(cells, sx, sy, res, ox, oy);
+  const int nv = 3 * p->control_steps;
+  for (size_t i = 0; i < b->count; ++i) {
+    neo_mpc_command* out = &b->commands[i];
+    memset(out, 0, sizeof(*out));
+    double* warm = b->warm_start + i * nv;
+    if (orc_reset_if_new_goal(p, &b->problems[i], &b->states[i], warm)) out->flags |= NEO_MPC_FLAG_RESET;
+    double x[ORC_MAXV];
+    memcpy(x, b->solution + i * nv, sizeof(double) * nv);
+    double fc = orc_batch_footprint(&m, b, i);
+    out->cost = orc_objective(p, &m, &b->problems[i], x, fc);
+    orc_postprocess(p, &m, &b->problems[i], &b->states[i], warm, x, success ? success[i] : 1, fc, out,
+                    b->predicted_path ? b->predicted_path + i * nv : NULL);
+  }
+}
+
+/* full path with the build's solver: reset -> pg_solve -> postprocess */
+void orc_solve_batch(const neo_mpc_params* p, const uint8_t* cells, int32_t sx, int32_t sy,
+                     double res, double ox, double oy, const neo_mpc_batch* b) {
+  orc_map m = orc_make_map(cells, sx, sy, res, ox, oy);
+  const int nv = 3 * p->control_steps;
+#pragma omp parallel for schedule(dynamic, 16)
+  for (long long ii = 0; ii < (long long)b->count; ++ii) {
+    size_t i = (size_t)ii;
+    neo_mpc_command* out = &b->commands[i];
+    memset(out, 0, sizeof(*out));
+    double* warm = b->warm_start + i * nv;
+    if (orc_reset_if_new_goal(p, &b->problems[i], &b->states[i], warm)) out->flags |= NEO_MPC_FLAG_RESET;
+    double fc = orc_batch_footprint(&m, b, i);
+    double x[ORC_MAXV], f;
+    out->status = orc_pg_solve(p, &m, &b->problems[i], fc, warm, x, &f, &out->iterations, &out->evaluations);
+    out->cost = f;
+    if (b->solution) memcpy(b->solution + i * nv, x, sizeof(double) * nv);
+    orc_postprocess(p, &m, &b->problems[i], &b->states[i], warm, x, out->status == NEO_MPC_STATUS_CONVERGED,
+                    fc, out, b->predicted_path ? b->predicted_path + i * nv : NULL);
+  }
+}

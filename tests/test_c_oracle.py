@@ -1,0 +1,123 @@
+"""The plain-C oracle (oracle/mpc_oracle.c) against the reference's golden vectors and
+against the Python restatement; and the CPU mirror of the build's solver against SciPy
+SLSQP solves of the reference (tiers P2/P3 of SURVEY §8c)."""
+import numpy as np
+import pytest
+
+from neo_mpc_planner2_amd import abi, synthetic
+from oracle import c_oracle
+from oracle import mpc_oracle as orc
+from tests import util
+
+
+@pytest.mark.parametrize("n_steps", [3, 8, 32])
+def test_g1_objective(n_steps):
+    g = util.load("g1_objective.npz")
+    k = "n%d_" % n_steps
+    params = util.params_from(g["param_keys"], g[k + "params"])
+    cmap = (g[k + "cells"],) + tuple(g[k + "map_meta"])
+    probs = util.problems_from(g[k + "problems"]).copy()
+    probs["footprint_cost"] = g[k + "footprint_cost"]
+    f = c_oracle.objective_batch(params, cmap, probs, g[k + "u"])
+    ref = g[k + "objective"]
+    assert np.all(np.abs(f - ref) <= 1e-12 * np.maximum(1.0, np.abs(ref)))
+    # the rasterised footprint cost itself
+    fp = g[k + "footprint"]
+    has = ~np.isnan(fp).any(axis=(1, 2))
+    fc = c_oracle.footprint_cost_batch(cmap, fp[has])
+    assert (fc == g[k + "footprint_cost"][has]).all()
+
+
+def test_g2_yaw():
+    g = util.load("g2_yaw.npz")
+    for q, rpy in zip(g["q_xyzw"], g["rpy"]):
+        assert c_oracle.yaw(*q) == rpy[2]
+
+
+def test_g4_wrapper_episodes_injected():
+    """P5 for the C wrapper: responses and state over 8 x 50 calls, reference x.x injected."""
+    g = util.load("g4_episodes.npz")
+    params = util.params_from(g["param_keys"], g["params"])
+    cmap = (g["cells"],) + tuple(g["map_meta"])
+    probs = util.problems_from(g["problems"])
+    n_ep, n_calls = probs.shape
+    states, warm = abi.new_states(n_ep, 3)
+    for k in range(n_calls):
+        fp = g["footprint"][:, k]
+        rows = probs[:, k].copy()
+        has = ~np.isnan(fp).any(axis=(1, 2))
+        rows["footprint_cost"] = 0.0
+        if has.any():
+            rows["footprint_cost"][has] = c_oracle.footprint_cost_batch(cmap, fp[has])
+        cmds, _, _ = c_oracle.postprocess_batch(params, cmap, rows, states, warm, g["raw_x"][:, k],
+                                               g["success"][:, k].astype(np.int32))
+        assert np.allclose(cmds["vel"], g["out"][:, k], rtol=0, atol=1e-15), k
+        assert np.allclose(warm, g["init_guess"][:, k], rtol=0, atol=1e-15), k
+        assert np.allclose(states["last_control"], g["last_control"][:, k], rtol=0, atol=1e-15)
+        assert (states["collision"] == g["collision"][:, k]).all(), k
+        assert (states["collision_footprint"] == g["collision_footprint"][:, k]).all(), k
+        assert np.allclose(states["waiting_time"], g["waiting_time"][:, k], rtol=0, atol=1e-12)
+        assert ((cmds["flags"] & abi.FLAG_RESET) != 0).tolist() == \
+            [k == 0 or (k == 25 and ep % 2 == 1) for ep in range(n_ep)]
+
+
+def _g3():
+    g = util.load("g3_solves.npz")
+    params = util.params_from(g["param_keys"], g["params"])
+    probs = util.problems_from(g["problems"])
+    hm = g["has_map"].astype(bool)
+    return g, params, probs, hm
+
+
+def _cold_solve(params, cmap, probs):
+    st, warm = synthetic.make_states(probs, params["control_steps"])
+    cmds, x, _ = c_oracle.solve_batch(params, cmap, probs, st, warm)
+    return cmds, x
+
+
+def test_p2_solver_mirror_matches_tight_slsqp_where_unique():
+    """P2: zero costmap (unique minimiser): first control within 1e-3 of SciPy SLSQP at
+    ftol=1e-12 run on the REFERENCE's objective; objective not worse."""
+    g, params, probs, hm = _g3()
+    zero = (np.zeros_like(g["cells"]),) + tuple(g["map_meta"])
+    cmds, x = _cold_solve(params, zero, probs[~hm])
+    du0 = np.abs(x[:, :3] - g["x_tight"][~hm][:, :3]).max(axis=1)
+    assert du0.max() <= 1e-3, du0.max()
+    assert du0.max() <= 2e-4            # what the algorithm actually achieves
+    assert (cmds["cost"] <= g["f_tight"][~hm] + 1e-9).all()
+    assert (cmds["status"] == 0).all()
+
+
+def test_p3_solver_mirror_not_worse_than_reference_tolerance():
+    """P3: all cases incl. costmaps: f(build) <= f(SciPy @ ftol=1e-3) + 1e-3, feasible."""
+    g, params, probs, hm = _g3()
+    for mask, cells in ((~hm, np.zeros_like(g["cells"])), (hm, g["cells"])):
+        cmap = (cells,) + tuple(g["map_meta"])
+        cmds, x = _cold_solve(params, cmap, probs[mask])
+        assert (cmds["cost"] <= g["f_loose"][mask] + 1e-3).all()
+        # cost reported == the reference objective at the returned point
+        pr = probs[mask].copy()
+        f = c_oracle.objective_batch(params, cmap, pr, x)
+        assert np.allclose(f, cmds["cost"], rtol=1e-12, atol=1e-12)
+        assert (np.abs(x.reshape(len(x), -1, 3)[:, :, 0]) <= params["max_vel_x"] + 1e-12).all()
+        assert (np.abs(x.reshape(len(x), -1, 3)[:, :, 2]) <= params["max_vel_theta"] + 1e-12).all()
+        speed = np.hypot(x.reshape(len(x), -1, 3)[:, :, 0], x.reshape(len(x), -1, 3)[:, :, 1])
+        assert (speed <= params["max_vel_trans"] + 1e-9).all()
+
+
+def test_projection_box_cuts_disc():
+    """box ∩ disc projection when the box cuts the disc (SURVEY §7 hard part 3): the solver
+    output must satisfy both and not be worse than SciPy tight."""
+    params = orc.make_params(max_vel_trans=0.7, max_vel_x=0.4, min_vel_x=-0.2, max_vel_y=0.65,
+                             min_vel_y=-0.65)
+    probs = synthetic.make_problems(24, 200, seed=91)
+    zero = (np.zeros((200, 200), np.uint8), 0.05, -5.0, -5.0)
+    cmds, x = _cold_solve(params, zero, probs)
+    xs = x.reshape(len(x), -1, 3)
+    assert (xs[:, :, 0] <= 0.4 + 1e-12).all() and (xs[:, :, 0] >= -0.2 - 1e-12).all()
+    assert (np.hypot(xs[:, :, 0], xs[:, :, 1]) <= 0.7 + 1e-9).all()
+    cm = orc.Costmap(*zero)
+    for j in range(8):
+        r = orc.solve_slsqp(util.oracle_problem(probs[j]), params, cm, np.zeros(9), ftol=1e-12, maxiter=500)
+        assert cmds["cost"][j] <= r.fun + 1e-8
+        assert np.abs(x[j, :3] - r.x[:3]).max() <= 1e-3
