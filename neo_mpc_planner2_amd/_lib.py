@@ -1,0 +1,73 @@
+"""ctypes binding of the C-ABI library `libneo_mpc.so` (include/neo_mpc.h).
+
+The library is built in-tree by `__graft_entry__.build()` /
+`make -C neo_mpc_planner2_amd/csrc`.  There is no Python or CPU fallback: when the
+shared object is missing, `load()` raises.
+"""
+import ctypes as C
+import os
+
+from . import abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libneo_mpc.so")
+
+#: every symbol include/neo_mpc.h declares
+EXPORTS = (
+    "neo_mpc_abi_version", "neo_mpc_last_error", "neo_mpc_default_params", "neo_mpc_create",
+    "neo_mpc_destroy", "neo_mpc_set_params", "neo_mpc_get_params", "neo_mpc_set_costmap",
+    "neo_mpc_set_costmap_device", "neo_mpc_solve_batch", "neo_mpc_solve_batch_device",
+    "neo_mpc_postprocess_batch", "neo_mpc_objective_batch", "neo_mpc_kernel_info",
+)
+
+_lib = None
+
+
+class NeoMpcError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("neo_mpc error %d: %s" % (code, message))
+        self.code = code
+
+
+def load():
+    """Load libneo_mpc.so and declare the prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C neo_mpc_planner2_amd/csrc`).  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    lib.neo_mpc_abi_version.restype = C.c_int
+    lib.neo_mpc_last_error.restype = C.c_char_p
+    lib.neo_mpc_default_params.argtypes = [P(abi.NeoMpcParams)]
+    lib.neo_mpc_create.restype = C.c_void_p
+    lib.neo_mpc_create.argtypes = [P(abi.NeoMpcParams), C.c_int]
+    lib.neo_mpc_destroy.restype = None
+    lib.neo_mpc_destroy.argtypes = [C.c_void_p]
+    lib.neo_mpc_set_params.argtypes = [C.c_void_p, P(abi.NeoMpcParams)]
+    lib.neo_mpc_get_params.argtypes = [C.c_void_p, P(abi.NeoMpcParams)]
+    lib.neo_mpc_set_costmap.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                        C.c_double, C.c_double, C.c_double]
+    lib.neo_mpc_set_costmap_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                               C.c_double, C.c_double, C.c_double, C.c_void_p]
+    lib.neo_mpc_solve_batch.argtypes = [C.c_void_p, P(abi.NeoMpcBatch)]
+    lib.neo_mpc_solve_batch_device.argtypes = [C.c_void_p, P(abi.NeoMpcBatch), C.c_void_p]
+    lib.neo_mpc_postprocess_batch.argtypes = [C.c_void_p, P(abi.NeoMpcBatch), C.c_void_p]
+    lib.neo_mpc_objective_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.neo_mpc_kernel_info.argtypes = [C.c_void_p, P(C.c_uint32), P(C.c_uint32), P(C.c_uint32)]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int and name not in ("neo_mpc_abi_version",):
+            pass
+    if lib.neo_mpc_abi_version() != 1:
+        raise ImportError("libneo_mpc.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != 0:
+        raise NeoMpcError(code, (load().neo_mpc_last_error() or b"").decode())

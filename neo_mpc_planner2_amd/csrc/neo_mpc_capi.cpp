@@ -1,0 +1,436 @@
+// neo_mpc_capi.cpp -- the C-ABI of libneo_mpc.so (include/neo_mpc.h) over the gfx950 kernels.
+//
+// Host side of the drop-in boundary: what `NeoMpcPlanner::computeVelocityCommands`
+// (src/NeoMpcPlanner.cpp:240-252) calls instead of the ROS2 service hop, and what
+// `MpcOptimizationServer.__init__` (mpc_optimization_server.py:45-152) sets up.
+// There is deliberately no CPU fallback: without a gfx950 device create() fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "neo_mpc_device.h"
+
+using namespace neo_mpc;
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess)                                                               \
+      return fail(NEO_MPC_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));   \
+  } while (0)
+
+struct DeviceBuffer {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  int reserve(size_t need) {
+    if (need <= bytes) return NEO_MPC_OK;
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+    size_t cap = need + need / 4 + 256;
+    HIP_TRY(hipMalloc(&ptr, cap));
+    bytes = cap;
+    return NEO_MPC_OK;
+  }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+  }
+};
+
+}  // namespace
+
+struct neo_mpc_handle {
+  int device = 0;
+  neo_mpc_params params{};
+  DevParams dp{};
+  DevMap map{};
+  bool has_map = false;
+  LdsLayout lds{};
+  DeviceBuffer map_buf, raw_buf, term_buf;
+  DeviceBuffer problems, states, warm, commands, solution, path, footprints, success, u, cost;
+};
+
+namespace {
+
+int validate(const neo_mpc_params& p) {
+  if (p.control_steps < 1 || p.control_steps > NEO_MPC_MAX_CONTROL_STEPS)
+    return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "control_steps %d outside [1, %d]", p.control_steps,
+                NEO_MPC_MAX_CONTROL_STEPS);
+  if (!(p.prediction_horizon > 0.0)) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "prediction_horizon must be > 0");
+  if (!(p.min_vel_x <= p.max_vel_x) || !(p.min_vel_y <= p.max_vel_y) || !(p.min_vel_theta <= p.max_vel_theta))
+    return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "velocity bounds: min > max");  // SciPy raises here too
+  if (!(p.max_vel_trans > 0.0)) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "max_vel_trans must be > 0");
+  // box ∩ disc must be non-empty: closest box point to the origin inside the disc
+  double nx = std::fmin(std::fmax(0.0, p.min_vel_x), p.max_vel_x);
+  double ny = std::fmin(std::fmax(0.0, p.min_vel_y), p.max_vel_y);
+  if (nx * nx + ny * ny > p.max_vel_trans * p.max_vel_trans)
+    return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "velocity box does not intersect the max_vel_trans disc");
+  if (p.lbfgs_memory > NEO_MPC_MAX_LBFGS_MEMORY)
+    return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "lbfgs_memory > %d", NEO_MPC_MAX_LBFGS_MEMORY);
+  return NEO_MPC_OK;
+}
+
+int occupancy(int raw) {  // nav2 Costmap2DPublisher translation (build's costmap contract)
+  if (raw == 0) return 0;
+  if (raw == 253) return 99;
+  if (raw == 254) return 100;
+  if (raw == 255) return -1;
+  return 1 + (97 * (raw - 1)) / 251;
+}
+
+void derive(neo_mpc_handle* h) {
+  const neo_mpc_params& p = h->params;
+  DevParams& d = h->dp;
+  const int n = p.control_steps;
+  d.n = n;
+  d.dt = p.prediction_horizon / n;  // py:137
+  d.wt_n = p.w_trans / n;
+  d.wo_n = p.w_orient / n;
+  d.wc_n = p.w_control / n;
+  d.wterm_o = p.w_terminal * p.w_orient;
+  d.wterm_t = p.w_terminal * p.w_trans;
+  d.w_footprint = p.w_footprint;
+  d.lo[0] = p.min_vel_x; d.hi[0] = p.max_vel_x;
+  d.lo[1] = p.min_vel_y; d.hi[1] = p.max_vel_y;
+  d.lo[2] = p.min_vel_theta; d.hi[2] = p.max_vel_theta;
+  d.r = p.max_vel_trans;
+  d.acc[0] = p.acc_x_limit; d.acc[1] = p.acc_y_limit; d.acc[2] = p.acc_theta_limit;
+  d.low_pass_gain = p.low_pass_gain;
+  d.xtol = p.step_tolerance > 0.0 ? p.step_tolerance : 1e-3 * p.opt_tolerance;
+  d.max_it = p.max_iterations > 0 ? p.max_iterations : 100;
+  d.mem = p.lbfgs_memory > 0 ? p.lbfgs_memory : 4;
+  d.compat = p.compat_flags;
+
+  // LDS carve-up
+  LdsLayout& l = h->lds;
+  const int nv = 3 * n;
+  int off = 0;
+  auto take = [&](int cnt) { int o = off; off += cnt; return o; };
+  l.prob = take(32); l.state = take(16); l.term = take(256);
+  l.u = take(nv); l.gs = take(nv); l.gt = take(nv); l.gr = take(nv); l.d = take(nv);
+  l.u_prev = take(nv); l.gt_prev = take(nv); l.u_new = take(nv);
+  l.S = take(d.mem * nv); l.Y = take(d.mem * nv); l.rho = take(NEO_MPC_MAX_LBFGS_MEMORY);
+  l.cs = take(n); l.sn = take(n); l.dxs = take(n); l.dys = take(n);
+  l.rx = take(n); l.ry = take(n); l.rt = take(n); l.nx = take(n); l.ny = take(n);
+  l.mode = take(n);
+  off = (off + 1) & ~1;  // 16-byte align the tile
+  l.tile = off;
+  l.tile_w = 0; l.tile_h = 0; l.reach = 0;
+  if (h->has_map) {
+    const double bx = std::fmax(std::fabs(p.min_vel_x), std::fabs(p.max_vel_x));
+    const double by = std::fmax(std::fabs(p.min_vel_y), std::fabs(p.max_vel_y));
+    const double vmax = std::fmin(p.max_vel_trans, std::hypot(bx, by));
+    const double cells = std::ceil(vmax * p.prediction_horizon / h->map.resolution);
+    if (cells < 60.0) {
+      const int R = (int)cells + 1;
+      int w = 4;
+      while (w < 2 * R + 4) w <<= 1;
+      if (w <= kMaxTileWidth) { l.reach = R; l.tile_w = w; l.tile_h = 2 * R + 1; }
+    }
+  }
+  l.total_bytes = off * 8 + l.tile_w * l.tile_h;
+  l.total_bytes = (l.total_bytes + 15) & ~15;
+}
+
+int upload_term_table(neo_mpc_handle* h) {
+  double table[256];
+  const neo_mpc_params& p = h->params;
+  const int n = p.control_steps;
+  for (int raw = 0; raw < 256; ++raw) {
+    const double c = (double)occupancy(raw) / 100.0;  // getCost contract
+    const double cc = c * c;                           // py:247
+    table[raw] = (c == 1.0) ? cc * 1000 / n : p.w_costmap * cc / n;  // py:257-260
+  }
+  int rc = h->term_buf.reserve(sizeof(table));
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(h->term_buf.ptr, table, sizeof(table), hipMemcpyHostToDevice));
+  return NEO_MPC_OK;
+}
+
+int apply_params(neo_mpc_handle* h, const neo_mpc_params* params) {
+  int rc = validate(*params);
+  if (rc) return rc;
+  h->params = *params;
+  derive(h);
+  return upload_term_table(h);
+}
+
+int ingest(neo_mpc_handle* h, const uint8_t* d_cells, uint32_t sx, uint32_t sy, double res, double ox, double oy,
+           void* stream) {
+  if (!d_cells || sx == 0 || sy == 0 || sx > (1u << 20) || sy > (1u << 20) || !(res > 0.0))
+    return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "bad costmap geometry %ux%u res %g", sx, sy, res);
+  const int pitch = (int)((sx + 2 * kMapBorder + 127) & ~127u);
+  const int rows = (int)sy + 2 * kMapBorder;
+  int rc = h->map_buf.reserve((size_t)pitch * rows);
+  if (rc) return rc;
+  IngestArgs a;
+  a.src = d_cells;
+  a.dst = (uint8_t*)h->map_buf.ptr;
+  a.size_x = (int)sx; a.size_y = (int)sy; a.pitch = pitch; a.rows = rows;
+  launch_ingest(a, stream);
+  HIP_TRY(hipGetLastError());
+  h->map.cells = (const uint8_t*)h->map_buf.ptr + (size_t)kMapBorder * pitch + kMapBorder;
+  h->map.size_x = (int)sx; h->map.size_y = (int)sy; h->map.pitch = pitch;
+  h->map.resolution = res; h->map.inv_resolution = 1.0 / res;
+  h->map.origin_x = ox; h->map.origin_y = oy;
+  h->has_map = true;
+  derive(h);
+  return NEO_MPC_OK;
+}
+
+int fill_args(neo_mpc_handle* h, const neo_mpc_batch* b, SolveArgs& a) {
+  if (!h) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "null handle");
+  if (!b) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "null batch");
+  if (!h->has_map) return fail(NEO_MPC_ERR_NO_COSTMAP, "neo_mpc_set_costmap has not been called");
+  if (b->count > 0 && (!b->problems || !b->states || !b->warm_start || !b->commands))
+    return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "problems/states/warm_start/commands must not be null");
+  if (b->count > 0x7fffffffull) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "count too large");
+  if (b->footprints && b->footprint_points > NEO_MPC_MAX_FOOTPRINT_POINTS)
+    return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "footprint_points > %d", NEO_MPC_MAX_FOOTPRINT_POINTS);
+  std::memset(&a, 0, sizeof(a));
+  a.problems = b->problems; a.states = b->states; a.warm = b->warm_start; a.commands = b->commands;
+  a.solution = b->solution; a.path = b->predicted_path;
+  a.footprints = b->footprint_points ? b->footprints : nullptr;
+  a.footprint_points = b->footprints ? b->footprint_points : 0;
+  a.count = (uint32_t)b->count;
+  a.term_table = (const double*)h->term_buf.ptr;
+  a.p = h->dp; a.map = h->map; a.lds = h->lds;
+  return NEO_MPC_OK;
+}
+
+// host batch -> device staging; returns the device-pointer batch in `d`
+int stage_in(neo_mpc_handle* h, const neo_mpc_batch* b, neo_mpc_batch& d, bool solution_is_input) {
+  const size_t n = b->count, nv = 3 * (size_t)h->params.control_steps;
+  int rc;
+  if ((rc = h->problems.reserve(n * sizeof(neo_mpc_problem)))) return rc;
+  if ((rc = h->states.reserve(n * sizeof(neo_mpc_state)))) return rc;
+  if ((rc = h->warm.reserve(n * nv * 8))) return rc;
+  if ((rc = h->commands.reserve(n * sizeof(neo_mpc_command)))) return rc;
+  d = *b;
+  d.problems = (const neo_mpc_problem*)h->problems.ptr;
+  d.states = (neo_mpc_state*)h->states.ptr;
+  d.warm_start = (double*)h->warm.ptr;
+  d.commands = (neo_mpc_command*)h->commands.ptr;
+  HIP_TRY(hipMemcpy(h->problems.ptr, b->problems, n * sizeof(neo_mpc_problem), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->states.ptr, b->states, n * sizeof(neo_mpc_state), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->warm.ptr, b->warm_start, n * nv * 8, hipMemcpyHostToDevice));
+  if (b->solution) {
+    if ((rc = h->solution.reserve(n * nv * 8))) return rc;
+    d.solution = (double*)h->solution.ptr;
+    if (solution_is_input) HIP_TRY(hipMemcpy(h->solution.ptr, b->solution, n * nv * 8, hipMemcpyHostToDevice));
+  }
+  if (b->predicted_path) {
+    if ((rc = h->path.reserve(n * nv * 8))) return rc;
+    d.predicted_path = (double*)h->path.ptr;
+  }
+  if (b->footprints && b->footprint_points) {
+    const size_t bytes = n * b->footprint_points * 2 * 8;
+    if ((rc = h->footprints.reserve(bytes))) return rc;
+    HIP_TRY(hipMemcpy(h->footprints.ptr, b->footprints, bytes, hipMemcpyHostToDevice));
+    d.footprints = (const double*)h->footprints.ptr;
+  }
+  return NEO_MPC_OK;
+}
+
+int stage_out(neo_mpc_handle* h, const neo_mpc_batch* b, bool solution_is_output) {
+  const size_t n = b->count, nv = 3 * (size_t)h->params.control_steps;
+  HIP_TRY(hipMemcpy(b->commands, h->commands.ptr, n * sizeof(neo_mpc_command), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(b->states, h->states.ptr, n * sizeof(neo_mpc_state), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(b->warm_start, h->warm.ptr, n * nv * 8, hipMemcpyDeviceToHost));
+  if (b->solution && solution_is_output)
+    HIP_TRY(hipMemcpy(b->solution, h->solution.ptr, n * nv * 8, hipMemcpyDeviceToHost));
+  if (b->predicted_path)
+    HIP_TRY(hipMemcpy(b->predicted_path, h->path.ptr, n * nv * 8, hipMemcpyDeviceToHost));
+  return NEO_MPC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int neo_mpc_abi_version(void) { return NEO_MPC_ABI_VERSION; }
+
+const char* neo_mpc_last_error(void) { return g_error.c_str(); }
+
+int neo_mpc_default_params(neo_mpc_params* p) {
+  if (!p) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "null params");
+  std::memset(p, 0, sizeof(*p));
+  p->acc_x_limit = p->acc_y_limit = p->acc_theta_limit = 0.5;             // py:49-51
+  p->min_vel_x = p->min_vel_y = p->min_vel_theta = -0.5;                   // py:53-56
+  p->min_vel_trans = 0.5;                                                  // py:55 (sic)
+  p->max_vel_x = p->max_vel_y = p->max_vel_trans = p->max_vel_theta = 0.5; // py:58-61
+  p->w_trans = p->w_orient = p->w_control = p->w_terminal = p->w_costmap = 0.5;  // py:63-67
+  p->w_footprint = 2000;                                                   // py:68
+  p->waiting_time = 3.0;                                                   // py:70
+  p->low_pass_gain = 0.5;                                                  // py:71
+  p->opt_tolerance = 1e-5;                                                 // py:72
+  p->prediction_horizon = 0.5;                                             // py:73
+  p->control_steps = 3;                                                    // py:75
+  p->max_iterations = 100;
+  p->lbfgs_memory = 4;
+  p->compat_flags = NEO_MPC_COMPAT_ODOM_YAW_GOAL_W;
+  p->step_tolerance = 0.0;
+  return NEO_MPC_OK;
+}
+
+neo_mpc_handle* neo_mpc_create(const neo_mpc_params* params, int device) {
+  if (!params) { fail(NEO_MPC_ERR_INVALID_ARGUMENT, "null params"); return nullptr; }
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    fail(NEO_MPC_ERR_NO_DEVICE, "no HIP device visible (%s); this library has no CPU fallback",
+         e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    return nullptr;
+  }
+  if (device < 0 || device >= count) { fail(NEO_MPC_ERR_INVALID_ARGUMENT, "device %d of %d", device, count); return nullptr; }
+  if (hipSetDevice(device) != hipSuccess) { fail(NEO_MPC_ERR_DEVICE, "hipSetDevice(%d) failed", device); return nullptr; }
+  neo_mpc_handle* h = new (std::nothrow) neo_mpc_handle();
+  if (!h) { fail(NEO_MPC_ERR_DEVICE, "out of host memory"); return nullptr; }
+  h->device = device;
+  if (apply_params(h, params) != NEO_MPC_OK) { neo_mpc_destroy(h); return nullptr; }
+  return h;
+}
+
+void neo_mpc_destroy(neo_mpc_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  DeviceBuffer* all[] = {&h->map_buf, &h->raw_buf, &h->term_buf, &h->problems, &h->states, &h->warm, &h->commands,
+                         &h->solution, &h->path, &h->footprints, &h->success, &h->u, &h->cost};
+  for (DeviceBuffer* b : all) b->release();
+  delete h;
+}
+
+int neo_mpc_set_params(neo_mpc_handle* h, const neo_mpc_params* params) {
+  if (!h || !params) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  return apply_params(h, params);
+}
+
+int neo_mpc_get_params(const neo_mpc_handle* h, neo_mpc_params* params) {
+  if (!h || !params) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "null argument");
+  *params = h->params;
+  return NEO_MPC_OK;
+}
+
+int neo_mpc_set_costmap(neo_mpc_handle* h, const uint8_t* cells, uint32_t sx, uint32_t sy, double res, double ox,
+                        double oy) {
+  if (!h || !cells) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = h->raw_buf.reserve((size_t)sx * sy);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(h->raw_buf.ptr, cells, (size_t)sx * sy, hipMemcpyHostToDevice));
+  rc = ingest(h, (const uint8_t*)h->raw_buf.ptr, sx, sy, res, ox, oy, nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  return NEO_MPC_OK;
+}
+
+int neo_mpc_set_costmap_device(neo_mpc_handle* h, const uint8_t* d_cells, uint32_t sx, uint32_t sy, double res,
+                               double ox, double oy, void* stream) {
+  if (!h || !d_cells) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  return ingest(h, d_cells, sx, sy, res, ox, oy, stream);
+}
+
+int neo_mpc_solve_batch_device(neo_mpc_handle* h, const neo_mpc_batch* batch, void* stream) {
+  SolveArgs a;
+  int rc = fill_args(h, batch, a);
+  if (rc) return rc;
+  launch_solve(a, stream);
+  HIP_TRY(hipGetLastError());
+  return NEO_MPC_OK;
+}
+
+int neo_mpc_solve_batch(neo_mpc_handle* h, const neo_mpc_batch* batch) {
+  SolveArgs a;
+  int rc = fill_args(h, batch, a);  // validates
+  if (rc) return rc;
+  if (batch->count == 0) return NEO_MPC_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  neo_mpc_batch d;
+  if ((rc = stage_in(h, batch, d, false))) return rc;
+  if ((rc = fill_args(h, &d, a))) return rc;
+  launch_solve(a, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  return stage_out(h, batch, true);
+}
+
+int neo_mpc_postprocess_batch(neo_mpc_handle* h, const neo_mpc_batch* batch, const int32_t* success) {
+  SolveArgs a;
+  int rc = fill_args(h, batch, a);
+  if (rc) return rc;
+  if (!batch->solution) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "postprocess needs batch->solution (x.x)");
+  if (batch->count == 0) return NEO_MPC_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  neo_mpc_batch d;
+  if ((rc = stage_in(h, batch, d, true))) return rc;
+  if ((rc = fill_args(h, &d, a))) return rc;
+  if (success) {
+    if ((rc = h->success.reserve(batch->count * 4))) return rc;
+    HIP_TRY(hipMemcpy(h->success.ptr, success, batch->count * 4, hipMemcpyHostToDevice));
+    a.success = (const int32_t*)h->success.ptr;
+  }
+  launch_postprocess(a, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  return stage_out(h, batch, false);
+}
+
+int neo_mpc_objective_batch(neo_mpc_handle* h, const neo_mpc_problem* problems, const double* u, double* cost_out,
+                            size_t count) {
+  if (!h || !problems || !u || !cost_out) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "null argument");
+  if (!h->has_map) return fail(NEO_MPC_ERR_NO_COSTMAP, "neo_mpc_set_costmap has not been called");
+  if (count == 0) return NEO_MPC_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t nv = 3 * (size_t)h->params.control_steps;
+  int rc;
+  if ((rc = h->problems.reserve(count * sizeof(neo_mpc_problem)))) return rc;
+  if ((rc = h->u.reserve(count * nv * 8))) return rc;
+  if ((rc = h->cost.reserve(count * 8))) return rc;
+  HIP_TRY(hipMemcpy(h->problems.ptr, problems, count * sizeof(neo_mpc_problem), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->u.ptr, u, count * nv * 8, hipMemcpyHostToDevice));
+  ObjectiveArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.problems = (const neo_mpc_problem*)h->problems.ptr;
+  a.u = (const double*)h->u.ptr;
+  a.cost = (double*)h->cost.ptr;
+  a.term_table = (const double*)h->term_buf.ptr;
+  a.count = (uint32_t)count;
+  a.p = h->dp; a.map = h->map;
+  launch_objective(a, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(cost_out, h->cost.ptr, count * 8, hipMemcpyDeviceToHost));
+  return NEO_MPC_OK;
+}
+
+int neo_mpc_kernel_info(const neo_mpc_handle* h, uint32_t* lds_bytes, uint32_t* reach_cells, uint32_t* tile_in_lds) {
+  if (!h) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "null handle");
+  if (lds_bytes) *lds_bytes = (uint32_t)h->lds.total_bytes;
+  if (reach_cells) *reach_cells = (uint32_t)h->lds.reach;
+  if (tile_in_lds) *tile_in_lds = h->lds.tile_w ? 1u : 0u;
+  return NEO_MPC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+// neo_mpc_device.h -- host/device shared argument blocks of the gfx950 kernels.
+// Internal to libneo_mpc.so (the public surface is include/neo_mpc.h).
+#pragma once
+#include <stdint.h>
+
+#include "../../include/neo_mpc.h"
+
+namespace neo_mpc {
+
+constexpr int kLanes = 64;          // one CDNA4 wavefront per MPC instance
+constexpr int kMapBorder = 64;      // lethal border (cells) K3 adds around the costmap
+constexpr int kMaxTileWidth = 128;  // widest reach tile staged in LDS (bytes per row)
+
+// Constants of one solver configuration, precomputed on the host in float64 exactly as
+// the reference evaluates them (mpc_optimization_server.py:137, 252-268).
+struct DevParams {
+  double dt;                 // prediction_horizon / control_steps (py:137)
+  double wt_n, wo_n, wc_n;   // w_trans/N, w_orient/N, w_control/N (py:252-254)
+  double wterm_o;            // w_terminal * w_orient (py:268)
+  double wterm_t;            // w_terminal * w_trans  (py:268, constant in u)
+  double w_footprint;        // py:263 (constant in u)
+  double lo[3], hi[3];       // box bounds vx, vy, omega (py:127-133)
+  double r;                  // max_vel_trans (py:158)
+  double acc[3];             // post clamp (py:385-391)
+  double low_pass_gain;      // py:367
+  double xtol;               // step tolerance
+  int32_t n;                 // control_steps
+  int32_t max_it;
+  int32_t mem;               // L-BFGS pairs
+  int32_t compat;
+};
+
+// Device costmap written by the ingest kernel (K3): raw nav2 costs with a lethal border of
+// kMapBorder cells and a 128-byte row pitch; `cells` points at cell (0, 0).
+struct DevMap {
+  const uint8_t* cells;
+  int32_t size_x, size_y;
+  int32_t pitch;
+  double resolution, inv_resolution, origin_x, origin_y;
+};
+
+// LDS carve-up of the solve kernel, in doubles from the start of dynamic LDS.
+struct LdsLayout {
+  int32_t prob, state, term, u, gs, gt, gr, d, u_prev, gt_prev, u_new, S, Y, rho;
+  int32_t cs, sn, dxs, dys, rx, ry, rt, nx, ny, mode;  // per-step scratch
+  int32_t tile;        // byte tile starts here (double index)
+  int32_t total_bytes;
+  int32_t tile_w;      // row stride of the tile in bytes (power of two), 0: no tile
+  int32_t tile_h;      // rows
+  int32_t reach;       // R: the tile spans [m0 - R, m0 + R]
+};
+
+struct SolveArgs {
+  const neo_mpc_problem* problems;
+  neo_mpc_state* states;
+  double* warm;
+  neo_mpc_command* commands;
+  double* solution;        // optional
+  double* path;            // optional
+  const double* footprints;  // optional
+  const int32_t* success;    // postprocess only, optional
+  const double* term_table;  // [256] per-step costmap term by raw cell value
+  uint32_t footprint_points;
+  uint32_t count;
+  DevParams p;
+  DevMap map;
+  LdsLayout lds;
+};
+
+struct ObjectiveArgs {
+  const neo_mpc_problem* problems;
+  const double* u;
+  double* cost;
+  const double* term_table;
+  uint32_t count;
+  DevParams p;
+  DevMap map;
+};
+
+struct IngestArgs {
+  const uint8_t* src;  // raw nav2 costmap, row-major size_x * size_y
+  uint8_t* dst;        // padded map base (row 0 of the border)
+  int32_t size_x, size_y, pitch, rows;  // rows = size_y + 2*border
+};
+
+void launch_solve(const SolveArgs& a, void* stream);
+void launch_postprocess(const SolveArgs& a, void* stream);
+void launch_objective(const ObjectiveArgs& a, void* stream);
+void launch_ingest(const IngestArgs& a, void* stream);
+
+}  // namespace neo_mpc

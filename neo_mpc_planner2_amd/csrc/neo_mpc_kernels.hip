@@ -1,0 +1,722 @@
+// neo_mpc_kernels.hip -- gfx950 (CDNA4 / MI355X) kernels of the batched MPC solver.
+//
+// Replaces, for thousands of independent instances per launch, what the reference does
+// one request at a time in Python: `MpcOptimizationServer.optimizer`
+// (neo_mpc_planner2/mpc_optimization_server.py:349-403), i.e. the SciPy SLSQP `minimize`
+// call (py:363-364) over `objective` (py:204-269) with the box bounds and the
+// translational-speed disc (py:125-134, 157-158), followed by the low-pass, collision
+// check, stop latch, acceleration clamp and warm-start shift (py:365-403).
+//
+//   K1 k_solve        one 64-lane wavefront per instance.  Per iteration the wave
+//                     evaluates 64 candidate control sequences at once (one rollout per
+//                     lane): lanes 0-31 walk the projected proximal-gradient arc at 32
+//                     step sizes, lanes 32-63 the projected L-BFGS direction at 32 step
+//                     lengths; the lowest objective wins (wave arg-min).  Iterates,
+//                     gradients, L-BFGS pairs and the adjoint sweep's per-step state live
+//                     in LDS; the (2R+1)^2 costmap reach tile is staged into LDS once per
+//                     solve with coalesced dword loads.  float64 throughout (the arc
+//                     search compares objective values, which resolves the minimiser to
+//                     sqrt(eps); MI355X has full-rate vector f64).
+//   K2 postprocess    py:365-403, fused as the epilogue of K1 and launchable on its own.
+//   K3 k_ingest       raw nav2 costmap -> device map with a lethal border and 128-byte
+//                     row pitch (16 B per lane, HBM-streaming).
+//   k_objective       py:204-269 for given controls (parity checks of the objective).
+//
+// No MFMA: a 3*control_steps-variable problem has no dense contraction.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "neo_mpc_device.h"
+
+namespace neo_mpc {
+namespace {
+
+#define WAVE_SYNC() __syncthreads()
+
+// ---------------------------------------------------------------- wave primitives
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
+  return v;
+}
+// lowest value, ties to the lowest lane; every lane returns the same pair
+__device__ __forceinline__ void wave_argmin(double& v, int& idx) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    double ov = __shfl_xor(v, m);
+    int oi = __shfl_xor(idx, m);
+    if (ov < v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+  }
+}
+__device__ __forceinline__ int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// ---------------------------------------------------------------- problem record indices (doubles)
+enum : int {
+  P_CUR_X = 0, P_CUR_Y = 1, P_CUR_Q = 2, P_CARROT_X = 6, P_CARROT_Y = 7, P_CARROT_Q = 8,
+  P_GOAL = 12, P_GOAL_Q = 15, P_VEL = 19, P_INTERVAL = 22, P_DELTA_T = 23, P_FOOTPRINT = 24,
+  S_LAST = 0, S_OLD_GOAL = 3, S_WAIT = 10, SI_HAS_GOAL = 22, SI_COLLISION = 23, SI_COLL_FP = 24
+};
+
+struct Ctx {
+  double cx, cy, tyaw, fyaw, c0, s0, X0, Y0, v0, v1, v2, konst, true_yaw;
+  int tile_x0, tile_y0;
+};
+
+// py:176-178
+__device__ __forceinline__ double yaw_of(const double* q) {
+  double t3 = 2.0 * (q[3] * q[2] + q[0] * q[1]);
+  double t4 = 1.0 - 2.0 * (q[1] * q[1] + q[2] * q[2]);
+  return atan2(t3, t4);
+}
+
+// ---------------------------------------------------------------- costmap
+// floor((w - origin) / resolution): multiply by the reciprocal, redo with the exact division
+// only when the quotient sits on a cell edge, so the result always equals the division's.
+__device__ __forceinline__ int cell_of(double w, double origin, double res, double inv) {
+  double t = w - origin;
+  double q = t * inv;
+  double fl = floor(q);
+  if (fabs(q - rint(q)) < 1e-6) fl = floor(t / res);
+  fl = fmin(fmax(fl, -1.0e9), 1.0e9);
+  return (int)fl;
+}
+
+__device__ __forceinline__ int map_raw(const DevMap& m, int mx, int my) {
+  if (mx < -kMapBorder || my < -kMapBorder || mx >= m.size_x + kMapBorder || my >= m.size_y + kMapBorder)
+    return 254;  // contract: out of bounds is lethal
+  return m.cells[(long)my * m.pitch + mx];
+}
+
+// normalised cost of a raw cell: nav2 occupancy translation / 100 (build's costmap contract)
+__device__ __forceinline__ double raw_cost(int raw) {
+  int occ = raw == 0 ? 0 : raw == 253 ? 99 : raw == 254 ? 100 : raw == 255 ? -1 : 1 + (97 * (raw - 1)) / 251;
+  return (double)occ / 100.0;
+}
+
+__device__ __forceinline__ double step_term(const SolveArgs& a, const Ctx& c, const double* L, double x, double y) {
+  const double X = c.X0 + (c.c0 * x - c.s0 * y), Y = c.Y0 + (c.s0 * x + c.c0 * y);
+  const int mx = cell_of(X, a.map.origin_x, a.map.resolution, a.map.inv_resolution);
+  const int my = cell_of(Y, a.map.origin_y, a.map.resolution, a.map.inv_resolution);
+  const unsigned tx = (unsigned)(mx - c.tile_x0), ty = (unsigned)(my - c.tile_y0);
+  int raw;
+  if (tx < (unsigned)a.lds.tile_w && ty < (unsigned)a.lds.tile_h)
+    raw = reinterpret_cast<const uint8_t*>(L + a.lds.tile)[ty * a.lds.tile_w + tx];
+  else
+    raw = map_raw(a.map, mx, my);
+  return L[a.lds.term + raw];
+}
+
+// Bresenham outline cost of one polygon edge (end points inclusive)
+__device__ double edge_cost(const DevMap& m, double ax, double ay, double bx, double by) {
+  int x0 = cell_of(ax, m.origin_x, m.resolution, m.inv_resolution);
+  int y0 = cell_of(ay, m.origin_y, m.resolution, m.inv_resolution);
+  const int x1 = cell_of(bx, m.origin_x, m.resolution, m.inv_resolution);
+  const int y1 = cell_of(by, m.origin_y, m.resolution, m.inv_resolution);
+  const long dx = labs((long)x1 - x0), dy = labs((long)y1 - y0);
+  const int sx = x1 >= x0 ? 1 : -1, sy = y1 >= y0 ? 1 : -1;
+  long err = dx - dy;
+  double worst = -1.0;
+  for (long guard = 0; guard <= dx + dy + 1; ++guard) {
+    worst = fmax(worst, raw_cost(map_raw(m, x0, y0)));
+    if (x0 == x1 && y0 == y1) break;
+    long e2 = 2 * err;
+    if (e2 > -dy) { err -= dy; x0 += sx; }
+    if (e2 < dx) { err += dx; y0 += sy; }
+  }
+  return worst;
+}
+
+// getFootprintCost of the published footprint (py:343): lanes take edges, wave max
+__device__ double footprint_cost(const SolveArgs& a, const double* L, uint32_t b, int lane) {
+  if (!a.footprints || a.footprint_points == 0) return L[a.lds.prob + P_FOOTPRINT];
+  const int np = (int)a.footprint_points;
+  const double* pts = a.footprints + (size_t)b * 2 * np;
+  double worst = -1.0;
+  for (int e = lane; e < np; e += kLanes) {
+    int j = (e + 1) % np;
+    worst = fmax(worst, edge_cost(a.map, pts[2 * e], pts[2 * e + 1], pts[2 * j], pts[2 * j + 1]));
+  }
+  return wave_max(worst);
+}
+
+// ---------------------------------------------------------------- feasible set
+__device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Euclidean projection of (vx, vy) onto box ∩ disc; omega clamped (py:125-134, 157-158)
+__device__ __forceinline__ void project_block(const DevParams& p, double& b0, double& b1, double& b2) {
+  b2 = clampd(b2, p.lo[2], p.hi[2]);
+  const double zx = b0, zy = b1, r = p.r;
+  const double px = clampd(zx, p.lo[0], p.hi[0]), py = clampd(zy, p.lo[1], p.hi[1]);
+  if (px * px + py * py <= r * r) { b0 = px; b1 = py; return; }
+  const double nz = sqrt(zx * zx + zy * zy);
+  const double qx = zx * (r / nz), qy = zy * (r / nz);
+  if (qx >= p.lo[0] && qx <= p.hi[0] && qy >= p.lo[1] && qy <= p.hi[1]) { b0 = qx; b1 = qy; return; }
+  double best = INFINITY, bx = px, by = py;  // both bind: closest circle / box-edge intersection
+  for (int e = 0; e < 4; ++e) {
+    const double fixed = (e == 0) ? p.lo[0] : (e == 1) ? p.hi[0] : (e == 2) ? p.lo[1] : p.hi[1];
+    if (fabs(fixed) > r) continue;
+    const double o = sqrt(r * r - fixed * fixed);
+    for (int s = -1; s <= 1; s += 2) {
+      const double ex = (e < 2) ? fixed : s * o, ey = (e < 2) ? s * o : fixed;
+      if (ex < p.lo[0] || ex > p.hi[0] || ey < p.lo[1] || ey > p.hi[1]) continue;
+      const double dd = (ex - zx) * (ex - zx) + (ey - zy) * (ey - zy);
+      if (dd < best) { best = dd; bx = ex; by = ey; }
+    }
+  }
+  b0 = bx; b1 = by;
+}
+
+// candidate step multipliers: lanes 0..31 scale the proximal-gradient step by 2^(-12 + l/2),
+// lanes 32..63 are step lengths along the L-BFGS direction
+__constant__ double kQnSteps[32] = {
+    1.0, 0.84, 1.19, 0.71, 1.41, 0.59, 1.68, 0.5, 2.0, 0.42, 2.38, 0.35, 2.83, 0.25, 4.0, 0.177,
+    0.125, 0.088, 0.0625, 0.044, 0.03125, 0.0156, 0.0078, 0.0039, 0.00195, 0.00098, 4.9e-4, 2.4e-4,
+    1.2e-4, 6e-5, 3e-5, 1.5e-5};
+
+__device__ __forceinline__ double lane_scale(int lane) {
+  if (lane >= 32) return kQnSteps[lane - 32];
+  double s = ldexp(1.0, -12 + (lane >> 1));
+  return (lane & 1) ? s * 1.4142135623730951 : s;
+}
+
+// control block i of this lane's candidate
+__device__ __forceinline__ void candidate_block(const SolveArgs& a, const Ctx& c, const double* L, int lane,
+                                                double step, int i, double& b0, double& b1, double& b2) {
+  const double* u = L + a.lds.u + 3 * i;
+  if (lane < 32) {  // proximal gradient: forward step on the smooth part, prox of the control norm
+    const double* gs = L + a.lds.gs + 3 * i;
+    const double e0 = (u[0] - step * gs[0]) - c.v0, e1 = (u[1] - step * gs[1]) - c.v1,
+                 e2 = (u[2] - step * gs[2]) - c.v2;
+    const double ne = sqrt(e0 * e0 + e1 * e1 + e2 * e2);
+    const double sh = (ne > 0.0) ? fmax(0.0, 1.0 - step * a.p.wc_n / ne) : 0.0;
+    b0 = c.v0 + sh * e0; b1 = c.v1 + sh * e1; b2 = c.v2 + sh * e2;
+  } else {          // quasi-Newton direction
+    const double* d = L + a.lds.d + 3 * i;
+    b0 = u[0] + step * d[0]; b1 = u[1] + step * d[1]; b2 = u[2] + step * d[2];
+  }
+  project_block(a.p, b0, b1, b2);
+}
+
+// rollout + cost of one control sequence (py:224-268); Block(i, b0, b1, b2) yields the controls
+template <class Block>
+__device__ __forceinline__ double rollout_cost(const SolveArgs& a, const Ctx& c, const double* L, Block block) {
+  const DevParams& p = a.p;
+  double f = 0.0, x = 0.0, y = 0.0, th = 0.0;
+  for (int i = 0; i < p.n; ++i) {
+    double vx, vy, w;
+    block(i, vx, vy, w);
+    th += w * p.dt;                                     // py:230
+    double sn, cs;
+    sincos(th, &sn, &cs);
+    x += (vx * cs - vy * sn) * p.dt;                    // py:231
+    y += (vx * sn + vy * cs) * p.dt;                    // py:232
+    const double dx = c.cx - x, dy = c.cy - y, et = c.tyaw - th;
+    const double e0 = c.v0 - vx, e1 = c.v1 - vy, e2 = c.v2 - w;
+    f += p.wt_n * (dx * dx + dy * dy) + p.wo_n * (et * et);   // py:252
+    f += p.wc_n * sqrt(e0 * e0 + e1 * e1 + e2 * e2);           // py:253-254
+    f += step_term(a, c, L, x, y);                             // py:246-247, 257-260
+  }
+  const double et = c.fyaw - th;
+  return f + p.wterm_o * (et * et) + c.konst;                  // py:266-268
+}
+
+// ---------------------------------------------------------------- set-up shared by the kernels
+__device__ void load_term_table(const double* table, double* L, int term, int lane) {
+  for (int k = lane; k < 256; k += kLanes) L[term + k] = table[k];
+}
+
+__device__ void make_ctx(const DevParams& p, const DevMap& m, const double* P, double fcost, Ctx& c) {
+  c.cx = P[P_CARROT_X]; c.cy = P[P_CARROT_Y];
+  c.tyaw = yaw_of(P + P_CARROT_Q);                       // py:211
+  c.fyaw = yaw_of(P + P_GOAL_Q);                         // py:212
+  double q[4] = {P[P_CUR_Q], P[P_CUR_Q + 1], P[P_CUR_Q + 2],
+                 (p.compat & NEO_MPC_COMPAT_ODOM_YAW_GOAL_W) ? P[P_GOAL_Q + 3] : P[P_CUR_Q + 3]};
+  const double psi0 = yaw_of(q);                          // py:213 (goal's w: reference quirk)
+  sincos(psi0, &c.s0, &c.c0);
+  c.true_yaw = yaw_of(P + P_CUR_Q);                      // py:317
+  c.X0 = P[P_CUR_X]; c.Y0 = P[P_CUR_Y];
+  c.v0 = P[P_VEL]; c.v1 = P[P_VEL + 1]; c.v2 = P[P_VEL + 2];
+  const double gdx = c.cx - P[P_GOAL], gdy = c.cy - P[P_GOAL + 1];
+  c.konst = p.wterm_t * (gdx * gdx + gdy * gdy);          // py:266, 268: constant in u
+  if (fcost == 1.0) c.konst += p.w_footprint;             // py:262-263: N steps * w_footprint/N
+  c.tile_x0 = 0; c.tile_y0 = 0;
+}
+
+// stage the reach tile: rows [my0-R, my0+R], columns from floor4(mx0-R), dword loads
+__device__ void load_tile(const SolveArgs& a, Ctx& c, double* L, int lane) {
+  if (a.lds.tile_w == 0) { c.tile_x0 = 0; c.tile_y0 = 0; return; }
+  const int mx0 = cell_of(c.X0, a.map.origin_x, a.map.resolution, a.map.inv_resolution);
+  const int my0 = cell_of(c.Y0, a.map.origin_y, a.map.resolution, a.map.inv_resolution);
+  c.tile_x0 = (mx0 - a.lds.reach) & ~3;
+  c.tile_y0 = my0 - a.lds.reach;
+  uint32_t* tile = reinterpret_cast<uint32_t*>(L + a.lds.tile);
+  const int wq = a.lds.tile_w >> 2;  // dwords per row (power of two)
+  const int total = wq * a.lds.tile_h;
+  const int shift = __ffs(wq) - 1;
+  for (int idx = lane; idx < total; idx += kLanes) {
+    const int row = idx >> shift, col = idx & (wq - 1);
+    const long gy = (long)c.tile_y0 + row, gx = (long)c.tile_x0 + 4 * col;
+    uint32_t v = 0xFEFEFEFEu;  // lethal outside the padded map
+    if (gy >= -kMapBorder && gy < (long)a.map.size_y + kMapBorder && gx >= -kMapBorder &&
+        gx + 4 <= (long)a.map.pitch - kMapBorder)
+      v = *reinterpret_cast<const uint32_t*>(a.map.cells + gy * a.map.pitch + gx);
+    tile[idx] = v;
+  }
+}
+
+// ---------------------------------------------------------------- K2: py:365-403
+// `x` (LDS, 3N doubles) is the raw solver output; modified in place like `x.x`.
+__device__ void postprocess(const SolveArgs& a, const Ctx& c, double* L, uint32_t b, int lane, double* x,
+                            bool success, double fcost, int flags, double cost, int status, int nit, int nfev) {
+  const DevParams& p = a.p;
+  const int n = p.n, nv = 3 * n;
+  double* S = L + a.lds.state;
+  int* Si = reinterpret_cast<int*>(S);
+  const double* P = L + a.lds.prob;
+  // the `local_plan` rollout of the UNFILTERED solution (publishLocalPlan, py:293-306, runs
+  // before the low-pass at py:366) from the request's current pose
+  if (a.path) {
+    double yaw = c.true_yaw, px = c.X0, py = c.Y0;
+    for (int i = 0; i < n; ++i) {
+      yaw += x[3 * i + 2] * p.dt;
+      double sn, cs;
+      sincos(yaw, &sn, &cs);
+      px += x[3 * i] * cs * p.dt - x[3 * i + 1] * sn * p.dt;
+      py += x[3 * i] * sn * p.dt + x[3 * i + 1] * cs * p.dt;
+      if (lane == 0) {
+        double* o = a.path + ((size_t)b * n + i) * 3;
+        o[0] = px; o[1] = py; o[2] = yaw;
+      }
+    }
+  }
+  // low-pass on the first control, in place (py:366-367)
+  const double g = p.low_pass_gain;
+  double x0 = x[0] * g + S[S_LAST + 0] * (1 - g);
+  double x1 = x[1] * g + S[S_LAST + 1] * (1 - g);
+  double x2 = x[2] * g + S[S_LAST + 2] * (1 - g);
+  WAVE_SYNC();
+  if (lane == 0) { x[0] = x0; x[1] = x1; x[2] = x2; }
+  WAVE_SYNC();
+  // collision_check (py:312-341): global-frame rollout from the TRUE yaw
+  int collision = Si[SI_COLLISION];
+  {
+    double yaw = c.true_yaw, px = c.X0, py = c.Y0;
+    for (int i = 0; i < n; ++i) {
+      yaw += x[3 * i + 2] * p.dt;
+      double sn, cs;
+      sincos(yaw, &sn, &cs);
+      px += x[3 * i] * cs * p.dt - x[3 * i + 1] * sn * p.dt;   // py:326
+      py += x[3 * i] * sn * p.dt + x[3 * i + 1] * cs * p.dt;   // py:327
+      const int mx = cell_of(px, a.map.origin_x, a.map.resolution, a.map.inv_resolution);
+      const int my = cell_of(py, a.map.origin_y, a.map.resolution, a.map.inv_resolution);
+      if (raw_cost(map_raw(a.map, mx, my)) >= 0.99) { collision = 1; break; }   // py:338-341
+    }
+  }
+  const int coll_fp = (fcost == 1.0) ? 1 : 0;                       // py:343-347
+  double out0, out1, out2, waiting = S[S_WAIT];
+  if (collision || coll_fp) {                                       // py:374-382
+    out0 = out1 = out2 = 0.0;
+    flags |= NEO_MPC_FLAG_STOPPED;
+    waiting += P[P_DELTA_T];
+    if (waiting >= 3.0) { collision = 0; waiting = 0.0; }
+  } else {                                                          // py:385-391
+    const double ci = P[P_INTERVAL];
+    out0 = fmax(fmin(x0, S[S_LAST + 0] + p.acc[0] * ci), S[S_LAST + 0] - p.acc[0] * ci);
+    out1 = fmax(fmin(x1, S[S_LAST + 1] + p.acc[1] * ci), S[S_LAST + 1] - p.acc[1] * ci);
+    out2 = fmax(fmin(x2, S[S_LAST + 2] + p.acc[2] * ci), S[S_LAST + 2] - p.acc[2] * ci);
+  }
+  // warm start (py:397-400, 198-202)
+  double* warm = a.warm + (size_t)b * nv;
+  for (int k = lane; k < nv; k += kLanes) {
+    double v;
+    if (success) v = (k < nv - 3) ? x[k + 3] : x[k - (nv - 3)];
+    else v = x[k];
+    warm[k] = v;
+  }
+  WAVE_SYNC();
+  if (lane == 0) {
+    S[S_LAST + 0] = out0; S[S_LAST + 1] = out1; S[S_LAST + 2] = out2;   // py:393-395
+    for (int k = 0; k < 3; ++k) S[S_OLD_GOAL + k] = P[P_GOAL + k];       // py:402
+    for (int k = 0; k < 4; ++k) S[S_OLD_GOAL + 3 + k] = P[P_GOAL_Q + k];
+    S[S_WAIT] = waiting;
+    Si[SI_HAS_GOAL] = 1; Si[SI_COLLISION] = collision; Si[SI_COLL_FP] = coll_fp;
+    neo_mpc_command cmd;
+    cmd.vel[0] = out0; cmd.vel[1] = out1; cmd.vel[2] = out2;
+    cmd.cost = cost; cmd.status = status; cmd.iterations = nit; cmd.evaluations = nfev; cmd.flags = flags;
+    a.commands[b] = cmd;
+  }
+  WAVE_SYNC();
+  if (lane < 16) reinterpret_cast<double*>(a.states + b)[lane] = S[lane];
+}
+
+// py:358-361; returns true when the reset is taken.  x0 -> L[u]
+__device__ bool reset_and_warm(const SolveArgs& a, double* L, uint32_t b, int lane) {
+  double* S = L + a.lds.state;
+  int* Si = reinterpret_cast<int*>(S);
+  const double* P = L + a.lds.prob;
+  bool same = Si[SI_HAS_GOAL] != 0;
+  for (int k = 0; k < 3; ++k) same = same && (S[S_OLD_GOAL + k] == P[P_GOAL + k]);
+  for (int k = 0; k < 4; ++k) same = same && (S[S_OLD_GOAL + 3 + k] == P[P_GOAL_Q + k]);
+  same = uniform_int(same ? 1 : 0) != 0;
+  const int nv = 3 * a.p.n;
+  WAVE_SYNC();
+  for (int k = lane; k < nv; k += kLanes) L[a.lds.u + k] = same ? a.warm[(size_t)b * nv + k] : 0.0;
+  if (!same && lane == 0) { S[S_LAST] = 0.0; S[S_LAST + 1] = 0.0; S[S_LAST + 2] = 0.0; S[S_WAIT] = 0.0; }
+  WAVE_SYNC();
+  return !same;
+}
+
+__device__ void load_records(const SolveArgs& a, double* L, uint32_t b, int lane) {
+  if (lane < 32) L[a.lds.prob + lane] = reinterpret_cast<const double*>(a.problems + b)[lane];
+  else if (lane < 48) L[a.lds.state + lane - 32] = reinterpret_cast<const double*>(a.states + b)[lane - 32];
+  load_term_table(a.term_table, L, a.lds.term, lane);
+  WAVE_SYNC();
+}
+
+// ---------------------------------------------------------------- K1
+__global__ __launch_bounds__(kLanes) void k_solve(const SolveArgs a) {
+  extern __shared__ __align__(16) double L[];
+  const int lane = threadIdx.x;
+  const uint32_t b = blockIdx.x;
+  if (b >= a.count) return;
+  const DevParams& p = a.p;
+  const int n = p.n, nv = 3 * n, mem = p.mem;
+
+  load_records(a, L, b, lane);
+  int flags = reset_and_warm(a, L, b, lane) ? NEO_MPC_FLAG_RESET : 0;
+  const double fcost = footprint_cost(a, L, b, lane);
+  Ctx c;
+  make_ctx(p, a.map, L + a.lds.prob, fcost, c);
+  load_tile(a, c, L, lane);
+
+  double* u = L + a.lds.u;
+  double* gs = L + a.lds.gs;
+  double* gt = L + a.lds.gt;
+  double* gr = L + a.lds.gr;
+  double* d = L + a.lds.d;
+  double* u_prev = L + a.lds.u_prev;
+  double* gt_prev = L + a.lds.gt_prev;
+  double* u_new = L + a.lds.u_new;
+  double* Sm = L + a.lds.S;
+  double* Ym = L + a.lds.Y;
+  double* rho = L + a.lds.rho;
+  double* ACS = L + a.lds.cs;
+  double* ASN = L + a.lds.sn;
+  double* ADX = L + a.lds.dxs;
+  double* ADY = L + a.lds.dys;
+  double* ARX = L + a.lds.rx;
+  double* ARY = L + a.lds.ry;
+  double* ART = L + a.lds.rt;
+  double* ANX = L + a.lds.nx;
+  double* ANY = L + a.lds.ny;
+  int* AMODE = reinterpret_cast<int*>(L + a.lds.mode);  // [2n]: mode[i], wfroz[i]
+
+  // x0 clipped to the feasible set (SciPy clips x0 to the bounds, _slsqp_py.py:268)
+  for (int i = lane; i < n; i += kLanes) project_block(p, u[3 * i], u[3 * i + 1], u[3 * i + 2]);
+  WAVE_SYNC();
+  double f = rollout_cost(a, c, L, [&](int i, double& b0, double& b1, double& b2) {
+    b0 = u[3 * i]; b1 = u[3 * i + 1]; b2 = u[3 * i + 2];
+  });
+  f = __shfl(f, 0);
+
+  double alpha = 1.0;
+  int npairs = 0, head = 0, nfev = 1, it = 0, status = NEO_MPC_STATUS_MAX_ITER;
+  for (it = 0; it < p.max_it; ++it) {
+    // ---- adjoint gradient of the tracking + terminal cost (all lanes walk the same sweep)
+    {
+      double x = 0.0, y = 0.0, th = 0.0;
+      for (int i = 0; i < n; ++i) {
+        const double vx = u[3 * i], vy = u[3 * i + 1], w = u[3 * i + 2];
+        th += w * p.dt;
+        double sn, cs;
+        sincos(th, &sn, &cs);
+        const double ddx = (vx * cs - vy * sn) * p.dt, ddy = (vx * sn + vy * cs) * p.dt;
+        x += ddx; y += ddy;
+        double rt = -2.0 * p.wo_n * (c.tyaw - th);
+        if (i == n - 1) rt += -2.0 * p.wterm_o * (c.fyaw - th);
+        if (lane == 0) {
+          ACS[i] = cs; ASN[i] = sn; ADX[i] = ddx; ADY[i] = ddy;
+          ARX[i] = -2.0 * p.wt_n * (c.cx - x); ARY[i] = -2.0 * p.wt_n * (c.cy - y); ART[i] = rt;
+        }
+      }
+      WAVE_SYNC();
+      double SX = 0.0, SY = 0.0, ST = 0.0;
+      for (int k = n - 1; k >= 0; --k) {
+        SX += ARX[k]; SY += ARY[k];
+        ST += ART[k] - ADY[k] * SX + ADX[k] * SY;
+        if (lane == 0) {
+          gs[3 * k] = p.dt * (ACS[k] * SX + ASN[k] * SY);
+          gs[3 * k + 1] = p.dt * (-ASN[k] * SX + ACS[k] * SY);
+          gs[3 * k + 2] = p.dt * ST;
+        }
+      }
+      WAVE_SYNC();
+    }
+    // ---- total gradient (control norm: minimal-norm subgradient at the kink), tangent-cone
+    //      reduction at active bounds; lanes take steps
+    for (int i = lane; i < n; i += kLanes) {
+      const double u0 = u[3 * i], u1 = u[3 * i + 1], u2 = u[3 * i + 2];
+      const double g0 = gs[3 * i], g1 = gs[3 * i + 1], g2 = gs[3 * i + 2];
+      const double e0 = u0 - c.v0, e1 = u1 - c.v1, e2 = u2 - c.v2;
+      const double ne = sqrt(e0 * e0 + e1 * e1 + e2 * e2);
+      double t0, t1, t2;
+      if (ne > 0.0) {
+        t0 = g0 + p.wc_n * (e0 / ne); t1 = g1 + p.wc_n * (e1 / ne); t2 = g2 + p.wc_n * (e2 / ne);
+      } else {
+        const double ng = sqrt(g0 * g0 + g1 * g1 + g2 * g2);
+        const double sh = (ng > p.wc_n) ? 1.0 - p.wc_n / ng : 0.0;
+        t0 = g0 * sh; t1 = g1 * sh; t2 = g2 * sh;
+      }
+      gt[3 * i] = t0; gt[3 * i + 1] = t1; gt[3 * i + 2] = t2;
+      const int wfroz = ((u2 <= p.lo[2] && t2 > 0.0) || (u2 >= p.hi[2] && t2 < 0.0)) ? 1 : 0;
+      double r0 = t0, r1 = t1;
+      double nx[3], ny[3];
+      int na = 0;
+      if (u0 <= p.lo[0]) { nx[na] = -1.0; ny[na] = 0.0; ++na; }
+      else if (u0 >= p.hi[0]) { nx[na] = 1.0; ny[na] = 0.0; ++na; }
+      if (u1 <= p.lo[1]) { nx[na] = 0.0; ny[na] = -1.0; ++na; }
+      else if (u1 >= p.hi[1]) { nx[na] = 0.0; ny[na] = 1.0; ++na; }
+      const double nvv = sqrt(u0 * u0 + u1 * u1);
+      if (nvv > 0.0 && nvv >= p.r * (1.0 - 1e-12)) { nx[na] = u0 / nvv; ny[na] = u1 / nvv; ++na; }
+      const double dx = -t0, dy = -t1;
+      int mode = 0;
+      double mnx = 0.0, mny = 0.0;
+      bool violated = false;
+      for (int k = 0; k < na; ++k) violated = violated || (nx[k] * dx + ny[k] * dy > 0.0);
+      if (violated) {
+        double bestn = -1.0;
+        int bestk = -1;
+        for (int k = 0; k < na; ++k) {
+          const double dn = nx[k] * dx + ny[k] * dy;
+          if (!(dn > 0.0)) continue;
+          const double px = dx - dn * nx[k], py = dy - dn * ny[k];
+          bool ok = true;
+          for (int j = 0; j < na; ++j)
+            if (j != k && nx[j] * px + ny[j] * py > 1e-14 * (fabs(px) + fabs(py))) ok = false;
+          const double pn = px * px + py * py;
+          if (ok && pn > bestn) { bestn = pn; bestk = k; }
+        }
+        if (bestk >= 0) {
+          const double dn = nx[bestk] * dx + ny[bestk] * dy;
+          mode = 1; mnx = nx[bestk]; mny = ny[bestk];
+          r0 = -(dx - dn * mnx); r1 = -(dy - dn * mny);
+        } else {
+          mode = 2; r0 = 0.0; r1 = 0.0;
+        }
+      }
+      gr[3 * i] = r0; gr[3 * i + 1] = r1; gr[3 * i + 2] = wfroz ? 0.0 : t2;
+      ANX[i] = mnx; ANY[i] = mny; AMODE[2 * i] = mode; AMODE[2 * i + 1] = wfroz;
+    }
+    WAVE_SYNC();
+    // ---- new curvature pair
+    if (it > 0) {
+      double* s = Sm + head * nv;
+      double* yv = Ym + head * nv;
+      double sy = 0.0, ss = 0.0, yy = 0.0;
+      for (int k = lane; k < nv; k += kLanes) {
+        const double sk = u[k] - u_prev[k], yk = gt[k] - gt_prev[k];
+        s[k] = sk; yv[k] = yk;
+        sy += sk * yk; ss += sk * sk; yy += yk * yk;
+      }
+      sy = wave_sum(sy); ss = wave_sum(ss); yy = wave_sum(yy);
+      const int ok = uniform_int((ss > 0.0 && sy > 1e-10 * sqrt(ss * yy)) ? 1 : 0);
+      if (ok) {
+        if (lane == 0) rho[head] = 1.0 / sy;
+        head = (head + 1) % mem;
+        if (npairs < mem) ++npairs;
+      }
+      WAVE_SYNC();
+    }
+    // ---- L-BFGS two-loop recursion on the reduced gradient; lanes take vector elements
+    {
+      double al[NEO_MPC_MAX_LBFGS_MEMORY];
+      double q0 = lane < nv ? gr[lane] : 0.0;
+      double q1 = lane + 64 < nv ? gr[lane + 64] : 0.0;
+      double q2 = lane + 128 < nv ? gr[lane + 128] : 0.0;
+      for (int j = 0; j < npairs; ++j) {
+        const int idx = (head - 1 - j + 2 * mem) % mem;
+        const double* s = Sm + idx * nv;
+        const double* yv = Ym + idx * nv;
+        double part = 0.0;
+        if (lane < nv) part += s[lane] * q0;
+        if (lane + 64 < nv) part += s[lane + 64] * q1;
+        if (lane + 128 < nv) part += s[lane + 128] * q2;
+        al[j] = rho[idx] * wave_sum(part);
+        if (lane < nv) q0 -= al[j] * yv[lane];
+        if (lane + 64 < nv) q1 -= al[j] * yv[lane + 64];
+        if (lane + 128 < nv) q2 -= al[j] * yv[lane + 128];
+      }
+      if (npairs > 0) {
+        const int idx = (head - 1 + mem) % mem;
+        const double* yv = Ym + idx * nv;
+        double part = 0.0;
+        if (lane < nv) part += yv[lane] * yv[lane];
+        if (lane + 64 < nv) part += yv[lane + 64] * yv[lane + 64];
+        if (lane + 128 < nv) part += yv[lane + 128] * yv[lane + 128];
+        const double gamma = 1.0 / (rho[idx] * wave_sum(part));
+        q0 *= gamma; q1 *= gamma; q2 *= gamma;
+      }
+      for (int j = npairs - 1; j >= 0; --j) {
+        const int idx = (head - 1 - j + 2 * mem) % mem;
+        const double* s = Sm + idx * nv;
+        const double* yv = Ym + idx * nv;
+        double part = 0.0;
+        if (lane < nv) part += yv[lane] * q0;
+        if (lane + 64 < nv) part += yv[lane + 64] * q1;
+        if (lane + 128 < nv) part += yv[lane + 128] * q2;
+        const double be = rho[idx] * wave_sum(part);
+        if (lane < nv) q0 += s[lane] * (al[j] - be);
+        if (lane + 64 < nv) q1 += s[lane + 64] * (al[j] - be);
+        if (lane + 128 < nv) q2 += s[lane + 128] * (al[j] - be);
+      }
+      if (lane < nv) d[lane] = -q0;
+      if (lane + 64 < nv) d[lane + 64] = -q1;
+      if (lane + 128 < nv) d[lane + 128] = -q2;
+      WAVE_SYNC();
+      for (int i = lane; i < n; i += kLanes) {  // restrict to the tangent cone's face
+        if (AMODE[2 * i + 1]) d[3 * i + 2] = 0.0;
+        const int mode = AMODE[2 * i];
+        if (mode == 1) {
+          const double dot = d[3 * i] * ANX[i] + d[3 * i + 1] * ANY[i];
+          d[3 * i] -= dot * ANX[i]; d[3 * i + 1] -= dot * ANY[i];
+        } else if (mode == 2) {
+          d[3 * i] = 0.0; d[3 * i + 1] = 0.0;
+        }
+      }
+      WAVE_SYNC();
+    }
+    // ---- 64 candidates, one rollout per lane; lowest objective wins
+    const double step = (lane < 32 ? alpha : 1.0) * lane_scale(lane);
+    double fc = rollout_cost(a, c, L, [&](int i, double& b0, double& b1, double& b2) {
+      candidate_block(a, c, L, lane, step, i, b0, b1, b2);
+    });
+    if (!(fc == fc)) fc = INFINITY;
+    double fb = fc;
+    int best = lane;
+    wave_argmin(fb, best);
+    ++nfev;
+    if (!(fb < f)) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
+    if (lane == best) {
+      for (int i = 0; i < n; ++i) {
+        double b0, b1, b2;
+        candidate_block(a, c, L, lane, step, i, b0, b1, b2);
+        u_new[3 * i] = b0; u_new[3 * i + 1] = b1; u_new[3 * i + 2] = b2;
+      }
+    }
+    WAVE_SYNC();
+    double stepmax = 0.0;
+    for (int k = lane; k < nv; k += kLanes) {
+      const double nu = u_new[k], ou = u[k];
+      stepmax = fmax(stepmax, fabs(nu - ou));
+      u_prev[k] = ou; gt_prev[k] = gt[k]; u[k] = nu;
+    }
+    stepmax = wave_max(stepmax);
+    f = fb;
+    if (best < 32) {
+      alpha = __shfl(step, best);
+      alpha = clampd(alpha, 1e-6, 1e6);
+    }
+    WAVE_SYNC();
+    if (stepmax < p.xtol) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
+  }
+
+  if (a.solution)
+    for (int k = lane; k < nv; k += kLanes) a.solution[(size_t)b * nv + k] = u[k];
+  WAVE_SYNC();
+  postprocess(a, c, L, b, lane, u, status == NEO_MPC_STATUS_CONVERGED, fcost, flags, f, status, it, nfev);
+}
+
+// K2 on its own: `solution` supplies x.x, `success` supplies x.success
+__global__ __launch_bounds__(kLanes) void k_postprocess(const SolveArgs a) {
+  extern __shared__ __align__(16) double L[];
+  const int lane = threadIdx.x;
+  const uint32_t b = blockIdx.x;
+  if (b >= a.count) return;
+  const int nv = 3 * a.p.n;
+  load_records(a, L, b, lane);
+  int flags = reset_and_warm(a, L, b, lane) ? NEO_MPC_FLAG_RESET : 0;
+  const double fcost = footprint_cost(a, L, b, lane);
+  Ctx c;
+  make_ctx(a.p, a.map, L + a.lds.prob, fcost, c);
+  load_tile(a, c, L, lane);
+  double* u = L + a.lds.u;
+  for (int k = lane; k < nv; k += kLanes) u[k] = a.solution[(size_t)b * nv + k];
+  WAVE_SYNC();
+  double f = rollout_cost(a, c, L, [&](int i, double& b0, double& b1, double& b2) {
+    b0 = u[3 * i]; b1 = u[3 * i + 1]; b2 = u[3 * i + 2];
+  });
+  f = __shfl(f, 0);
+  const bool success = a.success ? a.success[b] != 0 : true;
+  postprocess(a, c, L, b, lane, u, success, fcost, flags, f, success ? 0 : 1, 0, 1);
+}
+
+// py:204-269 for given controls, one lane per instance
+__global__ __launch_bounds__(256) void k_objective(const ObjectiveArgs a) {
+  __shared__ double term[256];
+  term[threadIdx.x] = a.term_table[threadIdx.x];
+  __syncthreads();
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.count) return;
+  SolveArgs sa = {};
+  sa.p = a.p; sa.map = a.map;
+  sa.lds.term = 0; sa.lds.tile = 0; sa.lds.tile_w = 0; sa.lds.tile_h = 0;
+  const double* P = reinterpret_cast<const double*>(a.problems + b);
+  Ctx c;
+  make_ctx(a.p, a.map, P, P[P_FOOTPRINT], c);
+  const double* u = a.u + (size_t)b * 3 * a.p.n;
+  a.cost[b] = rollout_cost(sa, c, term, [&](int i, double& b0, double& b1, double& b2) {
+    b0 = u[3 * i]; b1 = u[3 * i + 1]; b2 = u[3 * i + 2];
+  });
+}
+
+// K3: raw nav2 costmap -> bordered, pitched device map.  One 16-byte store per lane.
+__global__ __launch_bounds__(256) void k_ingest(const IngestArgs a) {
+  const int chunks_per_row = a.pitch >> 4;
+  const long total = (long)a.rows * chunks_per_row;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(idx / chunks_per_row), chunk = (int)(idx - (long)row * chunks_per_row);
+    const int my = row - kMapBorder;
+    const int mx0 = chunk * 16 - kMapBorder;
+    uint4 v = make_uint4(0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu);
+    if (my >= 0 && my < a.size_y && mx0 + 16 > 0 && mx0 < a.size_x) {
+      uint8_t bytes[16];
+      const uint8_t* src = a.src + (long)my * a.size_x;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int mx = mx0 + k;
+        bytes[k] = (mx >= 0 && mx < a.size_x) ? src[mx] : (uint8_t)254;
+      }
+      v = *reinterpret_cast<const uint4*>(bytes);
+    }
+    *reinterpret_cast<uint4*>(a.dst + (long)row * a.pitch + chunk * 16) = v;
+  }
+}
+
+}  // namespace
+
+void launch_solve(const SolveArgs& a, void* stream) {
+  if (a.count == 0) return;
+  hipLaunchKernelGGL(k_solve, dim3(a.count), dim3(kLanes), a.lds.total_bytes, (hipStream_t)stream, a);
+}
+void launch_postprocess(const SolveArgs& a, void* stream) {
+  if (a.count == 0) return;
+  hipLaunchKernelGGL(k_postprocess, dim3(a.count), dim3(kLanes), a.lds.total_bytes, (hipStream_t)stream, a);
+}
+void launch_objective(const ObjectiveArgs& a, void* stream) {
+  if (a.count == 0) return;
+  hipLaunchKernelGGL(k_objective, dim3((a.count + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+}
+void launch_ingest(const IngestArgs& a, void* stream) {
+  const long total = (long)a.rows * (a.pitch >> 4);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_ingest, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+}
+
+}  // namespace neo_mpc

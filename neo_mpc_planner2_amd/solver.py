@@ -1,0 +1,171 @@
+"""Batched MPC solver handle: thin Python host side over the C-ABI (include/neo_mpc.h).
+
+`BatchSolver` is what bench.py, the tests and `MpcOptimizationServer` (the mirror of
+the reference's service node) drive.  Host (NumPy) batches go through
+`neo_mpc_solve_batch`; device-resident batches (torch CUDA tensors, plumbing only)
+through `neo_mpc_solve_batch_device` on torch's current stream.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, abi
+
+
+class BatchSolver:
+    """One solver configuration + one costmap on one GPU (a `neo_mpc_handle`)."""
+
+    def __init__(self, params=None, device=0, **overrides):
+        self._lib = _lib.load()
+        self._handle = None
+        self.params = dict(params or {})
+        self.params.update(overrides)
+        ps = abi.params_struct(self.params)
+        self.control_steps = int(ps.control_steps)
+        self.device = int(device)
+        h = self._lib.neo_mpc_create(C.byref(ps), self.device)
+        if not h:
+            raise _lib.NeoMpcError(-1, (self._lib.neo_mpc_last_error() or b"").decode())
+        self._handle = C.c_void_p(h)
+        self._keep = None
+
+    # -- lifecycle ------------------------------------------------------------------
+    def close(self):
+        if self._handle is not None:
+            self._lib.neo_mpc_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- configuration --------------------------------------------------------------
+    def set_params(self, **changes):
+        """Dynamic reconfigure (reference: cb_params, mpc_optimization_server.py:405-439)."""
+        self.params.update(changes)
+        ps = abi.params_struct(self.params)
+        if int(ps.control_steps) != self.control_steps:
+            raise ValueError("control_steps cannot change on a live handle (the reference bakes it at init, py:125-137)")
+        _lib.check(self._lib.neo_mpc_set_params(self._handle, C.byref(ps)))
+
+    def set_costmap(self, cells, resolution, origin_x, origin_y):
+        """cells: uint8 [size_y, size_x] raw nav2 costs (NumPy) or a CUDA uint8 torch tensor."""
+        if isinstance(cells, np.ndarray):
+            cells = np.ascontiguousarray(cells, dtype=np.uint8)
+            sy, sx = cells.shape
+            _lib.check(self._lib.neo_mpc_set_costmap(self._handle, C.c_void_p(cells.ctypes.data), sx, sy,
+                                                    float(resolution), float(origin_x), float(origin_y)))
+        else:
+            import torch
+            assert cells.is_cuda and cells.dtype == torch.uint8 and cells.is_contiguous()
+            sy, sx = cells.shape
+            stream = torch.cuda.current_stream(cells.device).cuda_stream
+            _lib.check(self._lib.neo_mpc_set_costmap_device(
+                self._handle, C.c_void_p(cells.data_ptr()), sx, sy, float(resolution), float(origin_x),
+                float(origin_y), C.c_void_p(stream)))
+
+    def kernel_info(self):
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _lib.check(self._lib.neo_mpc_kernel_info(self._handle, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(lds_bytes=a.value, reach_cells=b.value, tile_in_lds=bool(c.value))
+
+    # -- host batches ----------------------------------------------------------------
+    def _host_batch(self, problems, states, warm, solution, want_path, footprints):
+        n = self.control_steps
+        problems = np.ascontiguousarray(problems, dtype=abi.PROBLEM_DTYPE)
+        count = problems.shape[0]
+        assert states.dtype == abi.STATE_DTYPE and states.shape == (count,) and states.flags.c_contiguous
+        assert warm.dtype == np.float64 and warm.shape == (count, 3 * n) and warm.flags.c_contiguous
+        commands = np.zeros(count, dtype=abi.COMMAND_DTYPE)
+        path = np.zeros((count, n, 3)) if want_path else None
+        if footprints is not None:
+            footprints = np.ascontiguousarray(footprints, dtype=np.float64)
+            assert footprints.shape[0] == count and footprints.shape[2] == 2
+        b = abi.batch_struct(problems, states, warm, commands, solution, path, footprints)
+        self._keep = (problems, footprints)
+        return b, commands, path
+
+    def solve(self, problems, states, warm, want_path=False, footprints=None):
+        """`optimizer()` (py:349-403) for a batch of host records.  `states` / `warm` are
+        updated in place.  Returns (commands, solution[, path])."""
+        count = len(problems)
+        solution = np.zeros((count, 3 * self.control_steps))
+        b, commands, path = self._host_batch(problems, states, warm, solution, want_path, footprints)
+        _lib.check(self._lib.neo_mpc_solve_batch(self._handle, C.byref(b)))
+        return (commands, solution, path) if want_path else (commands, solution)
+
+    def postprocess(self, problems, states, warm, solution, success=None, want_path=False, footprints=None):
+        """Everything of `optimizer()` after the solve (py:365-403) with `solution` = x.x."""
+        solution = np.ascontiguousarray(solution, dtype=np.float64)
+        b, commands, path = self._host_batch(problems, states, warm, solution, want_path, footprints)
+        sp = None
+        if success is not None:
+            success = np.ascontiguousarray(success, dtype=np.int32)
+            sp = C.c_void_p(success.ctypes.data)
+        _lib.check(self._lib.neo_mpc_postprocess_batch(self._handle, C.byref(b), sp))
+        return (commands, path) if want_path else commands
+
+    def objective(self, problems, u):
+        """`objective()` (py:204-269) on the device for u[count, 3*control_steps]."""
+        problems = np.ascontiguousarray(problems, dtype=abi.PROBLEM_DTYPE)
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        out = np.zeros(len(problems))
+        _lib.check(self._lib.neo_mpc_objective_batch(
+            self._handle, C.c_void_p(problems.ctypes.data), C.c_void_p(u.ctypes.data),
+            C.c_void_p(out.ctypes.data), len(problems)))
+        return out
+
+    # -- device-resident batches (torch tensors as plain device memory) ----------------
+    def solve_device(self, problems, states, warm, commands, solution=None, path=None, footprints=None,
+                     stream=None):
+        """All arguments are CUDA uint8/float64 torch tensors holding the C records
+        (`DeviceBatch` builds them).  Enqueues K1 on `stream` (default: torch's current)."""
+        import torch
+        count = problems.shape[0]
+        b = abi.NeoMpcBatch()
+        b.count = count
+        b.problems = problems.data_ptr()
+        b.states = states.data_ptr()
+        b.warm_start = warm.data_ptr()
+        b.commands = commands.data_ptr()
+        b.solution = solution.data_ptr() if solution is not None else None
+        b.predicted_path = path.data_ptr() if path is not None else None
+        if footprints is not None:
+            b.footprints = footprints.data_ptr()
+            b.footprint_points = footprints.shape[1]
+        if stream is None:
+            stream = torch.cuda.current_stream(problems.device).cuda_stream
+        _lib.check(self._lib.neo_mpc_solve_batch_device(self._handle, C.byref(b), C.c_void_p(stream)))
+
+
+class DeviceBatch:
+    """A batch resident in HBM: the C records as torch CUDA byte/float64 tensors."""
+
+    def __init__(self, problems, states, warm, device, want_solution=True):
+        import torch
+        self.count = len(problems)
+        dev = torch.device(device)
+        self.problems = torch.from_numpy(np.ascontiguousarray(problems).view(np.uint8).reshape(self.count, -1)).to(dev)
+        self.states = torch.from_numpy(np.ascontiguousarray(states).view(np.uint8).reshape(self.count, -1)).to(dev)
+        self.warm = torch.from_numpy(np.ascontiguousarray(warm)).to(dev)
+        self.commands = torch.zeros((self.count, abi.COMMAND_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        self.solution = torch.zeros_like(self.warm) if want_solution else None
+
+    def commands_host(self):
+        return self.commands.cpu().numpy().view(abi.COMMAND_DTYPE).reshape(self.count)
+
+    def velocities(self):
+        """(count, 3) float64 view of the (vx, vy, omega) outputs on the device."""
+        import torch
+        return self.commands.view(torch.float64).view(self.count, 6)[:, :3]
+
+    def states_host(self):
+        return self.states.cpu().numpy().view(abi.STATE_DTYPE).reshape(self.count)

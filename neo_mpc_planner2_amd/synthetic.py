@@ -103,3 +103,17 @@ def make_workload(name, seed=0, batch=None):
     probs = make_problems(cfg["batch"], cfg["map_size"], seed=seed + 1000)
     st, warm = make_states(probs, cfg["control_steps"])
     return cfg, cmap, probs, st, warm
+
+
+#: a rectangular robot outline in the base frame (metres)
+RECT_FOOTPRINT = ((0.35, 0.25), (-0.35, 0.25), (-0.35, -0.25), (0.35, -0.25))
+
+
+def footprint_world(prob_row, base=RECT_FOOTPRINT):
+    """The footprint polygon nav2 publishes on /local_costmap/published_footprint: `base`
+    placed at the request's current pose (global frame)."""
+    x0, y0 = prob_row["cur_xy"]
+    q = prob_row["cur_q"]
+    yaw = math.atan2(2.0 * (q[3] * q[2] + q[0] * q[1]), 1.0 - 2.0 * (q[1] * q[1] + q[2] * q[2]))
+    c, s = math.cos(yaw), math.sin(yaw)
+    return [(x0 + px * c - py * s, y0 + px * s + py * c) for (px, py) in base]

@@ -42,16 +42,7 @@ def params_vec(p):
     return np.array([float(p[k]) for k in PARAM_KEYS], dtype=np.float64)
 
 
-RECT_FOOTPRINT = ((0.35, 0.25), (-0.35, 0.25), (-0.35, -0.25), (0.35, -0.25))
-
-
-def footprint_world(prob_row, base=RECT_FOOTPRINT):
-    """published footprint = base polygon placed at the current pose (global frame)."""
-    x0, y0 = prob_row["cur_xy"]
-    q = prob_row["cur_q"]
-    yaw = math.atan2(2.0 * (q[3] * q[2] + q[0] * q[1]), 1.0 - 2.0 * (q[1] * q[1] + q[2] * q[2]))
-    c, s = math.cos(yaw), math.sin(yaw)
-    return [(x0 + px * c - py * s, y0 + px * s + py * c) for (px, py) in base]
+footprint_world = synthetic.footprint_world
 
 
 class Ref:

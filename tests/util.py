@@ -35,3 +35,5 @@ def oracle_problem(row, footprint=None):
 
 def oracle_costmap(cells, meta):
     return orc.Costmap(cells, meta[0], meta[1], meta[2])
+
+orc = orc  # re-export: tests use util.orc.make_params
