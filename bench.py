@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- MPC solves/sec of the batched HIP solver (BASELINE.json metric).
+
+A "step" is one pass of the hot path (K1: full `optimizer()` equivalent -- solve +
+low-pass + collision check + acceleration clamp + warm-start shift) over one batch of
+synthetic instances that is already resident in HBM.  Workload = BASELINE config 2:
+4 096 independent instances per GPU, control_steps=3, 500x500 costmap, README params.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: weak scaling, instances shard embarrassingly (one process per GPU, each
+with its own 4 096 instances and a replica of the costmap); the only exchange is one
+RCCL all-gather of the (vx, vy, omega) commands per step.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# BASELINE.md "Algorithmic bytes per solve": inputs (17+3N)*4 + outputs (3+3N+1)*4 + reach tile 729
+ALGO_BYTES = {3: 885, 8: 1005, 32: 1581}
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def readme_params(control_steps):
+    from neo_mpc_planner2_amd.mpc_optimization_server import README_PARAMS
+    p = dict(README_PARAMS)
+    p["control_steps"] = control_steps
+    return p
+
+
+def cpu_baseline(params, cmap, probs, seconds=15.0):
+    """The reference's path restated (oracle/mpc_oracle.py): SciPy SLSQP at ftol=opt_tolerance on
+    the Python objective, cold start, on a bounded sample of the SAME workload, 1 core."""
+    from oracle import mpc_oracle as orc
+    cm = orc.Costmap(*cmap)
+    n = params["control_steps"]
+    done, t0 = 0, time.perf_counter()
+    while done < len(probs):
+        row = probs[done]
+        prob = orc.Problem(row["cur_xy"], row["cur_q"], row["carrot_xy"], row["carrot_q"], row["goal_xyz"],
+                           row["goal_q"], row["cur_vel"], float(row["control_interval"]), float(row["delta_t"]))
+        state = orc.ServerState(n)
+        state.old_goal = prob.goal_key()
+        state.last_control = list(prob.cur_vel)
+        state.waiting_time = 0.0
+        orc.optimizer_step(state, prob, params, cm)
+        done += 1
+        if time.perf_counter() - t0 > seconds:
+            break
+    dt = time.perf_counter() - t0
+    return done / dt, done, dt
+
+
+def cpu_mirror_rate(params, cmap, probs, st, warm):
+    """Secondary: the build's own algorithm on the host cores (oracle/mpc_oracle.c, OpenMP)."""
+    from oracle import c_oracle
+    c_oracle.load()
+    t0 = time.perf_counter()
+    c_oracle.solve_batch(params, cmap, probs, st.copy(), warm.copy())
+    return len(probs) / (time.perf_counter() - t0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="C2", choices=["C2", "C3", "C5"])
+    ap.add_argument("--batch", type=int, default=None, help="instances per GPU (default: the config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from neo_mpc_planner2_amd import synthetic
+    from neo_mpc_planner2_amd.solver import BatchSolver, DeviceBatch
+    from neo_mpc_planner2_amd.sharding import gather_commands
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    cfg = dict(synthetic.CONFIGS[args.workload])
+    if args.batch:
+        cfg["batch"] = args.batch
+    n = cfg["control_steps"]
+    params = readme_params(n)
+    cmap = synthetic.make_costmap(cfg["map_size"], seed=0)                 # shared map, replicated
+    probs = synthetic.make_problems(cfg["batch"], cfg["map_size"], seed=1000 + rank)
+    st, warm = synthetic.make_states(probs, n)
+
+    solver = BatchSolver(params, device=local_rank)
+    solver.set_costmap(torch.from_numpy(cmap[0]).to(dev), *cmap[1:])
+    # one fresh (state, warm start, command) set per step, allocated up front (about 1 MB per
+    # set at C2), so every step solves the same cold problems and nothing but the hot path runs
+    # inside the timed region; the problems themselves are read-only and shared
+    base = DeviceBatch(probs, st, warm, dev, want_solution=False)
+    sets = [base.fresh_state() for _ in range(args.steps)]
+    warm_sets = [base.fresh_state() for _ in range(min(args.warmup, 8))]
+    gathered = torch.empty((world, cfg["batch"], 3), dtype=torch.float64, device=dev) if world > 1 else None
+    stream = torch.cuda.current_stream()
+
+    for i in range(args.warmup):
+        b = warm_sets[i % len(warm_sets)]
+        solver.solve_device(base.problems, b.states, b.warm, b.commands)
+        if world > 1:
+            gather_commands(b.velocities(), gathered)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        b = sets[i]
+        evs[i][0].record(stream)
+        solver.solve_device(base.problems, b.states, b.warm, b.commands)
+        evs[i][1].record(stream)
+        if world > 1:
+            gather_commands(b.velocities(), gathered)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = [a.elapsed_time(b) for a, b in evs]
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    cmds = sets[0].commands_host()
+    if rank == 0:
+        total_instances = cfg["batch"] * world
+        value = total_instances * args.steps / elapsed
+        k_ms = float(np.mean(kernel_ms))
+        achieved = ALGO_BYTES[n] * cfg["batch"] / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "MPC solves/sec (control_steps=%d, %dx%d costmap)" % (n, cfg["map_size"], cfg["map_size"]),
+            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: batch %d instances/GPU, control_steps=%d, horizon=0.8 s, %dx%d u8 costmap, "
+                                   "README params, cold start" % (args.workload, cfg["batch"], n, cfg["map_size"],
+                                                                  cfg["map_size"]),
+                       "parallelism": "instances sharded x%d, 1 RCCL all-gather of (vx,vy,w)/step" % world
+                       if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_solve", "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_solve": ALGO_BYTES[n]},
+            "solver": {"mean_iterations": float(cmds["iterations"].mean()),
+                       "converged_frac": float((cmds["status"] == 0).mean())},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rate, cnt, secs = cpu_baseline(params, cmap, probs)
+            out["cpu_baseline"] = {"value": rate, "unit": "solves/s", "cores": 1, "kind": "port",
+                                   "sample": "first %d of the %d %s instances, SciPy SLSQP ftol=%g on the restated "
+                                             "Python objective (oracle/mpc_oracle.py), cold start, %.1f s"
+                                             % (cnt, cfg["batch"], args.workload, params["opt_tolerance"], secs)}
+            try:
+                sub = min(len(probs), 4096)
+                out["cpu_mirror"] = {"value": cpu_mirror_rate(params, cmap, probs[:sub], st[:sub], warm[:sub]),
+                                     "unit": "solves/s", "cores": os.cpu_count(),
+                                     "what": "the build's own algorithm in C with OpenMP (oracle/mpc_oracle.c)"}
+            except Exception as e:  # the mirror is informational
+                out["cpu_mirror"] = {"error": str(e)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

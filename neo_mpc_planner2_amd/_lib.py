@@ -38,6 +38,13 @@ def load():
         raise ImportError(
             "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C neo_mpc_planner2_amd/csrc`).  There is no CPU fallback." % LIB_PATH)
+    # PyTorch wheels bundle their own HIP runtime; if torch is going to be used in this process
+    # (device memory / streams / torch.distributed plumbing) it must initialise that runtime
+    # BEFORE another copy is mapped, otherwise torch reports "No HIP GPUs are available".
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     P = C.POINTER
     lib.neo_mpc_abi_version.restype = C.c_int

@@ -118,6 +118,8 @@ void derive(neo_mpc_handle* h) {
   d.acc[0] = p.acc_x_limit; d.acc[1] = p.acc_y_limit; d.acc[2] = p.acc_theta_limit;
   d.low_pass_gain = p.low_pass_gain;
   d.xtol = p.step_tolerance > 0.0 ? p.step_tolerance : 1e-3 * p.opt_tolerance;
+  d.ftol = p.cost_tolerance > 0.0 ? p.cost_tolerance : 3e-6 * p.opt_tolerance;
+  d.kink_radius = p.kink_radius > 0.0 ? p.kink_radius : 3e-3;
   d.max_it = p.max_iterations > 0 ? p.max_iterations : 100;
   d.mem = p.lbfgs_memory > 0 ? p.lbfgs_memory : 4;
   d.compat = p.compat_flags;
@@ -133,7 +135,7 @@ void derive(neo_mpc_handle* h) {
   l.S = take(d.mem * nv); l.Y = take(d.mem * nv); l.rho = take(NEO_MPC_MAX_LBFGS_MEMORY);
   l.cs = take(n); l.sn = take(n); l.dxs = take(n); l.dys = take(n);
   l.rx = take(n); l.ry = take(n); l.rt = take(n); l.nx = take(n); l.ny = take(n);
-  l.mode = take(n);
+  l.mode = take(2 * n);  // int[4n]: mode, omega-frozen, near-kink, near-kink at the previous iterate
   off = (off + 1) & ~1;  // 16-byte align the tile
   l.tile = off;
   l.tile_w = 0; l.tile_h = 0; l.reach = 0;
@@ -291,6 +293,8 @@ int neo_mpc_default_params(neo_mpc_params* p) {
   p->lbfgs_memory = 4;
   p->compat_flags = NEO_MPC_COMPAT_ODOM_YAW_GOAL_W;
   p->step_tolerance = 0.0;
+  p->cost_tolerance = 0.0;
+  p->kink_radius = 0.0;
   return NEO_MPC_OK;
 }
 

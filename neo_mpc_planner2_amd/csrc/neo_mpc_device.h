@@ -24,6 +24,8 @@ struct DevParams {
   double acc[3];             // post clamp (py:385-391)
   double low_pass_gain;      // py:367
   double xtol;               // step tolerance
+  double ftol;               // relative cost decrease below which an iteration counts as stalled
+  double kink_radius;        // |u_i - v_cur| below which a block is handled by the prox step only
   int32_t n;                 // control_steps
   int32_t max_it;
   int32_t mem;               // L-BFGS pairs

@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "neo_mpc_device.h"
 
@@ -33,6 +34,10 @@ namespace neo_mpc {
 namespace {
 
 #define WAVE_SYNC() __syncthreads()
+
+// consecutive iterations gaining less than ftol*max(1,|f|) that end the search (creeping along a
+// costmap cell edge gains ~1e-9 per iteration for ever)
+constexpr int kStallIterations = 5;
 
 // ---------------------------------------------------------------- wave primitives
 __device__ __forceinline__ double wave_sum(double v) {
@@ -186,10 +191,15 @@ __device__ __forceinline__ double lane_scale(int lane) {
 }
 
 // control block i of this lane's candidate
+// (`step`: this lane's step along its own family; `pstep`: its proximal-gradient step length, used
+// by the L-BFGS lanes for blocks sitting next to the control-norm kink)
 __device__ __forceinline__ void candidate_block(const SolveArgs& a, const Ctx& c, const double* L, int lane,
-                                                double step, int i, double& b0, double& b1, double& b2) {
+                                                double step, double pstep, int i, double& b0, double& b1,
+                                                double& b2) {
   const double* u = L + a.lds.u + 3 * i;
-  if (lane < 32) {  // proximal gradient: forward step on the smooth part, prox of the control norm
+  const bool near = reinterpret_cast<const int*>(L + a.lds.mode)[4 * i + 2] != 0;
+  if (lane < 32 || near) {  // proximal gradient: forward step on the smooth part, prox of the control norm
+    if (lane >= 32) step = pstep;
     const double* gs = L + a.lds.gs + 3 * i;
     const double e0 = (u[0] - step * gs[0]) - c.v0, e1 = (u[1] - step * gs[1]) - c.v1,
                  e2 = (u[2] - step * gs[2]) - c.v2;
@@ -380,7 +390,8 @@ __device__ void load_records(const SolveArgs& a, double* L, uint32_t b, int lane
 }
 
 // ---------------------------------------------------------------- K1
-__global__ __launch_bounds__(kLanes) void k_solve(const SolveArgs a) {
+template <int kMinWavesPerSimd>
+__global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveArgs a) {
   extern __shared__ __align__(16) double L[];
   const int lane = threadIdx.x;
   const uint32_t b = blockIdx.x;
@@ -415,7 +426,7 @@ __global__ __launch_bounds__(kLanes) void k_solve(const SolveArgs a) {
   double* ART = L + a.lds.rt;
   double* ANX = L + a.lds.nx;
   double* ANY = L + a.lds.ny;
-  int* AMODE = reinterpret_cast<int*>(L + a.lds.mode);  // [2n]: mode[i], wfroz[i]
+  int* AMODE = reinterpret_cast<int*>(L + a.lds.mode);  // [4n]: mode, wfroz, near, near_prev
 
   // x0 clipped to the feasible set (SciPy clips x0 to the bounds, _slsqp_py.py:268)
   for (int i = lane; i < n; i += kLanes) project_block(p, u[3 * i], u[3 * i + 1], u[3 * i + 2]);
@@ -425,8 +436,9 @@ __global__ __launch_bounds__(kLanes) void k_solve(const SolveArgs a) {
   });
   f = __shfl(f, 0);
 
+  for (int i = lane; i < n; i += kLanes) { AMODE[4 * i + 2] = 0; AMODE[4 * i + 3] = 0; }
   double alpha = 1.0;
-  int npairs = 0, head = 0, nfev = 1, it = 0, status = NEO_MPC_STATUS_MAX_ITER;
+  int npairs = 0, head = 0, nfev = 1, it = 0, status = NEO_MPC_STATUS_MAX_ITER, stall = 0;
   for (it = 0; it < p.max_it; ++it) {
     // ---- adjoint gradient of the tracking + terminal cost (all lanes walk the same sweep)
     {
@@ -473,6 +485,13 @@ __global__ __launch_bounds__(kLanes) void k_solve(const SolveArgs a) {
         const double sh = (ng > p.wc_n) ? 1.0 - p.wc_n / ng : 0.0;
         t0 = g0 * sh; t1 = g1 * sh; t2 = g2 * sh;
       }
+      AMODE[4 * i + 3] = AMODE[4 * i + 2];
+      if (ne < p.kink_radius) {  // next to the kink: prox-only block, outside the quasi-Newton model
+        gt[3 * i] = 0.0; gt[3 * i + 1] = 0.0; gt[3 * i + 2] = 0.0;
+        gr[3 * i] = 0.0; gr[3 * i + 1] = 0.0; gr[3 * i + 2] = 0.0;
+        ANX[i] = 0.0; ANY[i] = 0.0; AMODE[4 * i] = 0; AMODE[4 * i + 1] = 0; AMODE[4 * i + 2] = 1;
+        continue;
+      }
       gt[3 * i] = t0; gt[3 * i + 1] = t1; gt[3 * i + 2] = t2;
       const int wfroz = ((u2 <= p.lo[2] && t2 > 0.0) || (u2 >= p.hi[2] && t2 < 0.0)) ? 1 : 0;
       double r0 = t0, r1 = t1;
@@ -511,7 +530,7 @@ __global__ __launch_bounds__(kLanes) void k_solve(const SolveArgs a) {
         }
       }
       gr[3 * i] = r0; gr[3 * i + 1] = r1; gr[3 * i + 2] = wfroz ? 0.0 : t2;
-      ANX[i] = mnx; ANY[i] = mny; AMODE[2 * i] = mode; AMODE[2 * i + 1] = wfroz;
+      ANX[i] = mnx; ANY[i] = mny; AMODE[4 * i] = mode; AMODE[4 * i + 1] = wfroz; AMODE[4 * i + 2] = 0;
     }
     WAVE_SYNC();
     // ---- new curvature pair
@@ -520,7 +539,9 @@ __global__ __launch_bounds__(kLanes) void k_solve(const SolveArgs a) {
       double* yv = Ym + head * nv;
       double sy = 0.0, ss = 0.0, yy = 0.0;
       for (int k = lane; k < nv; k += kLanes) {
-        const double sk = u[k] - u_prev[k], yk = gt[k] - gt_prev[k];
+        const int blk = k / 3;
+        const bool skip = (AMODE[4 * blk + 2] | AMODE[4 * blk + 3]) != 0;
+        const double sk = skip ? 0.0 : u[k] - u_prev[k], yk = skip ? 0.0 : gt[k] - gt_prev[k];
         s[k] = sk; yv[k] = yk;
         sy += sk * yk; ss += sk * sk; yy += yk * yk;
       }
@@ -580,8 +601,9 @@ __global__ __launch_bounds__(kLanes) void k_solve(const SolveArgs a) {
       if (lane + 128 < nv) d[lane + 128] = -q2;
       WAVE_SYNC();
       for (int i = lane; i < n; i += kLanes) {  // restrict to the tangent cone's face
-        if (AMODE[2 * i + 1]) d[3 * i + 2] = 0.0;
-        const int mode = AMODE[2 * i];
+        if (AMODE[4 * i + 2]) { d[3 * i] = 0.0; d[3 * i + 1] = 0.0; d[3 * i + 2] = 0.0; continue; }
+        if (AMODE[4 * i + 1]) d[3 * i + 2] = 0.0;
+        const int mode = AMODE[4 * i];
         if (mode == 1) {
           const double dot = d[3 * i] * ANX[i] + d[3 * i + 1] * ANY[i];
           d[3 * i] -= dot * ANX[i]; d[3 * i + 1] -= dot * ANY[i];
@@ -592,9 +614,10 @@ __global__ __launch_bounds__(kLanes) void k_solve(const SolveArgs a) {
       WAVE_SYNC();
     }
     // ---- 64 candidates, one rollout per lane; lowest objective wins
-    const double step = (lane < 32 ? alpha : 1.0) * lane_scale(lane);
+    const double pstep = alpha * lane_scale(lane);
+    const double step = lane < 32 ? pstep : lane_scale(lane);
     double fc = rollout_cost(a, c, L, [&](int i, double& b0, double& b1, double& b2) {
-      candidate_block(a, c, L, lane, step, i, b0, b1, b2);
+      candidate_block(a, c, L, lane, step, pstep, i, b0, b1, b2);
     });
     if (!(fc == fc)) fc = INFINITY;
     double fb = fc;
@@ -605,7 +628,7 @@ __global__ __launch_bounds__(kLanes) void k_solve(const SolveArgs a) {
     if (lane == best) {
       for (int i = 0; i < n; ++i) {
         double b0, b1, b2;
-        candidate_block(a, c, L, lane, step, i, b0, b1, b2);
+        candidate_block(a, c, L, lane, step, pstep, i, b0, b1, b2);
         u_new[3 * i] = b0; u_new[3 * i + 1] = b1; u_new[3 * i + 2] = b2;
       }
     }
@@ -617,13 +640,14 @@ __global__ __launch_bounds__(kLanes) void k_solve(const SolveArgs a) {
       u_prev[k] = ou; gt_prev[k] = gt[k]; u[k] = nu;
     }
     stepmax = wave_max(stepmax);
+    stall = (f - fb <= p.ftol * fmax(1.0, fabs(fb))) ? stall + 1 : 0;
     f = fb;
     if (best < 32) {
       alpha = __shfl(step, best);
       alpha = clampd(alpha, 1e-6, 1e6);
     }
     WAVE_SYNC();
-    if (stepmax < p.xtol) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
+    if (stepmax < p.xtol || stall >= kStallIterations) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
   }
 
   if (a.solution)
@@ -700,9 +724,23 @@ __global__ __launch_bounds__(256) void k_ingest(const IngestArgs a) {
 
 }  // namespace
 
+// Register budget of K1: 2 waves/SIMD (no spills, 199 VGPRs) or 4 waves/SIMD (128 VGPRs, some
+// scratch).  NEO_MPC_SOLVE_WAVES=2|4 overrides the default for A/B measurements.
+static int solve_variant() {
+  static int v = 0;
+  if (v == 0) {
+    const char* e = getenv("NEO_MPC_SOLVE_WAVES");
+    v = (e && atoi(e) == 2) ? 2 : 4;
+  }
+  return v;
+}
+
 void launch_solve(const SolveArgs& a, void* stream) {
   if (a.count == 0) return;
-  hipLaunchKernelGGL(k_solve, dim3(a.count), dim3(kLanes), a.lds.total_bytes, (hipStream_t)stream, a);
+  if (solve_variant() == 2)
+    hipLaunchKernelGGL(k_solve<2>, dim3(a.count), dim3(kLanes), a.lds.total_bytes, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(k_solve<4>, dim3(a.count), dim3(kLanes), a.lds.total_bytes, (hipStream_t)stream, a);
 }
 void launch_postprocess(const SolveArgs& a, void* stream) {
   if (a.count == 0) return;

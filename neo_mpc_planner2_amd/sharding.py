@@ -1,0 +1,52 @@
+"""Multi-GPU sharding of a batch of independent MPC instances.
+
+Each instance is independent, so the batch is block-partitioned across ranks with no
+data-path collective; the costmap and the parameters are replicated.  The only exchange
+is one all-gather of the (vx, vy, omega) commands (RCCL over xGMI when the backend is
+"nccl"; gloo on CPU in the tests): 24 bytes per instance, e.g. 6.3 MB per rank at
+262 144 instances, one direct transfer per peer link.
+"""
+import numpy as np
+
+
+def partition(count, world_size, rank):
+    """Contiguous block partition: instance b -> rank b // ceil(count / world_size).
+    Returns (start, stop)."""
+    per = (count + world_size - 1) // world_size
+    start = min(count, rank * per)
+    return start, min(count, start + per)
+
+
+def gather_commands(local, out=None, group=None):
+    """All-gather the local (n_local, 3) command tensor of every rank into
+    out[world, n_local, 3] (allocated when None).  Equal shard sizes are required."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    local = local.contiguous()
+    if out is None:
+        out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local, group=group)
+    return out
+
+
+def solve_sharded(solve_fn, problems, states, warm, group=None):
+    """Solve a host batch that every rank holds in full: each rank solves its block with
+    `solve_fn(problems, states, warm) -> (commands, solution)` and the velocity commands of
+    all instances are returned on every rank (one all-gather).  `states` / `warm` are updated
+    in place for the local block only (per-instance state stays resident on its rank)."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    count = len(problems)
+    per = (count + world - 1) // world
+    lo, hi = partition(count, world, rank)
+    local = np.zeros((per, 3), dtype=np.float64)
+    if hi > lo:
+        st, wm = states[lo:hi].copy(), warm[lo:hi].copy()
+        cmds, _ = solve_fn(problems[lo:hi], st, wm)
+        states[lo:hi] = st
+        warm[lo:hi] = wm
+        local[: hi - lo] = cmds["vel"]
+    out = gather_commands(torch.from_numpy(local), group=group)
+    return out.numpy().reshape(world * per, 3)[:count]

@@ -159,6 +159,18 @@ class DeviceBatch:
         self.commands = torch.zeros((self.count, abi.COMMAND_DTYPE.itemsize), dtype=torch.uint8, device=dev)
         self.solution = torch.zeros_like(self.warm) if want_solution else None
 
+    def fresh_state(self):
+        """Another (states, warm, commands) set for the same problems (shares `problems`)."""
+        import torch
+        other = object.__new__(DeviceBatch)
+        other.count = self.count
+        other.problems = self.problems
+        other.states = self.states.clone()
+        other.warm = self.warm.clone()
+        other.commands = torch.zeros_like(self.commands)
+        other.solution = None
+        return other
+
     def commands_host(self):
         return self.commands.cpu().numpy().view(abi.COMMAND_DTYPE).reshape(self.count)
 

@@ -22,12 +22,14 @@
  */
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include "../include/neo_mpc.h"
 
 #define ORC_LANES 64
+#define ORC_STALL_ITERATIONS 5 /* consecutive iterations below cost_tolerance that end the search */
 #define ORC_MAXN NEO_MPC_MAX_CONTROL_STEPS
 #define ORC_MAXV (3 * ORC_MAXN)
 
@@ -219,6 +221,7 @@ typedef struct orc_ctx {
   double konst;          /* terms constant in u: terminal distance + footprint */
   double term[256];      /* per-step costmap term by raw cell value */
   double lo[3], hi[3], r;
+  double kink_radius;
   const orc_map* map;
 } orc_ctx;
 
@@ -252,6 +255,7 @@ static void orc_ctx_init(orc_ctx* c, const neo_mpc_params* p, const orc_map* m,
   c->lo[1] = p->min_vel_y; c->hi[1] = p->max_vel_y;
   c->lo[2] = p->min_vel_theta; c->hi[2] = p->max_vel_theta;
   c->r = p->max_vel_trans;
+  c->kink_radius = p->kink_radius > 0.0 ? p->kink_radius : 3e-3;
   c->map = m;
 }
 
@@ -344,8 +348,12 @@ static void orc_grad_smooth(const orc_ctx* c, const double* u, double* g) {
 typedef struct orc_active {
   uint8_t wfroz[ORC_MAXN]; /* omega at a bound, gradient pushing outward */
   uint8_t mode[ORC_MAXN];  /* (vx, vy): 0 free, 1 slide along the constraint with normal n, 2 pinned */
+  uint8_t near[ORC_MAXN];  /* block within kink_radius of the control-norm kink u_i = v_cur: it is
+                              moved by the proximal step in every candidate and kept out of the
+                              quasi-Newton model (the norm's curvature wc/|u_i - v| is unbounded there) */
   double nx[ORC_MAXN], ny[ORC_MAXN];
 } orc_active;
+
 
 static void orc_reduce(const orc_ctx* c, const double* u, const double* gs, double* gt, double* gr,
                        orc_active* a) {
@@ -363,6 +371,12 @@ static void orc_reduce(const orc_ctx* c, const double* u, const double* gs, doub
       for (int k = 0; k < 3; ++k) gi[k] = gsi[k] * sh;
     }
     for (int k = 0; k < 3; ++k) { gt[3 * i + k] = gi[k]; gr[3 * i + k] = gi[k]; }
+    a->near[i] = ne < c->kink_radius;
+    if (a->near[i]) {
+      for (int k = 0; k < 3; ++k) { gt[3 * i + k] = 0.0; gr[3 * i + k] = 0.0; }
+      a->wfroz[i] = 0; a->mode[i] = 0; a->nx[i] = 0.0; a->ny[i] = 0.0;
+      continue;
+    }
     /* omega: plain bound */
     a->wfroz[i] = (ui[2] <= c->lo[2] && gi[2] > 0.0) || (ui[2] >= c->hi[2] && gi[2] < 0.0);
     if (a->wfroz[i]) gr[3 * i + 2] = 0.0;
@@ -407,6 +421,7 @@ static void orc_reduce(const orc_ctx* c, const double* u, const double* gs, doub
 
 static void orc_apply_active(const orc_ctx* c, const orc_active* a, double* d) {
   for (int i = 0; i < c->n; ++i) {
+    if (a->near[i]) { d[3 * i] = 0.0; d[3 * i + 1] = 0.0; d[3 * i + 2] = 0.0; continue; }
     if (a->wfroz[i]) d[3 * i + 2] = 0.0;
     if (a->mode[i] == 1) {
       double dot = d[3 * i] * a->nx[i] + d[3 * i + 1] * a->ny[i];
@@ -436,12 +451,12 @@ static double orc_lane_scale(int lane) {
   return (lane & 1) ? s * 1.4142135623730951 : s;
 }
 
-static void orc_candidate(const orc_ctx* c, int lane, double alpha, const double* u,
+static void orc_candidate(const orc_ctx* c, const orc_active* act, int lane, double alpha, const double* u,
                           const double* gs, const double* d, double* cand) {
   const double sc = orc_lane_scale(lane);
   for (int i = 0; i < c->n; ++i) {
     double b[3];
-    if (lane < 32) {
+    if (lane < 32 || act->near[i]) {
       const double a = alpha * sc;
       double e[3], ne2 = 0.0;
       for (int k = 0; k < 3; ++k) { e[k] = (u[3 * i + k] - a * gs[3 * i + k]) - c->v[k]; ne2 += e[k] * e[k]; }
@@ -456,6 +471,9 @@ static void orc_candidate(const orc_ctx* c, int lane, double alpha, const double
   }
 }
 
+static int orc_trace = 0;
+void orc_set_trace(int on) { orc_trace = on; }
+
 /* Returns status; x_out = minimiser estimate, *f_out its objective. */
 int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_problem* q,
                  double footprint_cost, const double* x0, double* x_out, double* f_out,
@@ -467,6 +485,7 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
   int mem = p->lbfgs_memory > 0 ? p->lbfgs_memory : 4;
   if (mem > NEO_MPC_MAX_LBFGS_MEMORY) mem = NEO_MPC_MAX_LBFGS_MEMORY;
   const double xtol = p->step_tolerance > 0.0 ? p->step_tolerance : 1e-3 * p->opt_tolerance;
+  const double ftol = p->cost_tolerance > 0.0 ? p->cost_tolerance : 3e-6 * p->opt_tolerance;
 
   double u[ORC_MAXV], gs[ORC_MAXV], gt[ORC_MAXV], gr[ORC_MAXV], d[ORC_MAXV];
   double u_prev[ORC_MAXV], gt_prev[ORC_MAXV], cand[ORC_MAXV], best_c[ORC_MAXV];
@@ -474,6 +493,8 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
   double rho[NEO_MPC_MAX_LBFGS_MEMORY];
   int npairs = 0, head = 0; /* ring: newest at (head-1) mod mem */
   orc_active act;
+  uint8_t near_prev[ORC_MAXN];
+  memset(near_prev, 0, sizeof(near_prev));
 
   for (int i = 0; i < n; ++i) {
     double b[3] = {x0[3 * i], x0[3 * i + 1], x0[3 * i + 2]};
@@ -482,14 +503,18 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
   }
   double f = orc_eval(&c, u);
   double alpha = 1.0;
-  int nfev = 1, it = 0, status = NEO_MPC_STATUS_MAX_ITER;
+  int nfev = 1, it = 0, status = NEO_MPC_STATUS_MAX_ITER, stall = 0;
   for (it = 0; it < max_it; ++it) {
     orc_grad_smooth(&c, u, gs);
     orc_reduce(&c, u, gs, gt, gr, &act);
     if (it > 0) {
       double* s = S[head];
       double* y = Y[head];
-      for (int k = 0; k < nv; ++k) { s[k] = u[k] - u_prev[k]; y[k] = gt[k] - gt_prev[k]; }
+      for (int k = 0; k < nv; ++k) {
+        const int skip = act.near[k / 3] || near_prev[k / 3];
+        s[k] = skip ? 0.0 : u[k] - u_prev[k];
+        y[k] = skip ? 0.0 : gt[k] - gt_prev[k];
+      }
       double sy = orc_dot(s, y, nv), ss = orc_dot(s, s, nv), yy = orc_dot(y, y, nv);
       if (ss > 0.0 && sy > 1e-10 * sqrt(ss * yy)) {
         rho[head] = 1.0 / sy;
@@ -524,11 +549,29 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
     double fb = INFINITY;
     int best = -1;
     for (int lane = 0; lane < ORC_LANES; ++lane) {
-      orc_candidate(&c, lane, alpha, u, gs, d, cand);
+      orc_candidate(&c, &act, lane, alpha, u, gs, d, cand);
       double fc = orc_eval(&c, cand);
       if (fc < fb) { fb = fc; best = lane; memcpy(best_c, cand, sizeof(double) * nv); }
+      if (orc_trace > 1 && it == orc_trace) {
+        fprintf(stderr, "  lane %2d sc %.3e fc-f %.3e cand", lane, orc_lane_scale(lane), fc - f);
+        for (int k = 0; k < nv; ++k) fprintf(stderr, " %.7f", cand[k] - u[k]);
+        fprintf(stderr, "\n");
+      }
+    }
+    if (orc_trace > 1 && it == orc_trace) {
+      fprintf(stderr, "  u "); for (int k = 0; k < nv; ++k) fprintf(stderr, " %.7f", u[k]);
+      fprintf(stderr, "\n  gs"); for (int k = 0; k < nv; ++k) fprintf(stderr, " %.3e", gs[k]);
+      fprintf(stderr, "\n  gr"); for (int k = 0; k < nv; ++k) fprintf(stderr, " %.3e", gr[k]);
+      fprintf(stderr, "\n  d "); for (int k = 0; k < nv; ++k) fprintf(stderr, " %.3e", d[k]);
+      fprintf(stderr, "\n");
     }
     ++nfev;
+    if (orc_trace) {
+      double gn = 0.0;
+      for (int k = 0; k < nv; ++k) gn = fmax(gn, fabs(gr[k]));
+      fprintf(stderr, "it %3d f %.15g fb-f %.3e best %2d alpha %.3e |gr|inf %.3e npairs %d\n", it, f, fb - f, best,
+              alpha, gn, npairs);
+    }
     if (!(fb < f)) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
     double step = 0.0;
     for (int k = 0; k < nv; ++k) {
@@ -536,12 +579,17 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
       if (ad > step) step = ad;
       u_prev[k] = u[k]; gt_prev[k] = gt[k]; u[k] = best_c[k];
     }
+    memcpy(near_prev, act.near, sizeof(near_prev));
+    const double decrease = f - fb;
     f = fb;
     if (best < 32) {
       alpha *= orc_lane_scale(best);
       alpha = orc_clamp(alpha, 1e-6, 1e6);
     }
-    if (step < xtol) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
+    /* iterations that gain next to nothing (creeping along a costmap cell edge, or the slow tail
+     * next to the control-norm kink) end the search once ORC_STALL_ITERATIONS of them are in a row */
+    stall = (decrease <= ftol * fmax(1.0, fabs(fb))) ? stall + 1 : 0;
+    if (step < xtol || stall >= ORC_STALL_ITERATIONS) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
   }
   memcpy(x_out, u, sizeof(double) * nv);
   *f_out = f;
