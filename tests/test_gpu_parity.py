@@ -155,7 +155,8 @@ def test_c2_full_size_properties(solver_mod):
         st2 = st0.copy()
         cm2, x2 = s.solve(probs, st2, x.copy())
         assert (cm2["cost"] <= cmds["cost"] + 1e-12).all()
-        assert (np.abs(x2 - x).max(axis=1) <= 1e-4).mean() >= 0.99
+        assert (np.abs(x2 - x).max(axis=1) <= 1e-3).mean() >= 0.99     # the north-star tolerance
+        assert (np.abs(x2 - x).max(axis=1) <= 1e-4).mean() >= 0.95
         # sharding: two half batches == the whole batch, bit for bit
         h = len(probs) // 2
         sa, wa = st0[:h].copy(), warm0[:h].copy()
