@@ -205,3 +205,53 @@ def test_errors_are_reported_not_thrown(solver_mod):
     with pytest.raises(_lib.NeoMpcError):
         solver_mod.BatchSolver(util.orc.make_params(min_vel_x=0.9, max_vel_x=1.0, min_vel_y=0.9, max_vel_y=1.0))
     s.close()
+
+
+# ------------------------------------------------------------------ host mirror of the service node
+def test_server_mirror_episode_matches_oracle_wrapper():
+    """`MpcOptimizationServer.optimizer(request, response)` (the reference's service callback
+    surface) over a 40-call episode == the C oracle driven with the same requests/clock:
+    warm start, low-pass, clamp, latch, new goal."""
+    import math
+    from neo_mpc_planner2_amd import mpc_optimization_server as srv
+    from oracle import c_oracle
+    params = dict(srv.README_PARAMS)
+    cmap = synthetic.make_costmap(200, seed=4)
+    clock = {"t": 1000.0}
+    node = srv.MpcOptimizationServer(params, clock=lambda: clock["t"])
+    node.set_costmap(*cmap)
+    st_c, warm_c = abi.new_states(1, 3)
+    row = synthetic.make_problems(1, 200, seed=440)[0].copy()
+    pos, yaw, vel = np.array(row["cur_xy"]), 0.3, np.zeros(3)
+    last_time = 0.0
+    for k in range(40):
+        if k == 20:
+            g = synthetic.make_problems(1, 200, seed=901)[0]
+            row["goal_xyz"], row["goal_q"] = g["goal_xyz"], g["goal_q"]
+        if k % 10 == 0 and k:
+            c = synthetic.make_problems(1, 200, seed=1300 + k)[0]
+            row["carrot_xy"], row["carrot_q"] = c["carrot_xy"], c["carrot_q"]
+        clock["t"] += (1.0 / 30.0) if k % 7 else 0.9
+        row["cur_xy"], row["cur_q"], row["cur_vel"] = pos, synthetic.yaw_quat(np.array(yaw)), vel
+        req = srv.make_request(row["cur_xy"], row["cur_q"], row["carrot_xy"], row["carrot_q"], row["goal_xyz"],
+                               row["goal_q"], row["cur_vel"], control_interval=1.0 / 30.0)
+        resp = node.optimizer(req, srv.make_response())
+        out = np.array([resp.output_vel.twist.linear.x, resp.output_vel.twist.linear.y,
+                        resp.output_vel.twist.angular.z])
+        rec = srv.request_record(req, delta_t=clock["t"] - last_time)
+        last_time = clock["t"]
+        cc, xc, path_c = c_oracle.solve_batch(params, cmap, rec, st_c, warm_c, want_path=True)
+        assert np.abs(out - cc["vel"][0]).max() <= 1e-6, k
+        assert np.abs(node.initial_guess - warm_c[0]).max() <= 1e-6
+        assert node.collision == bool(st_c["collision"][0])
+        assert np.abs(node.local_plan - path_c[0]).max() <= 1e-6
+        assert node.last_result.success == (cc["status"][0] == 0)
+        vel = out.copy()
+        yaw += vel[2] / 30.0
+        pos = pos + np.array([vel[0] * math.cos(yaw) - vel[1] * math.sin(yaw),
+                              vel[0] * math.sin(yaw) + vel[1] * math.cos(yaw)]) / 30.0
+    # dynamic reconfigure through the reference's callback name (py:405-439)
+    from types import SimpleNamespace as NS
+    node.cb_params([NS(name="w_trans", value=0.5, type_=3), NS(name="not_dynamic", value=1.0, type_=3)])
+    assert node.w_trans == 0.5
+    node.close()
