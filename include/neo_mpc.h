@@ -70,11 +70,13 @@ typedef struct neo_mpc_params {
   int32_t lbfgs_memory;   /* <=0: 4 */
   int32_t compat_flags;   /* NEO_MPC_COMPAT_*; neo_mpc_default_params sets all (parity mode) */
   double step_tolerance;  /* stop when max|du| < this; <=0: 1e-3 * opt_tolerance */
-  double cost_tolerance;  /* stop after 5 consecutive iterations that each lower the objective by
-                             less than cost_tolerance * max(1, |f|); <=0: 3e-6 * opt_tolerance */
+  double cost_tolerance;  /* an iteration is "stalled" when it lowers the objective by less than
+                             cost_tolerance * max(1, |f|) (<=0: 3e-6 * opt_tolerance) or moves less
+                             than stall_step; 5 stalled iterations in a row end the search */
   double kink_radius;     /* blocks with |u_i - v_cur| below this are moved by the proximal step of
                              the control norm and kept out of the L-BFGS model; <=0: 3e-3 */
-  double reserved[2];
+  double stall_step;      /* <=0: 0.3 * opt_tolerance */
+  double reserved[1];
 } neo_mpc_params;
 
 /* One Optimizer.srv request (cpp:240-246).  256 bytes. */

@@ -120,9 +120,13 @@ void derive(neo_mpc_handle* h) {
   d.xtol = p.step_tolerance > 0.0 ? p.step_tolerance : 1e-3 * p.opt_tolerance;
   d.ftol = p.cost_tolerance > 0.0 ? p.cost_tolerance : 3e-6 * p.opt_tolerance;
   d.kink_radius = p.kink_radius > 0.0 ? p.kink_radius : 3e-3;
+  d.stall_step = p.stall_step > 0.0 ? p.stall_step : 0.3 * p.opt_tolerance;
   d.max_it = p.max_iterations > 0 ? p.max_iterations : 100;
   d.mem = p.lbfgs_memory > 0 ? p.lbfgs_memory : 4;
   d.compat = p.compat_flags;
+  d.disc_in_box = (p.min_vel_x <= -p.max_vel_trans && p.max_vel_x >= p.max_vel_trans &&
+                   p.min_vel_y <= -p.max_vel_trans && p.max_vel_y >= p.max_vel_trans) ? 1 : 0;
+  d.pad_ = 0;
 
   // LDS carve-up
   LdsLayout& l = h->lds;
@@ -295,6 +299,7 @@ int neo_mpc_default_params(neo_mpc_params* p) {
   p->step_tolerance = 0.0;
   p->cost_tolerance = 0.0;
   p->kink_radius = 0.0;
+  p->stall_step = 0.0;
   return NEO_MPC_OK;
 }
 

@@ -25,11 +25,14 @@ struct DevParams {
   double low_pass_gain;      // py:367
   double xtol;               // step tolerance
   double ftol;               // relative cost decrease below which an iteration counts as stalled
+  double stall_step;         // ... or max|du| below this
   double kink_radius;        // |u_i - v_cur| below which a block is handled by the prox step only
   int32_t n;                 // control_steps
   int32_t max_it;
   int32_t mem;               // L-BFGS pairs
   int32_t compat;
+  int32_t disc_in_box;       // the max_vel_trans disc lies inside the vx/vy box (README params)
+  int32_t pad_;
 };
 
 // Device costmap written by the ingest kernel (K3): raw nav2 costs with a lethal border of

@@ -35,8 +35,8 @@ namespace {
 
 #define WAVE_SYNC() __syncthreads()
 
-// consecutive iterations gaining less than ftol*max(1,|f|) that end the search (creeping along a
-// costmap cell edge gains ~1e-9 per iteration for ever)
+// consecutive iterations gaining less than ftol*max(1,|f|) or moving less than stall_step that end
+// the search (creeping along a costmap cell edge gains ~1e-9 per iteration for ever)
 constexpr int kStallIterations = 5;
 
 // ---------------------------------------------------------------- wave primitives
@@ -208,6 +208,11 @@ __device__ __forceinline__ double clampd(double v, double lo, double hi) { retur
 __device__ __forceinline__ void project_block(const DevParams& p, double& b0, double& b1, double& b2) {
   b2 = clampd(b2, p.lo[2], p.hi[2]);
   const double zx = b0, zy = b1, r = p.r;
+  if (p.disc_in_box) {  // README parameters: the box never binds, the projection is radial
+    const double n2 = zx * zx + zy * zy;
+    if (n2 > r * r) { const double sc = r / sqrt(n2); b0 = zx * sc; b1 = zy * sc; }
+    return;
+  }
   const double px = clampd(zx, p.lo[0], p.hi[0]), py = clampd(zy, p.lo[1], p.hi[1]);
   if (px * px + py * py <= r * r) { b0 = px; b1 = py; return; }
   const double nz = sqrt(zx * zx + zy * zy);
@@ -265,16 +270,25 @@ __device__ __forceinline__ void candidate_block(const SolveArgs& a, const Ctx& c
 }
 
 // rollout + cost of one control sequence (py:224-268); Block(i, b0, b1, b2) yields the controls
-template <class Block>
-__device__ __forceinline__ double rollout_cost(const SolveArgs& a, const Ctx& c, const double* L, Block block) {
+struct NoRecord {
+  __device__ __forceinline__ void operator()(int, double, double) const {}
+};
+// kSteps > 0: control_steps known at compile time (loops unroll); Record(i, sin, cos) lets the caller
+// keep the rollout's trigonometry (the winner's is reused by the next adjoint sweep)
+template <int kSteps = 0, class Block, class Record = NoRecord>
+__device__ __forceinline__ double rollout_cost(const SolveArgs& a, const Ctx& c, const double* L, Block block,
+                                               Record record = Record()) {
   const DevParams& p = a.p;
+  const int n = kSteps ? kSteps : p.n;
   double f = 0.0, x = 0.0, y = 0.0, th = 0.0;
-  for (int i = 0; i < p.n; ++i) {
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
     double vx, vy, w;
     block(i, vx, vy, w);
     th += w * p.dt;                                     // py:230
     double sn, cs;
     sincos_fast(th, &sn, &cs);
+    record(i, sn, cs);
     x += (vx * cs - vy * sn) * p.dt;                    // py:231
     y += (vx * sn + vy * cs) * p.dt;                    // py:232
     const double dx = c.cx - x, dy = c.cy - y, et = c.tyaw - th;
@@ -441,14 +455,20 @@ __device__ void load_records(const SolveArgs& a, double* L, uint32_t b, int lane
 }
 
 // ---------------------------------------------------------------- K1
-template <int kMinWavesPerSimd>
+// kSteps > 0: specialisation for control_steps == kSteps -- every lane keeps its candidate's controls
+// and sin/cos in registers, so the winner is stored without being recomputed and the next adjoint
+// sweep needs no trigonometry.  kSteps == 0: any control_steps (LDS-only path).
+template <int kMinWavesPerSimd, int kSteps>
 __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveArgs a) {
   extern __shared__ __align__(16) double L[];
   const int lane = threadIdx.x;
   const uint32_t b = blockIdx.x;
   if (b >= a.count) return;
   const DevParams& p = a.p;
-  const int n = p.n, nv = 3 * n, mem = p.mem;
+  const int n = kSteps ? kSteps : p.n, nv = 3 * n, mem = p.mem;
+  constexpr int kRegSteps = kSteps ? kSteps : 1;
+  double cand[3 * kRegSteps], cand_sn[kRegSteps], cand_cs[kRegSteps];
+  bool have_trig = false;  // ACS/ASN already hold sin/cos of the rollout at u
 
   load_records(a, L, b, lane);
   int flags = reset_and_warm(a, L, b, lane) ? NEO_MPC_FLAG_RESET : 0;
@@ -482,10 +502,10 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   // x0 clipped to the feasible set (SciPy clips x0 to the bounds, _slsqp_py.py:268)
   for (int i = lane; i < n; i += kLanes) project_block(p, u[3 * i], u[3 * i + 1], u[3 * i + 2]);
   WAVE_SYNC();
-  double f = rollout_cost(a, c, L, [&](int i, double& b0, double& b1, double& b2) {
+  double f = rollout_cost<kSteps>(a, c, L, [&](int i, double& b0, double& b1, double& b2) {
     b0 = u[3 * i]; b1 = u[3 * i + 1]; b2 = u[3 * i + 2];
   });
-  f = __shfl(f, 0);
+  f = lane_value(f, 0);
 
   for (int i = lane; i < n; i += kLanes) { AMODE[4 * i + 2] = 0; AMODE[4 * i + 3] = 0; }
   double alpha = 1.0;
@@ -494,11 +514,13 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     // ---- adjoint gradient of the tracking + terminal cost (all lanes walk the same sweep)
     {
       double x = 0.0, y = 0.0, th = 0.0;
+#pragma unroll
       for (int i = 0; i < n; ++i) {
         const double vx = u[3 * i], vy = u[3 * i + 1], w = u[3 * i + 2];
         th += w * p.dt;
         double sn, cs;
-        sincos_fast(th, &sn, &cs);
+        if (kSteps && have_trig) { sn = ASN[i]; cs = ACS[i]; }
+        else sincos_fast(th, &sn, &cs);
         const double ddx = (vx * cs - vy * sn) * p.dt, ddy = (vx * sn + vy * cs) * p.dt;
         x += ddx; y += ddy;
         double rt = -2.0 * p.wo_n * (c.tyaw - th);
@@ -510,6 +532,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       }
       WAVE_SYNC();
       double SX = 0.0, SY = 0.0, ST = 0.0;
+#pragma unroll
       for (int k = n - 1; k >= 0; --k) {
         SX += ARX[k]; SY += ARY[k];
         ST += ART[k] - ADY[k] * SX + ADX[k] * SY;
@@ -548,10 +571,12 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       double r0 = t0, r1 = t1;
       double nx[3], ny[3];
       int na = 0;
-      if (u0 <= p.lo[0]) { nx[na] = -1.0; ny[na] = 0.0; ++na; }
-      else if (u0 >= p.hi[0]) { nx[na] = 1.0; ny[na] = 0.0; ++na; }
-      if (u1 <= p.lo[1]) { nx[na] = 0.0; ny[na] = -1.0; ++na; }
-      else if (u1 >= p.hi[1]) { nx[na] = 0.0; ny[na] = 1.0; ++na; }
+      if (!p.disc_in_box) {  // (inside the box a bound can only touch where the disc touches too)
+        if (u0 <= p.lo[0]) { nx[na] = -1.0; ny[na] = 0.0; ++na; }
+        else if (u0 >= p.hi[0]) { nx[na] = 1.0; ny[na] = 0.0; ++na; }
+        if (u1 <= p.lo[1]) { nx[na] = 0.0; ny[na] = -1.0; ++na; }
+        else if (u1 >= p.hi[1]) { nx[na] = 0.0; ny[na] = 1.0; ++na; }
+      }
       const double nvv = sqrt(u0 * u0 + u1 * u1);
       if (nvv > 0.0 && nvv >= p.r * (1.0 - 1e-12)) { nx[na] = u0 / nvv; ny[na] = u1 / nvv; ++na; }
       const double dx = -t0, dy = -t1;
@@ -667,9 +692,15 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     // ---- 64 candidates, one rollout per lane; lowest objective wins
     const double pstep = alpha * lane_scale(lane);
     const double step = lane < 32 ? pstep : lane_scale(lane);
-    double fc = rollout_cost(a, c, L, [&](int i, double& b0, double& b1, double& b2) {
-      candidate_block(a, c, L, lane, step, pstep, i, b0, b1, b2);
-    });
+    double fc = rollout_cost<kSteps>(
+        a, c, L,
+        [&](int i, double& b0, double& b1, double& b2) {
+          candidate_block(a, c, L, lane, step, pstep, i, b0, b1, b2);
+          if (kSteps) { cand[3 * i] = b0; cand[3 * i + 1] = b1; cand[3 * i + 2] = b2; }
+        },
+        [&](int i, double sn, double cs) {
+          if (kSteps) { cand_sn[i] = sn; cand_cs[i] = cs; }
+        });
     if (!(fc == fc)) fc = INFINITY;
     double fb = fc;
     int best = lane;
@@ -677,12 +708,21 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     ++nfev;
     if (!(fb < f)) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
     if (lane == best) {
-      for (int i = 0; i < n; ++i) {
-        double b0, b1, b2;
-        candidate_block(a, c, L, lane, step, pstep, i, b0, b1, b2);
-        u_new[3 * i] = b0; u_new[3 * i + 1] = b1; u_new[3 * i + 2] = b2;
+      if (kSteps) {
+#pragma unroll
+        for (int i = 0; i < kRegSteps; ++i) {
+          u_new[3 * i] = cand[3 * i]; u_new[3 * i + 1] = cand[3 * i + 1]; u_new[3 * i + 2] = cand[3 * i + 2];
+          ASN[i] = cand_sn[i]; ACS[i] = cand_cs[i];
+        }
+      } else {
+        for (int i = 0; i < n; ++i) {
+          double b0, b1, b2;
+          candidate_block(a, c, L, lane, step, pstep, i, b0, b1, b2);
+          u_new[3 * i] = b0; u_new[3 * i + 1] = b1; u_new[3 * i + 2] = b2;
+        }
       }
     }
+    have_trig = true;
     WAVE_SYNC();
     double stepmax = 0.0;
     for (int k = lane; k < nv; k += kLanes) {
@@ -691,10 +731,10 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       u_prev[k] = ou; gt_prev[k] = gt[k]; u[k] = nu;
     }
     stepmax = wave_max(stepmax);
-    stall = (f - fb <= p.ftol * fmax(1.0, fabs(fb))) ? stall + 1 : 0;
+    stall = (f - fb <= p.ftol * fmax(1.0, fabs(fb)) || stepmax <= p.stall_step) ? stall + 1 : 0;
     f = fb;
     if (best < 32) {
-      alpha = __shfl(step, best);
+      alpha = lane_value(step, best);
       alpha = clampd(alpha, 1e-6, 1e6);
     }
     WAVE_SYNC();
@@ -788,10 +828,19 @@ static int solve_variant() {
 
 void launch_solve(const SolveArgs& a, void* stream) {
   if (a.count == 0) return;
-  if (solve_variant() == 2)
-    hipLaunchKernelGGL(k_solve<2>, dim3(a.count), dim3(kLanes), a.lds.total_bytes, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL(k_solve<4>, dim3(a.count), dim3(kLanes), a.lds.total_bytes, (hipStream_t)stream, a);
+  const dim3 grid(a.count), block(kLanes);
+  hipStream_t st = (hipStream_t)stream;
+  const bool w4 = solve_variant() == 4;
+  const bool generic = getenv("NEO_MPC_GENERIC_STEPS") != nullptr;  // A/B: force the LDS-only path
+  if (a.p.n == 3 && !generic) {
+    if (w4) hipLaunchKernelGGL((k_solve<4, 3>), grid, block, a.lds.total_bytes, st, a);
+    else hipLaunchKernelGGL((k_solve<2, 3>), grid, block, a.lds.total_bytes, st, a);
+  } else if (a.p.n == 8 && !generic) {
+    hipLaunchKernelGGL((k_solve<2, 8>), grid, block, a.lds.total_bytes, st, a);
+  } else {
+    if (w4) hipLaunchKernelGGL((k_solve<4, 0>), grid, block, a.lds.total_bytes, st, a);
+    else hipLaunchKernelGGL((k_solve<2, 0>), grid, block, a.lds.total_bytes, st, a);
+  }
 }
 void launch_postprocess(const SolveArgs& a, void* stream) {
   if (a.count == 0) return;

@@ -486,6 +486,7 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
   if (mem > NEO_MPC_MAX_LBFGS_MEMORY) mem = NEO_MPC_MAX_LBFGS_MEMORY;
   const double xtol = p->step_tolerance > 0.0 ? p->step_tolerance : 1e-3 * p->opt_tolerance;
   const double ftol = p->cost_tolerance > 0.0 ? p->cost_tolerance : 3e-6 * p->opt_tolerance;
+  const double stall_step = p->stall_step > 0.0 ? p->stall_step : 0.3 * p->opt_tolerance;
 
   double u[ORC_MAXV], gs[ORC_MAXV], gt[ORC_MAXV], gr[ORC_MAXV], d[ORC_MAXV];
   double u_prev[ORC_MAXV], gt_prev[ORC_MAXV], cand[ORC_MAXV], best_c[ORC_MAXV];
@@ -586,9 +587,10 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
       alpha *= orc_lane_scale(best);
       alpha = orc_clamp(alpha, 1e-6, 1e6);
     }
-    /* iterations that gain next to nothing (creeping along a costmap cell edge, or the slow tail
-     * next to the control-norm kink) end the search once ORC_STALL_ITERATIONS of them are in a row */
-    stall = (decrease <= ftol * fmax(1.0, fabs(fb))) ? stall + 1 : 0;
+    /* iterations that gain next to nothing or barely move (creeping along a costmap cell edge, the
+     * slow tail next to the control-norm kink) end the search once ORC_STALL_ITERATIONS of them
+     * are in a row */
+    stall = (decrease <= ftol * fmax(1.0, fabs(fb)) || step <= stall_step) ? stall + 1 : 0;
     if (step < xtol || stall >= ORC_STALL_ITERATIONS) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
   }
   memcpy(x_out, u, sizeof(double) * nv);
