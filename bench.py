@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--workload", default="C2", choices=["C2", "C3", "C5"])
     ap.add_argument("--batch", type=int, default=None, help="instances per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--max-iterations", type=int, default=None, help="study knob: cap the solver iterations")
     args = ap.parse_args()
 
     import torch
@@ -102,6 +103,8 @@ def main():
         cfg["batch"] = args.batch
     n = cfg["control_steps"]
     params = readme_params(n)
+    if args.max_iterations:
+        params["max_iterations"] = args.max_iterations
     cmap = synthetic.make_costmap(cfg["map_size"], seed=0)                 # shared map, replicated
     probs = synthetic.make_problems(cfg["batch"], cfg["map_size"], seed=1000 + rank)
     st, warm = synthetic.make_states(probs, n)

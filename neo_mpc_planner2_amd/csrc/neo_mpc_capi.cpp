@@ -128,20 +128,10 @@ void derive(neo_mpc_handle* h) {
                    p.min_vel_y <= -p.max_vel_trans && p.max_vel_y >= p.max_vel_trans) ? 1 : 0;
   d.pad_ = 0;
 
-  // LDS carve-up
+  // LDS carve-up (shared with the kernel specialisations) + reach tile geometry
   LdsLayout& l = h->lds;
-  const int nv = 3 * n;
-  int off = 0;
-  auto take = [&](int cnt) { int o = off; off += cnt; return o; };
-  l.prob = take(32); l.state = take(16); l.term = take(256);
-  l.u = take(nv); l.gs = take(nv); l.gt = take(nv); l.gr = take(nv); l.d = take(nv);
-  l.u_prev = take(nv); l.gt_prev = take(nv); l.u_new = take(nv);
-  l.S = take(d.mem * nv); l.Y = take(d.mem * nv); l.rho = take(NEO_MPC_MAX_LBFGS_MEMORY);
-  l.cs = take(n); l.sn = take(n); l.dxs = take(n); l.dys = take(n);
-  l.rx = take(n); l.ry = take(n); l.rt = take(n); l.nx = take(n); l.ny = take(n);
-  l.mode = take(2 * n);  // int[4n]: mode, omega-frozen, near-kink, near-kink at the previous iterate
-  off = (off + 1) & ~1;  // 16-byte align the tile
-  l.tile = off;
+  l = make_lds_layout(n, d.mem);
+  const int off = l.tile;
   l.tile_w = 0; l.tile_h = 0; l.reach = 0;
   if (h->has_map) {
     const double bx = std::fmax(std::fabs(p.min_vel_x), std::fabs(p.max_vel_x));

@@ -55,6 +55,43 @@ struct LdsLayout {
   int32_t reach;       // R: the tile spans [m0 - R, m0 + R]
 };
 
+// The carve-up depends on control_steps and the L-BFGS memory only, so the control_steps
+// specialisations of K1 evaluate it at compile time (offsets become immediates); the host uses the
+// same function and adds the reach tile geometry.
+constexpr LdsLayout make_lds_layout(int n, int mem) {
+  LdsLayout l{};
+  const int nv = 3 * n;
+  int off = 0;
+  l.prob = off; off += 32;
+  l.state = off; off += 16;
+  l.term = off; off += 256;
+  l.u = off; off += nv;
+  l.gs = off; off += nv;
+  l.gt = off; off += nv;
+  l.gr = off; off += nv;
+  l.d = off; off += nv;
+  l.u_prev = off; off += nv;
+  l.gt_prev = off; off += nv;
+  l.u_new = off; off += nv;
+  l.S = off; off += mem * nv;
+  l.Y = off; off += mem * nv;
+  l.rho = off; off += NEO_MPC_MAX_LBFGS_MEMORY;
+  l.cs = off; off += n;
+  l.sn = off; off += n;
+  l.dxs = off; off += n;
+  l.dys = off; off += n;
+  l.rx = off; off += n;
+  l.ry = off; off += n;
+  l.rt = off; off += n;
+  l.nx = off; off += n;
+  l.ny = off; off += n;
+  l.mode = off; off += 2 * n;  // int[4n]: mode, omega-frozen, near-kink, near-kink at the previous iterate
+  off = (off + 1) & ~1;        // 16-byte align the tile
+  l.tile = off;
+  l.total_bytes = off * 8;
+  return l;
+}
+
 struct SolveArgs {
   const neo_mpc_problem* problems;
   neo_mpc_state* states;

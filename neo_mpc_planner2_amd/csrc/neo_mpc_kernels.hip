@@ -459,14 +459,23 @@ __device__ void load_records(const SolveArgs& a, double* L, uint32_t b, int lane
 // and sin/cos in registers, so the winner is stored without being recomputed and the next adjoint
 // sweep needs no trigonometry.  kSteps == 0: any control_steps (LDS-only path).
 template <int kMinWavesPerSimd, int kSteps>
-__global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveArgs a) {
+__global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveArgs args) {
   extern __shared__ __align__(16) double L[];
+  SolveArgs a = args;
+  if (kSteps) {  // compile-time LDS offsets (lbfgs_memory is 4 in the specialisations' layout)
+    constexpr LdsLayout kL = make_lds_layout(kSteps ? kSteps : 1, 4);
+    const int tile_w = args.lds.tile_w, tile_h = args.lds.tile_h, reach = args.lds.reach;
+    a.lds = kL;
+    a.lds.tile_w = tile_w; a.lds.tile_h = tile_h; a.lds.reach = reach;
+    a.p.n = kSteps;
+  }
   const int lane = threadIdx.x;
   const uint32_t b = blockIdx.x;
   if (b >= a.count) return;
   const DevParams& p = a.p;
   const int n = kSteps ? kSteps : p.n, nv = 3 * n, mem = p.mem;
   constexpr int kRegSteps = kSteps ? kSteps : 1;
+  constexpr int kPairs = kSteps ? 4 : NEO_MPC_MAX_LBFGS_MEMORY;  // specialisations: lbfgs_memory <= 4
   double cand[3 * kRegSteps], cand_sn[kRegSteps], cand_cs[kRegSteps];
   bool have_trig = false;  // ACS/ASN already hold sin/cos of the rollout at u
 
@@ -476,6 +485,13 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   Ctx c;
   make_ctx(p, a.map, L + a.lds.prob, fcost, c);
   load_tile(a, c, L, lane);
+  // the per-instance constants are wave-uniform: keep them in scalar registers
+  c.cx = lane_value(c.cx, 0); c.cy = lane_value(c.cy, 0); c.tyaw = lane_value(c.tyaw, 0);
+  c.fyaw = lane_value(c.fyaw, 0); c.c0 = lane_value(c.c0, 0); c.s0 = lane_value(c.s0, 0);
+  c.X0 = lane_value(c.X0, 0); c.Y0 = lane_value(c.Y0, 0); c.v0 = lane_value(c.v0, 0);
+  c.v1 = lane_value(c.v1, 0); c.v2 = lane_value(c.v2, 0); c.konst = lane_value(c.konst, 0);
+  c.true_yaw = lane_value(c.true_yaw, 0);
+  c.tile_x0 = uniform_int(c.tile_x0); c.tile_y0 = uniform_int(c.tile_y0);
 
   double* u = L + a.lds.u;
   double* gs = L + a.lds.gs;
@@ -569,41 +585,39 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       gt[3 * i] = t0; gt[3 * i + 1] = t1; gt[3 * i + 2] = t2;
       const int wfroz = ((u2 <= p.lo[2] && t2 > 0.0) || (u2 >= p.hi[2] && t2 < 0.0)) ? 1 : 0;
       double r0 = t0, r1 = t1;
-      double nx[3], ny[3];
-      int na = 0;
+      // outward normals of the constraints active at u: slot 0 = vx bound, 1 = vy bound, 2 = disc
+      // (fixed slots + validity flags: no dynamically indexed private arrays, i.e. no scratch)
+      double nx0 = 0.0, ny0 = 0.0, nx1 = 0.0, ny1 = 0.0, nx2 = 0.0, ny2 = 0.0;
+      bool v0 = false, v1 = false, v2 = false;
       if (!p.disc_in_box) {  // (inside the box a bound can only touch where the disc touches too)
-        if (u0 <= p.lo[0]) { nx[na] = -1.0; ny[na] = 0.0; ++na; }
-        else if (u0 >= p.hi[0]) { nx[na] = 1.0; ny[na] = 0.0; ++na; }
-        if (u1 <= p.lo[1]) { nx[na] = 0.0; ny[na] = -1.0; ++na; }
-        else if (u1 >= p.hi[1]) { nx[na] = 0.0; ny[na] = 1.0; ++na; }
+        if (u0 <= p.lo[0]) { nx0 = -1.0; v0 = true; }
+        else if (u0 >= p.hi[0]) { nx0 = 1.0; v0 = true; }
+        if (u1 <= p.lo[1]) { ny1 = -1.0; v1 = true; }
+        else if (u1 >= p.hi[1]) { ny1 = 1.0; v1 = true; }
       }
       const double nvv = sqrt(u0 * u0 + u1 * u1);
-      if (nvv > 0.0 && nvv >= p.r * (1.0 - 1e-12)) { nx[na] = u0 / nvv; ny[na] = u1 / nvv; ++na; }
+      if (nvv > 0.0 && nvv >= p.r * (1.0 - 1e-12)) { nx2 = u0 / nvv; ny2 = u1 / nvv; v2 = true; }
       const double dx = -t0, dy = -t1;
+      const double dn0 = nx0 * dx + ny0 * dy, dn1 = nx1 * dx + ny1 * dy, dn2 = nx2 * dx + ny2 * dy;
       int mode = 0;
       double mnx = 0.0, mny = 0.0;
-      bool violated = false;
-      for (int k = 0; k < na; ++k) violated = violated || (nx[k] * dx + ny[k] * dy > 0.0);
-      if (violated) {
+      if ((v0 && dn0 > 0.0) || (v1 && dn1 > 0.0) || (v2 && dn2 > 0.0)) {
+        // slide along one violated constraint if that keeps the others satisfied; longest slide wins
         double bestn = -1.0;
-        int bestk = -1;
-        for (int k = 0; k < na; ++k) {
-          const double dn = nx[k] * dx + ny[k] * dy;
-          if (!(dn > 0.0)) continue;
-          const double px = dx - dn * nx[k], py = dy - dn * ny[k];
-          bool ok = true;
-          for (int j = 0; j < na; ++j)
-            if (j != k && nx[j] * px + ny[j] * py > 1e-14 * (fabs(px) + fabs(py))) ok = false;
-          const double pn = px * px + py * py;
-          if (ok && pn > bestn) { bestn = pn; bestk = k; }
+        mode = 2;
+#define NEO_TRY_SLIDE(vk, dnk, nxk, nyk, va, nxa, nya, vb, nxb, nyb)                                   \
+        if (vk && dnk > 0.0) {                                                                         \
+          const double px = dx - dnk * nxk, py = dy - dnk * nyk;                                       \
+          const double tol = 1e-14 * (fabs(px) + fabs(py));                                            \
+          const bool ok = !(va && nxa * px + nya * py > tol) && !(vb && nxb * px + nyb * py > tol);    \
+          const double pn = px * px + py * py;                                                         \
+          if (ok && pn > bestn) { bestn = pn; mode = 1; mnx = nxk; mny = nyk; r0 = -px; r1 = -py; }    \
         }
-        if (bestk >= 0) {
-          const double dn = nx[bestk] * dx + ny[bestk] * dy;
-          mode = 1; mnx = nx[bestk]; mny = ny[bestk];
-          r0 = -(dx - dn * mnx); r1 = -(dy - dn * mny);
-        } else {
-          mode = 2; r0 = 0.0; r1 = 0.0;
-        }
+        NEO_TRY_SLIDE(v0, dn0, nx0, ny0, v1, nx1, ny1, v2, nx2, ny2)
+        NEO_TRY_SLIDE(v1, dn1, nx1, ny1, v0, nx0, ny0, v2, nx2, ny2)
+        NEO_TRY_SLIDE(v2, dn2, nx2, ny2, v0, nx0, ny0, v1, nx1, ny1)
+#undef NEO_TRY_SLIDE
+        if (mode == 2) { r0 = 0.0; r1 = 0.0; }
       }
       gr[3 * i] = r0; gr[3 * i + 1] = r1; gr[3 * i + 2] = wfroz ? 0.0 : t2;
       ANX[i] = mnx; ANY[i] = mny; AMODE[4 * i] = mode; AMODE[4 * i + 1] = wfroz; AMODE[4 * i + 2] = 0;
@@ -630,47 +644,55 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       }
       WAVE_SYNC();
     }
-    // ---- L-BFGS two-loop recursion on the reduced gradient; lanes take vector elements
+    // ---- L-BFGS two-loop recursion on the reduced gradient; lanes take vector elements.
+    //      Pair slots are walked with compile-time indices so the alphas stay in registers.
     {
-      double al[NEO_MPC_MAX_LBFGS_MEMORY];
+      constexpr bool kWide = (kSteps == 0) || (3 * kSteps > 64);  // more than 64 variables
+      double al[kPairs];
       double q0 = lane < nv ? gr[lane] : 0.0;
-      double q1 = lane + 64 < nv ? gr[lane + 64] : 0.0;
-      double q2 = lane + 128 < nv ? gr[lane + 128] : 0.0;
-      for (int j = 0; j < npairs; ++j) {
-        const int idx = (head - 1 - j + 2 * mem) % mem;
-        const double* s = Sm + idx * nv;
-        const double* yv = Ym + idx * nv;
-        double part = 0.0;
-        if (lane < nv) part += s[lane] * q0;
-        if (lane + 64 < nv) part += s[lane + 64] * q1;
-        if (lane + 128 < nv) part += s[lane + 128] * q2;
-        al[j] = rho[idx] * wave_sum(part);
-        if (lane < nv) q0 -= al[j] * yv[lane];
-        if (lane + 64 < nv) q1 -= al[j] * yv[lane + 64];
-        if (lane + 128 < nv) q2 -= al[j] * yv[lane + 128];
+      double q1 = (kWide && lane + 64 < nv) ? gr[lane + 64] : 0.0;
+      double q2 = (kWide && lane + 128 < nv) ? gr[lane + 128] : 0.0;
+#pragma unroll
+      for (int j = 0; j < kPairs; ++j) {
+        if (j < npairs) {
+          const int idx = (head - 1 - j + 2 * mem) % mem;
+          const double* s = Sm + idx * nv;
+          const double* yv = Ym + idx * nv;
+          double part = 0.0;
+          if (lane < nv) part += s[lane] * q0;
+          if (kWide && lane + 64 < nv) part += s[lane + 64] * q1;
+          if (kWide && lane + 128 < nv) part += s[lane + 128] * q2;
+          al[j] = rho[idx] * wave_sum(part);
+          if (lane < nv) q0 -= al[j] * yv[lane];
+          if (kWide && lane + 64 < nv) q1 -= al[j] * yv[lane + 64];
+          if (kWide && lane + 128 < nv) q2 -= al[j] * yv[lane + 128];
+        }
       }
       if (npairs > 0) {
         const int idx = (head - 1 + mem) % mem;
         const double* yv = Ym + idx * nv;
         double part = 0.0;
         if (lane < nv) part += yv[lane] * yv[lane];
-        if (lane + 64 < nv) part += yv[lane + 64] * yv[lane + 64];
-        if (lane + 128 < nv) part += yv[lane + 128] * yv[lane + 128];
+        if (kWide && lane + 64 < nv) part += yv[lane + 64] * yv[lane + 64];
+        if (kWide && lane + 128 < nv) part += yv[lane + 128] * yv[lane + 128];
         const double gamma = 1.0 / (rho[idx] * wave_sum(part));
         q0 *= gamma; q1 *= gamma; q2 *= gamma;
       }
-      for (int j = npairs - 1; j >= 0; --j) {
-        const int idx = (head - 1 - j + 2 * mem) % mem;
-        const double* s = Sm + idx * nv;
-        const double* yv = Ym + idx * nv;
-        double part = 0.0;
-        if (lane < nv) part += yv[lane] * q0;
-        if (lane + 64 < nv) part += yv[lane + 64] * q1;
-        if (lane + 128 < nv) part += yv[lane + 128] * q2;
-        const double be = rho[idx] * wave_sum(part);
-        if (lane < nv) q0 += s[lane] * (al[j] - be);
-        if (lane + 64 < nv) q1 += s[lane + 64] * (al[j] - be);
-        if (lane + 128 < nv) q2 += s[lane + 128] * (al[j] - be);
+#pragma unroll
+      for (int j = kPairs - 1; j >= 0; --j) {
+        if (j < npairs) {
+          const int idx = (head - 1 - j + 2 * mem) % mem;
+          const double* s = Sm + idx * nv;
+          const double* yv = Ym + idx * nv;
+          double part = 0.0;
+          if (lane < nv) part += yv[lane] * q0;
+          if (kWide && lane + 64 < nv) part += yv[lane + 64] * q1;
+          if (kWide && lane + 128 < nv) part += yv[lane + 128] * q2;
+          const double be = rho[idx] * wave_sum(part);
+          if (lane < nv) q0 += s[lane] * (al[j] - be);
+          if (kWide && lane + 64 < nv) q1 += s[lane + 64] * (al[j] - be);
+          if (kWide && lane + 128 < nv) q2 += s[lane + 128] * (al[j] - be);
+        }
       }
       if (lane < nv) d[lane] = -q0;
       if (lane + 64 < nv) d[lane + 64] = -q1;
@@ -821,7 +843,7 @@ static int solve_variant() {
   static int v = 0;
   if (v == 0) {
     const char* e = getenv("NEO_MPC_SOLVE_WAVES");
-    v = (e && atoi(e) == 4) ? 4 : 2;
+    v = (e && atoi(e) == 4) ? 4 : (e && atoi(e) == 3) ? 3 : 2;
   }
   return v;
 }
@@ -830,16 +852,18 @@ void launch_solve(const SolveArgs& a, void* stream) {
   if (a.count == 0) return;
   const dim3 grid(a.count), block(kLanes);
   hipStream_t st = (hipStream_t)stream;
-  const bool w4 = solve_variant() == 4;
-  const bool generic = getenv("NEO_MPC_GENERIC_STEPS") != nullptr;  // A/B: force the LDS-only path
+  const int w = solve_variant();
+  const bool generic = getenv("NEO_MPC_GENERIC_STEPS") != nullptr || a.p.mem != 4;  // A/B: LDS-only path
+  const size_t lds = a.lds.total_bytes;
   if (a.p.n == 3 && !generic) {
-    if (w4) hipLaunchKernelGGL((k_solve<4, 3>), grid, block, a.lds.total_bytes, st, a);
-    else hipLaunchKernelGGL((k_solve<2, 3>), grid, block, a.lds.total_bytes, st, a);
+    if (w == 4) hipLaunchKernelGGL((k_solve<4, 3>), grid, block, lds, st, a);
+    else if (w == 3) hipLaunchKernelGGL((k_solve<3, 3>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((k_solve<2, 3>), grid, block, lds, st, a);
   } else if (a.p.n == 8 && !generic) {
-    hipLaunchKernelGGL((k_solve<2, 8>), grid, block, a.lds.total_bytes, st, a);
+    hipLaunchKernelGGL((k_solve<2, 8>), grid, block, lds, st, a);
   } else {
-    if (w4) hipLaunchKernelGGL((k_solve<4, 0>), grid, block, a.lds.total_bytes, st, a);
-    else hipLaunchKernelGGL((k_solve<2, 0>), grid, block, a.lds.total_bytes, st, a);
+    if (w == 4) hipLaunchKernelGGL((k_solve<4, 0>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((k_solve<2, 0>), grid, block, lds, st, a);
   }
 }
 void launch_postprocess(const SolveArgs& a, void* stream) {
