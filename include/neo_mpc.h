@@ -137,6 +137,42 @@ typedef struct neo_mpc_batch {
   uint32_t reserved;
 } neo_mpc_batch;
 
+/* ---- next row of the path: the carrot (look-ahead) selection that feeds the solver ---------- */
+
+/* `<plugin>.lookahead_dist_*` (cpp:311-322) and the plan cut-off of cpp:78-80. */
+typedef struct neo_mpc_lookahead_params {
+  double lookahead_dist_min, lookahead_dist_max, lookahead_dist_close_to_goal;
+  double max_transform_dist; /* max(size_x, size_y) * resolution / 2 (cpp:79-80) */
+} neo_mpc_lookahead_params;
+
+/* Result of transformGlobalPlan + getLookAheadDistance + getLookAheadPoint + the slow_down_
+ * update (cpp:66-135, 157-189, 221-232) for one robot.  80 bytes. */
+typedef struct neo_mpc_carrot {
+  double xy[2];           /* carrot_pose.pose.position, base frame (cpp:214) */
+  double q[4];            /* carrot_pose.pose.orientation x,y,z,w, base frame */
+  double lookahead_dist;  /* cpp:211 */
+  uint32_t begin, end;    /* plan poses [begin, end) were kept (cpp:83-104); the caller erases
+                             [0, begin) like cpp:126 */
+  int32_t closer_to_goal; /* cpp:95-100 (-> request.switch_opt, cpp:245) */
+  int32_t slow_down;      /* slow_down_ after cpp:221-232 */
+  int32_t status;         /* 0 ok; 1 plan with zero length (cpp:69-71); 2 nothing left (cpp:130-132) */
+  int32_t reserved;
+} neo_mpc_carrot;
+
+/* Ragged batch of global plans.  Poses are planar (x, y, yaw) in the plan frame; `robot_poses`
+ * is the robot pose already expressed in that frame (transformPose, cpp:74-77). */
+typedef struct neo_mpc_plan_batch {
+  size_t count;
+  const double* plan_poses;      /* [plan_offsets[count]][3] */
+  const uint32_t* plan_offsets;  /* [count + 1] */
+  const double* robot_poses;     /* [count][3] */
+  const double* footprint_costs; /* [count] footprintCostAtPose on nav2's 0..255 scale (cpp:218) */
+  int32_t* slow_down;            /* [count] in/out: slow_down_ (h:162, initially 1) */
+  neo_mpc_carrot* carrots;       /* [count] out */
+  neo_mpc_problem* problems;     /* optional [count]: carrot_xy / carrot_q are written into the
+                                    requests the solver will consume (cpp:242) */
+} neo_mpc_plan_batch;
+
 typedef struct neo_mpc_handle neo_mpc_handle;
 
 /* library / ABI */
@@ -181,6 +217,15 @@ int neo_mpc_postprocess_batch(neo_mpc_handle* handle, const neo_mpc_batch* batch
  * u[count][3*control_steps] (not projected); `footprint_cost` from problems[i].  Host pointers. */
 int neo_mpc_objective_batch(neo_mpc_handle* handle, const neo_mpc_problem* problems,
                             const double* u, double* cost_out, size_t count);
+
+/* Carrot selection for `count` robots (host pointers / device pointers + stream): replaces
+ * transformGlobalPlan's pruning, getLookAheadDistance, getLookAheadPoint and the slow_down_ state
+ * machine (cpp:83-104, 157-189, 221-232) with the plan->base transform taken as the planar rigid
+ * transform given by the robot pose. */
+int neo_mpc_select_carrots(neo_mpc_handle* handle, const neo_mpc_lookahead_params* params,
+                           const neo_mpc_plan_batch* batch);
+int neo_mpc_select_carrots_device(neo_mpc_handle* handle, const neo_mpc_lookahead_params* params,
+                                  const neo_mpc_plan_batch* batch, void* stream);
 
 /* Bytes of LDS and costmap reach (cells) the solve kernel uses with the current params/map. */
 int neo_mpc_kernel_info(const neo_mpc_handle* handle, uint32_t* lds_bytes, uint32_t* reach_cells,

@@ -18,6 +18,7 @@ EXPORTS = (
     "neo_mpc_destroy", "neo_mpc_set_params", "neo_mpc_get_params", "neo_mpc_set_costmap",
     "neo_mpc_set_costmap_device", "neo_mpc_solve_batch", "neo_mpc_solve_batch_device",
     "neo_mpc_postprocess_batch", "neo_mpc_objective_batch", "neo_mpc_kernel_info",
+    "neo_mpc_select_carrots", "neo_mpc_select_carrots_device",
 )
 
 _lib = None
@@ -64,6 +65,9 @@ def load():
     lib.neo_mpc_solve_batch_device.argtypes = [C.c_void_p, P(abi.NeoMpcBatch), C.c_void_p]
     lib.neo_mpc_postprocess_batch.argtypes = [C.c_void_p, P(abi.NeoMpcBatch), C.c_void_p]
     lib.neo_mpc_objective_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.neo_mpc_select_carrots.argtypes = [C.c_void_p, P(abi.NeoMpcLookaheadParams), P(abi.NeoMpcPlanBatch)]
+    lib.neo_mpc_select_carrots_device.argtypes = [C.c_void_p, P(abi.NeoMpcLookaheadParams),
+                                                  P(abi.NeoMpcPlanBatch), C.c_void_p]
     lib.neo_mpc_kernel_info.argtypes = [C.c_void_p, P(C.c_uint32), P(C.c_uint32), P(C.c_uint32)]
     for name in EXPORTS:
         fn = getattr(lib, name)

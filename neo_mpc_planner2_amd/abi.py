@@ -50,6 +50,15 @@ COMMAND_DTYPE = np.dtype([
 ], align=False)
 assert COMMAND_DTYPE.itemsize == 48
 
+#: `neo_mpc_carrot` (80 bytes): result of the plan pruning + look-ahead selection
+#: (NeoMpcPlanner.cpp:83-104, 157-189, 221-232)
+CARROT_DTYPE = np.dtype([
+    ("xy", "<f8", (2,)), ("q", "<f8", (4,)), ("lookahead_dist", "<f8"),
+    ("begin", "<u4"), ("end", "<u4"), ("closer_to_goal", "<i4"), ("slow_down", "<i4"),
+    ("status", "<i4"), ("reserved", "<i4"),
+], align=False)
+assert CARROT_DTYPE.itemsize == 80
+
 STATUS_CONVERGED = 0
 STATUS_MAX_ITER = 1
 
@@ -95,6 +104,19 @@ class NeoMpcBatch(_C.Structure):
                 ("warm_start", _C.c_void_p), ("commands", _C.c_void_p), ("solution", _C.c_void_p),
                 ("predicted_path", _C.c_void_p), ("footprints", _C.c_void_p),
                 ("footprint_points", _C.c_uint32), ("reserved", _C.c_uint32)]
+
+
+class NeoMpcLookaheadParams(_C.Structure):
+    """`neo_mpc_lookahead_params`: `<plugin>.lookahead_dist_*` (NeoMpcPlanner.cpp:311-322)."""
+    _fields_ = [("lookahead_dist_min", _C.c_double), ("lookahead_dist_max", _C.c_double),
+                ("lookahead_dist_close_to_goal", _C.c_double), ("max_transform_dist", _C.c_double)]
+
+
+class NeoMpcPlanBatch(_C.Structure):
+    """`neo_mpc_plan_batch` (include/neo_mpc.h)."""
+    _fields_ = [("count", _C.c_size_t), ("plan_poses", _C.c_void_p), ("plan_offsets", _C.c_void_p),
+                ("robot_poses", _C.c_void_p), ("footprint_costs", _C.c_void_p), ("slow_down", _C.c_void_p),
+                ("carrots", _C.c_void_p), ("problems", _C.c_void_p)]
 
 
 def params_struct(params=None, **over):

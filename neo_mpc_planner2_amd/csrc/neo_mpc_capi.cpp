@@ -69,6 +69,7 @@ struct neo_mpc_handle {
   LdsLayout lds{};
   DeviceBuffer map_buf, raw_buf, term_buf;
   DeviceBuffer problems, states, warm, commands, solution, path, footprints, success, u, cost;
+  DeviceBuffer plan_poses, plan_offsets, robot_poses, fp_costs, slow_down, carrots;
 };
 
 namespace {
@@ -315,7 +316,8 @@ void neo_mpc_destroy(neo_mpc_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   DeviceBuffer* all[] = {&h->map_buf, &h->raw_buf, &h->term_buf, &h->problems, &h->states, &h->warm, &h->commands,
-                         &h->solution, &h->path, &h->footprints, &h->success, &h->u, &h->cost};
+                         &h->solution, &h->path, &h->footprints, &h->success, &h->u, &h->cost, &h->plan_poses,
+                         &h->plan_offsets, &h->robot_poses, &h->fp_costs, &h->slow_down, &h->carrots};
   for (DeviceBuffer* b : all) b->release();
   delete h;
 }
@@ -421,6 +423,72 @@ int neo_mpc_objective_batch(neo_mpc_handle* h, const neo_mpc_problem* problems, 
   launch_objective(a, nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(cost_out, h->cost.ptr, count * 8, hipMemcpyDeviceToHost));
+  return NEO_MPC_OK;
+}
+
+static int check_plan_batch(const neo_mpc_handle* h, const neo_mpc_lookahead_params* lp, const neo_mpc_plan_batch* b) {
+  if (!h || !lp || !b) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "null argument");
+  if (b->count > 0 && (!b->plan_poses || !b->plan_offsets || !b->robot_poses || !b->slow_down || !b->carrots))
+    return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "plan_poses/plan_offsets/robot_poses/slow_down/carrots must not be null");
+  if (b->count > 0x7fffffffull) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "count too large");
+  return NEO_MPC_OK;
+}
+
+int neo_mpc_select_carrots_device(neo_mpc_handle* h, const neo_mpc_lookahead_params* lp,
+                                  const neo_mpc_plan_batch* b, void* stream) {
+  int rc = check_plan_batch(h, lp, b);
+  if (rc) return rc;
+  CarrotArgs a;
+  a.lp = *lp;
+  a.b = *b;
+  launch_carrots(a, stream);
+  HIP_TRY(hipGetLastError());
+  return NEO_MPC_OK;
+}
+
+int neo_mpc_select_carrots(neo_mpc_handle* h, const neo_mpc_lookahead_params* lp, const neo_mpc_plan_batch* b) {
+  int rc = check_plan_batch(h, lp, b);
+  if (rc) return rc;
+  if (b->count == 0) return NEO_MPC_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t n = b->count;
+  const size_t total = b->plan_offsets[n];
+  if ((rc = h->plan_poses.reserve(total * 24 + 8))) return rc;
+  if ((rc = h->plan_offsets.reserve((n + 1) * 4))) return rc;
+  if ((rc = h->robot_poses.reserve(n * 24))) return rc;
+  if ((rc = h->fp_costs.reserve(n * 8))) return rc;
+  if ((rc = h->slow_down.reserve(n * 4))) return rc;
+  if ((rc = h->carrots.reserve(n * sizeof(neo_mpc_carrot)))) return rc;
+  HIP_TRY(hipMemcpy(h->plan_poses.ptr, b->plan_poses, total * 24, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->plan_offsets.ptr, b->plan_offsets, (n + 1) * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->robot_poses.ptr, b->robot_poses, n * 24, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->slow_down.ptr, b->slow_down, n * 4, hipMemcpyHostToDevice));
+  CarrotArgs a;
+  a.lp = *lp;
+  a.b = *b;
+  a.b.plan_poses = (const double*)h->plan_poses.ptr;
+  a.b.plan_offsets = (const uint32_t*)h->plan_offsets.ptr;
+  a.b.robot_poses = (const double*)h->robot_poses.ptr;
+  a.b.slow_down = (int32_t*)h->slow_down.ptr;
+  a.b.carrots = (neo_mpc_carrot*)h->carrots.ptr;
+  a.b.footprint_costs = nullptr;
+  if (b->footprint_costs) {
+    HIP_TRY(hipMemcpy(h->fp_costs.ptr, b->footprint_costs, n * 8, hipMemcpyHostToDevice));
+    a.b.footprint_costs = (const double*)h->fp_costs.ptr;
+  }
+  a.b.problems = nullptr;
+  if (b->problems) {
+    if ((rc = h->problems.reserve(n * sizeof(neo_mpc_problem)))) return rc;
+    HIP_TRY(hipMemcpy(h->problems.ptr, b->problems, n * sizeof(neo_mpc_problem), hipMemcpyHostToDevice));
+    a.b.problems = (neo_mpc_problem*)h->problems.ptr;
+  }
+  launch_carrots(a, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(b->carrots, h->carrots.ptr, n * sizeof(neo_mpc_carrot), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(b->slow_down, h->slow_down.ptr, n * 4, hipMemcpyDeviceToHost));
+  if (b->problems)
+    HIP_TRY(hipMemcpy(b->problems, h->problems.ptr, n * sizeof(neo_mpc_problem), hipMemcpyDeviceToHost));
   return NEO_MPC_OK;
 }
 

@@ -125,7 +125,13 @@ struct IngestArgs {
   int32_t size_x, size_y, pitch, rows;  // rows = size_y + 2*border
 };
 
+struct CarrotArgs {
+  neo_mpc_lookahead_params lp;
+  neo_mpc_plan_batch b;  // device pointers
+};
+
 void launch_solve(const SolveArgs& a, void* stream);
+void launch_carrots(const CarrotArgs& a, void* stream);
 void launch_postprocess(const SolveArgs& a, void* stream);
 void launch_objective(const ObjectiveArgs& a, void* stream);
 void launch_ingest(const IngestArgs& a, void* stream);

@@ -835,6 +835,87 @@ __global__ __launch_bounds__(256) void k_ingest(const IngestArgs a) {
   }
 }
 
+// K4: carrot selection, one wavefront per robot.  Lanes stride over the plan poses (24 B each,
+// consecutive lanes read consecutive poses: one contiguous 1.5 KB segment per wave load), so the
+// kernel streams the plans once for the closest-pose search (cpp:83-88) and re-reads only the
+// kept window [begin, end) for the cut-off and look-ahead scans (cpp:102-106, 177-186).
+__global__ __launch_bounds__(kLanes) void k_carrot(const CarrotArgs a) {
+  const int lane = threadIdx.x;
+  const size_t b = blockIdx.x;
+  if (b >= a.b.count) return;
+  const uint32_t o0 = a.b.plan_offsets[b], np = a.b.plan_offsets[b + 1] - o0;
+  const double* poses = a.b.plan_poses + 3 * (size_t)o0;
+  const double rx = a.b.robot_poses[3 * b], ry = a.b.robot_poses[3 * b + 1], rth = a.b.robot_poses[3 * b + 2];
+  int slow = a.b.slow_down[b];
+  neo_mpc_carrot out;
+  out.xy[0] = 0.0; out.xy[1] = 0.0; out.q[0] = 0.0; out.q[1] = 0.0; out.q[2] = 0.0; out.q[3] = 1.0;
+  out.lookahead_dist = 0.0; out.begin = 0; out.end = 0; out.closer_to_goal = 0; out.slow_down = slow;
+  out.status = 0; out.reserved = 0;
+  if (np == 0) {                                                        // cpp:69-71
+    out.status = 1;
+    if (lane == 0) a.b.carrots[b] = out;
+    return;
+  }
+  // closest pose, first minimum (min_by, cpp:83-88)
+  double best = INFINITY;
+  uint32_t besti = 0xffffffffu;
+  for (uint32_t k = lane; k < np; k += kLanes) {
+    const double d = hypot(poses[3 * k] - rx, poses[3 * k + 1] - ry);
+    if (d < best) { best = d; besti = k; }
+  }
+  const double gmin = wave_min(best);
+  const uint32_t begin = (uint32_t)wave_min((best == gmin) ? (double)besti : 4.0e9);
+  out.closer_to_goal = hypot(poses[3 * (np - 1)] - rx, poses[3 * (np - 1) + 1] - ry) <=
+                       a.lp.lookahead_dist_close_to_goal ? 1 : 0;       // cpp:95-100
+  double la = a.lp.lookahead_dist_min;                                  // cpp:161-169
+  if (!slow || out.closer_to_goal) {
+    la = a.lp.lookahead_dist_max;
+    if (out.closer_to_goal) la = a.lp.lookahead_dist_close_to_goal;
+  }
+  double sn, cs;
+  sincos(rth, &sn, &cs);
+  // one scan from `begin`: first pose beyond the costmap (cpp:102-106) and first pose at least the
+  // look-ahead distance away in the base frame (cpp:177-181)
+  uint32_t end = np, pick = 0xffffffffu;
+  for (uint32_t base = begin; base < np; base += kLanes) {
+    const uint32_t k = base + lane;
+    bool far = false, hit = false;
+    if (k < np) {
+      const double dx = poses[3 * k] - rx, dy = poses[3 * k + 1] - ry;
+      far = hypot(dx, dy) > a.lp.max_transform_dist;
+      hit = hypot(cs * dx + sn * dy, -sn * dx + cs * dy) >= la;
+    }
+    const unsigned long long mfar = __ballot(far), mhit = __ballot(hit);
+    if (pick == 0xffffffffu && mhit) pick = base + (uint32_t)__ffsll((long long)mhit) - 1;
+    if (mfar) { end = base + (uint32_t)__ffsll((long long)mfar) - 1; break; }
+  }
+  out.begin = begin; out.end = end; out.lookahead_dist = la;
+  if (end == begin) {                                                   // cpp:130-132
+    out.status = 2;
+    if (lane == 0) a.b.carrots[b] = out;
+    return;
+  }
+  if (pick == 0xffffffffu || pick >= end) pick = end - 1;               // cpp:183-186
+  const double dx = poses[3 * pick] - rx, dy = poses[3 * pick + 1] - ry;
+  const double yaw_local = poses[3 * pick + 2] - rth;
+  out.xy[0] = cs * dx + sn * dy; out.xy[1] = -sn * dx + cs * dy;
+  double qs, qc;
+  sincos(0.5 * yaw_local, &qs, &qc);
+  out.q[2] = qs; out.q[3] = qc;
+  const double cy = fabs(atan2(2.0 * qc * qs, 1.0 - 2.0 * qs * qs));  // createYawFromQuat (cpp:54-62)
+  slow = (cy >= 1.0 && a.b.footprint_costs && a.b.footprint_costs[b] > 200.0) ? 1 : 0;   // cpp:221-232
+  out.slow_down = slow;
+  if (lane == 0) {
+    a.b.carrots[b] = out;
+    a.b.slow_down[b] = slow;
+    if (a.b.problems) {
+      neo_mpc_problem* pr = a.b.problems + b;
+      pr->carrot_xy[0] = out.xy[0]; pr->carrot_xy[1] = out.xy[1];
+      pr->carrot_q[0] = 0.0; pr->carrot_q[1] = 0.0; pr->carrot_q[2] = qs; pr->carrot_q[3] = qc;
+    }
+  }
+}
+
 }  // namespace
 
 // Register budget of K1: 2 waves/SIMD (default; measured 5.0 vs 4.1 M solves/s on C2) or 4 waves/SIMD (128 VGPRs,
@@ -865,6 +946,10 @@ void launch_solve(const SolveArgs& a, void* stream) {
     if (w == 4) hipLaunchKernelGGL((k_solve<4, 0>), grid, block, lds, st, a);
     else hipLaunchKernelGGL((k_solve<2, 0>), grid, block, lds, st, a);
   }
+}
+void launch_carrots(const CarrotArgs& a, void* stream) {
+  if (a.b.count == 0) return;
+  hipLaunchKernelGGL(k_carrot, dim3((unsigned)a.b.count), dim3(kLanes), 0, (hipStream_t)stream, a);
 }
 void launch_postprocess(const SolveArgs& a, void* stream) {
   if (a.count == 0) return;

@@ -123,6 +123,54 @@ class BatchSolver:
             C.c_void_p(out.ctypes.data), len(problems)))
         return out
 
+    # -- carrot selection (the step before the solver) ------------------------------------
+    def select_carrots(self, plan_poses, plan_offsets, robot_poses, slow_down, footprint_costs=None,
+                       problems=None, lookahead_dist_min=0.5, lookahead_dist_max=0.5,
+                       lookahead_dist_close_to_goal=0.5, max_transform_dist=1e9):
+        """Plan pruning + look-ahead point + slow_down_ update for a ragged batch of plans
+        (NeoMpcPlanner.cpp:83-104, 157-189, 221-232).  `slow_down` (int32) is updated in place;
+        when `problems` is given the carrot pose is written into the requests."""
+        plan_poses = np.ascontiguousarray(plan_poses, dtype=np.float64).reshape(-1, 3)
+        plan_offsets = np.ascontiguousarray(plan_offsets, dtype=np.uint32)
+        robot_poses = np.ascontiguousarray(robot_poses, dtype=np.float64).reshape(-1, 3)
+        count = robot_poses.shape[0]
+        assert plan_offsets.shape == (count + 1,) and slow_down.dtype == np.int32 and slow_down.shape == (count,)
+        carrots = np.zeros(count, dtype=abi.CARROT_DTYPE)
+        lp = abi.NeoMpcLookaheadParams(lookahead_dist_min, lookahead_dist_max, lookahead_dist_close_to_goal,
+                                       max_transform_dist)
+        b = abi.NeoMpcPlanBatch()
+        b.count = count
+        b.plan_poses = plan_poses.ctypes.data
+        b.plan_offsets = plan_offsets.ctypes.data
+        b.robot_poses = robot_poses.ctypes.data
+        if footprint_costs is not None:
+            footprint_costs = np.ascontiguousarray(footprint_costs, dtype=np.float64)
+            b.footprint_costs = footprint_costs.ctypes.data
+        b.slow_down = slow_down.ctypes.data
+        b.carrots = carrots.ctypes.data
+        if problems is not None:
+            assert problems.dtype == abi.PROBLEM_DTYPE and problems.flags.c_contiguous
+            b.problems = problems.ctypes.data
+        _lib.check(self._lib.neo_mpc_select_carrots(self._handle, C.byref(lp), C.byref(b)))
+        return carrots
+
+    def select_carrots_device(self, lp, plan_poses, plan_offsets, robot_poses, slow_down, carrots,
+                              footprint_costs=None, problems=None, stream=None):
+        """Device-resident variant: torch CUDA tensors; enqueues K4 on `stream`."""
+        import torch
+        b = abi.NeoMpcPlanBatch()
+        b.count = robot_poses.shape[0]
+        b.plan_poses = plan_poses.data_ptr()
+        b.plan_offsets = plan_offsets.data_ptr()
+        b.robot_poses = robot_poses.data_ptr()
+        b.footprint_costs = footprint_costs.data_ptr() if footprint_costs is not None else None
+        b.slow_down = slow_down.data_ptr()
+        b.carrots = carrots.data_ptr()
+        b.problems = problems.data_ptr() if problems is not None else None
+        if stream is None:
+            stream = torch.cuda.current_stream(robot_poses.device).cuda_stream
+        _lib.check(self._lib.neo_mpc_select_carrots_device(self._handle, C.byref(lp), C.byref(b), C.c_void_p(stream)))
+
     # -- device-resident batches (torch tensors as plain device memory) ----------------
     def solve_device(self, problems, states, warm, commands, solution=None, path=None, footprints=None,
                      stream=None):

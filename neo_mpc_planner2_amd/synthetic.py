@@ -117,3 +117,26 @@ def footprint_world(prob_row, base=RECT_FOOTPRINT):
     yaw = math.atan2(2.0 * (q[3] * q[2] + q[0] * q[1]), 1.0 - 2.0 * (q[1] * q[1] + q[2] * q[2]))
     c, s = math.cos(yaw), math.sin(yaw)
     return [(x0 + px * c - py * s, y0 + px * s + py * c) for (px, py) in base]
+
+
+def make_plans(count, seed=0, min_len=64, max_len=512, spacing=0.05):
+    """Ragged batch of global plans for the carrot selection (NeoMpcPlanner.cpp:66-189): smooth
+    random polylines of `min_len..max_len` poses `spacing` metres apart with heading = direction
+    of travel, and a robot pose near a random pose of each plan.
+    Returns (plan_poses[total, 3], plan_offsets[count+1] uint32, robot_poses[count, 3])."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(min_len, max_len + 1, size=count)
+    offsets = np.zeros(count + 1, dtype=np.uint32)
+    offsets[1:] = np.cumsum(lens)
+    poses = np.zeros((int(offsets[-1]), 3), dtype=np.float64)
+    robots = np.zeros((count, 3), dtype=np.float64)
+    for i in range(count):
+        n = int(lens[i])
+        heading = rng.uniform(-math.pi, math.pi) + np.cumsum(rng.normal(0.0, 0.03, size=n))
+        xy = rng.uniform(-10, 10, size=2) + spacing * np.cumsum(np.stack([np.cos(heading), np.sin(heading)], 1), axis=0)
+        poses[offsets[i]:offsets[i + 1], :2] = xy
+        poses[offsets[i]:offsets[i + 1], 2] = heading
+        k = int(rng.integers(0, n))
+        robots[i, :2] = xy[k] + rng.normal(0.0, 0.05, size=2)
+        robots[i, 2] = heading[k] + rng.uniform(-1.6, 1.6)
+    return poses, offsets, robots

@@ -103,3 +103,31 @@ def postprocess_batch(params, cmap, problems, states, warm, solution, success=No
         sp = C.c_void_p(keep.ctypes.data)
     return _run(load().orc_postprocess_batch, params, cmap, problems, states, warm, solution=solution,
                 want_path=want_path, footprints=footprints, extra=(sp,))
+
+
+def select_carrots(plan_poses, plan_offsets, robot_poses, slow_down, footprint_costs=None, problems=None,
+                   lookahead_dist_min=0.5, lookahead_dist_max=0.5, lookahead_dist_close_to_goal=0.5,
+                   max_transform_dist=1e9):
+    """cpp:83-104, 157-189, 221-232 restated (oracle/mpc_oracle.c part 3); slow_down updated in place."""
+    lib = load()
+    plan_poses = np.ascontiguousarray(plan_poses, dtype=np.float64).reshape(-1, 3)
+    plan_offsets = np.ascontiguousarray(plan_offsets, dtype=np.uint32)
+    robot_poses = np.ascontiguousarray(robot_poses, dtype=np.float64).reshape(-1, 3)
+    count = robot_poses.shape[0]
+    carrots = np.zeros(count, dtype=abi.CARROT_DTYPE)
+    lp = abi.NeoMpcLookaheadParams(lookahead_dist_min, lookahead_dist_max, lookahead_dist_close_to_goal,
+                                   max_transform_dist)
+    b = abi.NeoMpcPlanBatch()
+    b.count = count
+    b.plan_poses = plan_poses.ctypes.data
+    b.plan_offsets = plan_offsets.ctypes.data
+    b.robot_poses = robot_poses.ctypes.data
+    if footprint_costs is not None:
+        footprint_costs = np.ascontiguousarray(footprint_costs, dtype=np.float64)
+        b.footprint_costs = footprint_costs.ctypes.data
+    b.slow_down = slow_down.ctypes.data
+    b.carrots = carrots.ctypes.data
+    if problems is not None:
+        b.problems = problems.ctypes.data
+    lib.orc_select_carrots(C.byref(lp), C.byref(b))
+    return carrots

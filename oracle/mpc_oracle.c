@@ -667,3 +667,76 @@ void orc_solve_batch(const neo_mpc_params* p, const uint8_t* cells, int32_t sx, 
                     fc, out, b->predicted_path ? b->predicted_path + i * nv : NULL);
   }
 }
+
+
+/* ------------------------------------------------------------------ Part 3: carrot selection (cpp: = src/NeoMpcPlanner.cpp) */
+/* createYawFromQuat (cpp:54-62) of a planar quaternion */
+static double orc_yaw_planar(double z, double w) { return atan2(2.0 * w * z, 1.0 - 2.0 * z * z); }
+
+/* transformGlobalPlan's pruning (cpp:83-104), getLookAheadDistance (cpp:157-171),
+ * getLookAheadPoint (cpp:173-189) and the slow_down_ update (cpp:221-232) for one robot.
+ * The tf2 transform plan frame -> base frame (cpp:107-115) is restated as the planar rigid
+ * transform given by the robot pose (tf2 itself is not part of the reference: unpinned). */
+static void orc_select_carrot(const neo_mpc_lookahead_params* lp, const double* poses, uint32_t np,
+                              const double* robot, double footprint_cost, int32_t* slow_down,
+                              neo_mpc_carrot* out) {
+  memset(out, 0, sizeof(*out));
+  out->q[3] = 1.0;
+  out->slow_down = *slow_down;
+  if (np == 0) { out->status = 1; return; }                             /* cpp:69-71 */
+  const double rx = robot[0], ry = robot[1], rth = robot[2];
+  uint32_t begin = 0;
+  double best = INFINITY;
+  for (uint32_t k = 0; k < np; ++k) {                                   /* min_by, cpp:83-88 */
+    double d = hypot(poses[3 * k] - rx, poses[3 * k + 1] - ry);
+    if (d < best) { best = d; begin = k; }
+  }
+  out->closer_to_goal = hypot(poses[3 * (np - 1)] - rx, poses[3 * (np - 1) + 1] - ry) <=
+                        lp->lookahead_dist_close_to_goal;               /* cpp:95-100 */
+  uint32_t end = np;
+  for (uint32_t k = begin; k < np; ++k)                                 /* find_if, cpp:102-106 */
+    if (hypot(poses[3 * k] - rx, poses[3 * k + 1] - ry) > lp->max_transform_dist) { end = k; break; }
+  out->begin = begin; out->end = end;
+  if (end == begin) { out->status = 2; return; }                        /* cpp:130-132 */
+  double la = lp->lookahead_dist_min;                                   /* cpp:161-169 */
+  if (!*slow_down || out->closer_to_goal) {
+    la = lp->lookahead_dist_max;
+    if (out->closer_to_goal) la = lp->lookahead_dist_close_to_goal;
+  }
+  out->lookahead_dist = la;
+  const double c = cos(rth), s = sin(rth);
+  uint32_t pick = end - 1;                                              /* cpp:183-186 */
+  double lx = 0.0, ly = 0.0;
+  for (uint32_t k = begin; k < end; ++k) {                              /* cpp:177-181 */
+    double dx = poses[3 * k] - rx, dy = poses[3 * k + 1] - ry;
+    lx = c * dx + s * dy; ly = -s * dx + c * dy;
+    if (hypot(lx, ly) >= la) { pick = k; break; }
+  }
+  {
+    double dx = poses[3 * pick] - rx, dy = poses[3 * pick + 1] - ry;
+    lx = c * dx + s * dy; ly = -s * dx + c * dy;
+  }
+  const double yaw_local = poses[3 * pick + 2] - rth;
+  out->xy[0] = lx; out->xy[1] = ly;
+  out->q[0] = 0.0; out->q[1] = 0.0; out->q[2] = sin(0.5 * yaw_local); out->q[3] = cos(0.5 * yaw_local);
+  const double cy = fabs(orc_yaw_planar(out->q[2], out->q[3]));
+  int sd;                                                               /* cpp:221-232 */
+  if (cy < 1.0) sd = 0;   /* the re-check at cpp:224-227 sees the same pose: never true */
+  else if (cy >= 1.0 && footprint_cost > 200) sd = 1;
+  else sd = 0;
+  *slow_down = sd;
+  out->slow_down = sd;
+}
+
+void orc_select_carrots(const neo_mpc_lookahead_params* lp, const neo_mpc_plan_batch* b) {
+  for (size_t i = 0; i < b->count; ++i) {
+    const uint32_t o0 = b->plan_offsets[i], o1 = b->plan_offsets[i + 1];
+    orc_select_carrot(lp, b->plan_poses + 3 * (size_t)o0, o1 - o0, b->robot_poses + 3 * i,
+                      b->footprint_costs ? b->footprint_costs[i] : 0.0, &b->slow_down[i], &b->carrots[i]);
+    if (b->problems && b->carrots[i].status == 0) {
+      b->problems[i].carrot_xy[0] = b->carrots[i].xy[0];
+      b->problems[i].carrot_xy[1] = b->carrots[i].xy[1];
+      for (int k = 0; k < 4; ++k) b->problems[i].carrot_q[k] = b->carrots[i].q[k];
+    }
+  }
+}

@@ -1,0 +1,142 @@
+"""Carrot (look-ahead) selection -- SURVEY §8f row 2: the step before the solver
+(src/NeoMpcPlanner.cpp:83-104 plan pruning, 157-171 look-ahead distance, 173-189 look-ahead
+point, 221-232 slow_down_ state machine).  The C++ plugin cannot be built here (nav2/tf2 absent),
+so the oracle restatement (oracle/mpc_oracle.c part 3) is checked against an independent,
+literal NumPy transcription of those lines, and the HIP kernel against the oracle."""
+import math
+
+import numpy as np
+import pytest
+
+from neo_mpc_planner2_amd import abi, synthetic
+from oracle import c_oracle
+
+LP = dict(lookahead_dist_min=0.4, lookahead_dist_max=0.8, lookahead_dist_close_to_goal=0.3,
+          max_transform_dist=5.0)
+
+
+def transcription(poses, robot, slow, fcost, lp):
+    """cpp:66-135, 157-189, 221-232 line by line for one robot (planar transform)."""
+    if len(poses) == 0:
+        return dict(status=1)
+    d = np.hypot(poses[:, 0] - robot[0], poses[:, 1] - robot[1])
+    begin = int(np.argmin(d))                                   # min_by: first minimum
+    closer = bool(d[-1] <= lp["lookahead_dist_close_to_goal"])
+    far = np.nonzero(d[begin:] > lp["max_transform_dist"])[0]
+    end = begin + int(far[0]) if len(far) else len(poses)
+    if end == begin:
+        return dict(status=2, begin=begin, end=end, closer=closer)
+    la = lp["lookahead_dist_min"]
+    if (not slow) or closer:
+        la = lp["lookahead_dist_max"]
+        if closer:
+            la = lp["lookahead_dist_close_to_goal"]
+    c, s = math.cos(robot[2]), math.sin(robot[2])
+    dx, dy = poses[begin:end, 0] - robot[0], poses[begin:end, 1] - robot[1]
+    lx, ly = c * dx + s * dy, -s * dx + c * dy
+    hit = np.nonzero(np.hypot(lx, ly) >= la)[0]
+    k = int(hit[0]) if len(hit) else end - begin - 1
+    yaw = poses[begin + k, 2] - robot[2]
+    yaw_w = math.atan2(math.sin(yaw), math.cos(yaw))            # what getRPY of the quaternion returns
+    if abs(yaw_w) < 1.0:
+        new_slow = 0
+    elif abs(yaw_w) >= 1.0 and fcost > 200:
+        new_slow = 1
+    else:
+        new_slow = 0
+    return dict(status=0, begin=begin, end=end, closer=closer, la=la, xy=(lx[k], ly[k]), yaw=yaw_w, slow=new_slow)
+
+
+def _inputs(count, seed):
+    poses, offsets, robots = synthetic.make_plans(count, seed=seed, min_len=8, max_len=300)
+    rng = np.random.default_rng(seed + 1)
+    slow = rng.integers(0, 2, size=count).astype(np.int32)
+    fcost = rng.choice([0.0, 150.0, 201.0, 253.0], size=count)
+    return poses, offsets, robots, slow, fcost
+
+
+def test_oracle_restatement_matches_literal_transcription():
+    poses, offsets, robots, slow, fcost = _inputs(300, seed=5)
+    # edge cases: robot far from everything (status 2), robot at the goal (closer_to_goal)
+    robots[0, :2] += 100.0
+    robots[1, :2] = poses[offsets[2] - 1, :2]
+    slow_in = slow.copy()
+    car = c_oracle.select_carrots(poses, offsets, robots, slow, fcost, **LP)
+    assert car["status"][0] == 2 and car["closer_to_goal"][1] == 1
+    for i in range(len(robots)):
+        t = transcription(poses[offsets[i]:offsets[i + 1]], robots[i], slow_in[i], fcost[i], LP)
+        assert car["status"][i] == t["status"]
+        if t["status"]:
+            continue
+        assert (car["begin"][i], car["end"][i]) == (t["begin"], t["end"])
+        assert bool(car["closer_to_goal"][i]) == t["closer"] and car["lookahead_dist"][i] == t["la"]
+        assert np.allclose(car["xy"][i], t["xy"], rtol=0, atol=1e-12)
+        yaw = math.atan2(2 * car["q"][i][3] * car["q"][i][2], 1 - 2 * car["q"][i][2] ** 2)
+        assert abs(yaw - t["yaw"]) <= 1e-12
+        assert car["slow_down"][i] == t["slow"] == slow[i]
+
+
+def test_oracle_empty_plan_and_problem_write():
+    poses, offsets, robots, slow, fcost = _inputs(4, seed=9)
+    offsets2 = np.concatenate([offsets[:2], offsets[1:]]).astype(np.uint32)   # robot 1 gets an empty plan
+    robots2 = np.concatenate([robots[:1], robots[:1], robots[1:]])
+    slow2 = np.ones(5, dtype=np.int32)
+    probs = synthetic.make_problems(5, 200, seed=1)
+    before = probs["carrot_xy"].copy()
+    car = c_oracle.select_carrots(poses, offsets2, robots2, slow2, None, problems=probs, **LP)
+    assert car["status"][1] == 1 and (probs["carrot_xy"][1] == before[1]).all()
+    ok = car["status"] == 0
+    assert (probs["carrot_xy"][ok] == car["xy"][ok]).all() and (probs["carrot_q"][ok] == car["q"][ok]).all()
+
+
+@pytest.mark.gpu
+def test_carrot_kernel_matches_oracle():
+    from neo_mpc_planner2_amd.solver import BatchSolver
+    poses, offsets, robots, slow, fcost = _inputs(4096, seed=11)
+    robots[0, :2] += 100.0
+    slow_g, slow_c = slow.copy(), slow.copy()
+    pg = synthetic.make_problems(4096, 200, seed=2)
+    pc = pg.copy()
+    want = c_oracle.select_carrots(poses, offsets, robots, slow_c, fcost, problems=pc, **LP)
+    with BatchSolver({}) as s:
+        got = s.select_carrots(poses, offsets, robots, slow_g, fcost, problems=pg, **LP)
+    for f in ("begin", "end", "closer_to_goal", "slow_down", "status", "lookahead_dist"):
+        assert (got[f] == want[f]).all(), f
+    assert (slow_g == slow_c).all()
+    assert np.allclose(got["xy"], want["xy"], rtol=0, atol=1e-12)
+    assert np.allclose(got["q"], want["q"], rtol=0, atol=1e-12)
+    assert np.allclose(pg["carrot_xy"], pc["carrot_xy"], rtol=0, atol=1e-12)
+    assert np.allclose(pg["carrot_q"], pc["carrot_q"], rtol=0, atol=1e-12)
+    assert (got["status"] == 0).sum() >= 4000
+
+
+@pytest.mark.gpu
+def test_carrots_feed_the_solver_on_device():
+    """device-resident chain K4 -> K1: carrots are written straight into the request records."""
+    import torch
+    from neo_mpc_planner2_amd.solver import BatchSolver, DeviceBatch
+    from oracle import mpc_oracle as orc
+    count = 1024
+    poses, offsets, robots, slow, fcost = _inputs(count, seed=21)
+    cmap = synthetic.make_costmap(500, seed=0)
+    probs = synthetic.make_problems(count, 500, seed=3)
+    st, warm = synthetic.make_states(probs, 3)
+    # reference chain on the host: oracle carrots, then the GPU solver through host buffers
+    pc, sc = probs.copy(), slow.copy()
+    c_oracle.select_carrots(poses, offsets, robots, sc, fcost, problems=pc, **LP)
+    with BatchSolver(orc.make_params()) as s:
+        s.set_costmap(*cmap)
+        want, _ = s.solve(pc, st.copy(), warm.copy())
+        dev = "cuda:0"
+        db = DeviceBatch(probs, st, warm, dev)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        d_poses, d_off, d_rob, d_slow, d_fc = t(poses), t(offsets.view(np.int32)), t(robots), t(slow), t(fcost)
+        d_car = torch.zeros((count, abi.CARROT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        lp = abi.NeoMpcLookaheadParams(LP["lookahead_dist_min"], LP["lookahead_dist_max"],
+                                       LP["lookahead_dist_close_to_goal"], LP["max_transform_dist"])
+        s.select_carrots_device(lp, d_poses, d_off, d_rob, d_slow, d_car, d_fc, problems=db.problems)
+        s.solve_device(db.problems, db.states, db.warm, db.commands)
+        torch.cuda.synchronize()
+        got = db.commands_host()
+    dv = np.abs(got["vel"] - want["vel"]).max(axis=1)
+    assert (dv <= 1e-9).mean() >= 0.99
