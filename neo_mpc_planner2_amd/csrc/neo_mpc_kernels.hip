@@ -889,12 +889,13 @@ __global__ __launch_bounds__(kLanes) void k_carrot(const CarrotArgs a) {
     if (pick == 0xffffffffu && mhit) pick = base + (uint32_t)__ffsll((long long)mhit) - 1;
     if (mfar) { end = base + (uint32_t)__ffsll((long long)mfar) - 1; break; }
   }
-  out.begin = begin; out.end = end; out.lookahead_dist = la;
+  out.begin = begin; out.end = end;
   if (end == begin) {                                                   // cpp:130-132
     out.status = 2;
     if (lane == 0) a.b.carrots[b] = out;
     return;
   }
+  out.lookahead_dist = la;
   if (pick == 0xffffffffu || pick >= end) pick = end - 1;               // cpp:183-186
   const double dx = poses[3 * pick] - rx, dy = poses[3 * pick + 1] - ry;
   const double yaw_local = poses[3 * pick + 2] - rth;
