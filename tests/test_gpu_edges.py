@@ -1,0 +1,203 @@
+"""GPU edge cases of the hot path through the C-ABI: empty and tiny batches, control_steps 1 and
+the maximum 64, a reach too large for the LDS tile (global-lookup path), robots outside / at the
+edge of the map, a 1x1 map, box-cuts-disc bounds, footprints with the maximum number of points,
+dynamic reconfigure, and multi-tick device-resident state."""
+import numpy as np
+import pytest
+
+from neo_mpc_planner2_amd import abi, synthetic
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _mirror(params, cmap, probs, st, warm, **kw):
+    from oracle import c_oracle
+    return c_oracle.solve_batch(params, cmap, probs, st, warm, **kw)
+
+
+def _close(cg, cc, frac=0.97, tol=1e-3):
+    dv = np.abs(cg["vel"] - cc["vel"]).max(axis=1)
+    assert (dv <= tol).mean() >= frac, (dv <= tol).mean()
+
+
+def test_empty_and_single_instance_batches():
+    from neo_mpc_planner2_amd.solver import BatchSolver
+    params = util.orc.make_params()
+    cmap = synthetic.make_costmap(200, seed=1)
+    with BatchSolver(params) as s:
+        s.set_costmap(*cmap)
+        st, warm = abi.new_states(0, 3)
+        cmds, x = s.solve(np.zeros(0, dtype=abi.PROBLEM_DTYPE), st, warm)
+        assert len(cmds) == 0 and x.shape == (0, 9)
+        probs = synthetic.make_problems(1, 200, seed=2)
+        st, warm = abi.new_states(1, 3)             # very first call: reset path (py:358-361)
+        st["last_control"] = 0.4
+        cmds, x = s.solve(probs, st, warm)
+        assert cmds["flags"][0] & abi.FLAG_RESET
+        st_c, warm_c = abi.new_states(1, 3)
+        st_c["last_control"] = 0.4
+        cc, xc, _ = _mirror(params, cmap, probs, st_c, warm_c)
+        assert np.abs(cmds["vel"] - cc["vel"]).max() <= 1e-6
+        assert st["has_old_goal"][0] == 1 and np.allclose(st["old_goal"][0][:3], probs["goal_xyz"][0])
+
+
+@pytest.mark.parametrize("n_steps", [1, 2, 5, 64])
+def test_unusual_control_steps(n_steps):
+    """generic (runtime control_steps) kernel path, including the maximum 64 (192 variables)."""
+    from neo_mpc_planner2_amd.solver import BatchSolver
+    params = util.orc.make_params(control_steps=n_steps, max_iterations=100 if n_steps < 64 else 400)
+    cmap = synthetic.make_costmap(200, seed=3)
+    count = 128 if n_steps < 64 else 32
+    probs = synthetic.make_problems(count, 200, seed=4 + n_steps)
+    st, warm = synthetic.make_states(probs, n_steps)
+    st_c, warm_c = st.copy(), warm.copy()
+    with BatchSolver(params) as s:
+        s.set_costmap(*cmap)
+        cg, xg = s.solve(probs, st, warm)
+        f0 = s.objective(probs, np.zeros_like(xg))
+    assert (cg["cost"] <= f0 + 1e-12).all()
+    cc, xc, _ = _mirror(params, cmap, probs, st_c, warm_c)
+    _close(cg, cc, frac=0.9 if n_steps == 64 else 0.97)
+    assert (cg["cost"] <= cc["cost"] + 1e-5).mean() >= 0.9
+
+
+def test_reach_too_large_for_lds_tile_uses_global_lookups():
+    from neo_mpc_planner2_amd.solver import BatchSolver
+    # 2.5 m/s for 2 s on a 0.05 m grid = 100 cells of reach: no LDS tile
+    params = util.orc.make_params(max_vel_x=2.5, min_vel_x=-2.5, max_vel_y=2.5, min_vel_y=-2.5, max_vel_trans=2.5,
+                                  prediction_horizon=2.0)
+    cmap = synthetic.make_costmap(500, seed=5)
+    probs = synthetic.make_problems(256, 500, seed=6)
+    st, warm = synthetic.make_states(probs, 3)
+    st_c, warm_c = st.copy(), warm.copy()
+    with BatchSolver(params) as s:
+        s.set_costmap(*cmap)
+        assert s.kernel_info()["tile_in_lds"] is False
+        cg, xg = s.solve(probs, st, warm)
+    cc, xc, _ = _mirror(params, cmap, probs, st_c, warm_c)
+    _close(cg, cc, frac=0.95)
+    # and the README configuration does stage the 27-row tile
+    with BatchSolver(util.orc.make_params()) as s:
+        s.set_costmap(*cmap)
+        info = s.kernel_info()
+        assert info["tile_in_lds"] and info["reach_cells"] == 13 and info["lds_bytes"] < 8192
+
+
+def test_robots_outside_and_at_the_edge_of_the_map_and_tiny_map():
+    from neo_mpc_planner2_amd.solver import BatchSolver
+    params = util.orc.make_params()
+    for cmap in (synthetic.make_costmap(200, seed=7), (np.zeros((1, 1), np.uint8), 0.05, 0.0, 0.0),
+                 (np.full((3, 130), 17, np.uint8), 0.05, -3.25, -0.075)):
+        half_x = cmap[0].shape[1] * cmap[1] / 2
+        probs = synthetic.make_problems(64, 200, seed=8)
+        probs["cur_xy"][:16] = np.random.default_rng(1).uniform(-1, 1, (16, 2)) * 0.2 + (cmap[2], cmap[3])
+        probs["cur_xy"][16:32] += 50.0                      # far outside: every lookup is lethal
+        probs["cur_xy"][32:48, 0] = cmap[2] + 2 * half_x - 0.01   # hugging the far edge
+        st, warm = synthetic.make_states(probs, 3)
+        st_c, warm_c = st.copy(), warm.copy()
+        with BatchSolver(params) as s:
+            s.set_costmap(*cmap)
+            cg, xg = s.solve(probs, st, warm)
+        cc, xc, _ = _mirror(params, cmap, probs, st_c, warm_c)
+        assert (st["collision"] == st_c["collision"]).mean() >= 0.97
+        _close(cg, cc, frac=0.95)
+        assert (cg["vel"][16:32] == 0.0).all() and (st["collision"][16:32] == 1).all()
+
+
+def test_box_cutting_the_disc():
+    from neo_mpc_planner2_amd.solver import BatchSolver
+    params = util.orc.make_params(max_vel_trans=0.7, max_vel_x=0.4, min_vel_x=-0.2, max_vel_y=0.65, min_vel_y=-0.65)
+    probs = synthetic.make_problems(256, 200, seed=91)
+    zero = (np.zeros((200, 200), np.uint8), 0.05, -5.0, -5.0)
+    st, warm = synthetic.make_states(probs, 3)
+    st_c, warm_c = st.copy(), warm.copy()
+    with BatchSolver(params) as s:
+        s.set_costmap(*zero)
+        cg, xg = s.solve(probs, st, warm)
+    xs = xg.reshape(len(xg), -1, 3)
+    assert (xs[:, :, 0] <= 0.4 + 1e-12).all() and (xs[:, :, 0] >= -0.2 - 1e-12).all()
+    assert (np.hypot(xs[:, :, 0], xs[:, :, 1]) <= 0.7 + 1e-9).all()
+    cc, xc, _ = _mirror(params, zero, probs, st_c, warm_c)
+    assert (np.abs(xg - xc).max(axis=1) <= 1e-4).mean() >= 0.97
+    assert (cg["cost"] <= cc["cost"] + 1e-7).all()
+
+
+def test_sixteen_point_footprints():
+    from neo_mpc_planner2_amd.solver import BatchSolver
+    from oracle import c_oracle
+    cmap = synthetic.make_costmap(200, seed=9)
+    probs = synthetic.make_problems(300, 200, seed=10)
+    ang = np.linspace(0, 2 * np.pi, 16, endpoint=False)
+    base = tuple((0.4 * np.cos(a), 0.3 * np.sin(a)) for a in ang)
+    fps = np.array([synthetic.footprint_world(r, base) for r in probs])
+    want = c_oracle.footprint_cost_batch(cmap, fps)
+    st, warm = synthetic.make_states(probs, 3)
+    with BatchSolver(util.orc.make_params(w_footprint=2000)) as s:
+        s.set_costmap(*cmap)
+        cg, xg = s.solve(probs, st, warm, footprints=fps)
+        with pytest.raises(Exception):
+            s.solve(probs, st, warm, footprints=np.zeros((300, 17, 2)))
+    assert (st["collision_footprint"] == (want == 1.0)).all() and (want == 1.0).any()
+
+
+def test_dynamic_reconfigure_takes_effect():
+    from neo_mpc_planner2_amd.solver import BatchSolver
+    cmap = synthetic.make_costmap(200, seed=11)
+    probs = synthetic.make_problems(64, 200, seed=12)
+    with BatchSolver(util.orc.make_params()) as s:
+        s.set_costmap(*cmap)
+        st, warm = synthetic.make_states(probs, 3)
+        a, _ = s.solve(probs, st, warm)
+        s.set_params(w_trans=0.1, max_vel_theta=0.2, min_vel_theta=-0.2, w_costmap=5.0)
+        st, warm = synthetic.make_states(probs, 3)
+        b, xb = s.solve(probs, st, warm)
+        st_c, warm_c = synthetic.make_states(probs, 3)
+        cc, _, _ = _mirror(s.params, cmap, probs, st_c, warm_c)
+        with pytest.raises(ValueError):
+            s.set_params(control_steps=4)
+    assert (np.abs(xb.reshape(64, 3, 3)[:, :, 2]) <= 0.2 + 1e-12).all()
+    assert np.abs(a["vel"] - b["vel"]).max() > 1e-3
+    _close(b, cc)
+
+
+def test_multi_tick_state_stays_resident_on_the_device():
+    """20 control ticks for 512 robots with the records living in HBM (DeviceBatch): warm start,
+    last_control, latch and goal bookkeeping carried by the kernel across launches == the CPU
+    mirror fed tick by tick."""
+    import torch
+    from neo_mpc_planner2_amd.solver import BatchSolver, DeviceBatch
+    params = util.orc.make_params()
+    cmap = synthetic.make_costmap(500, seed=13)
+    count = 512
+    probs = synthetic.make_problems(count, 500, seed=14)
+    st, warm = abi.new_states(count, 3)
+    st_c, warm_c = st.copy(), warm.copy()
+    pos = probs["cur_xy"].copy()
+    yaw = np.random.default_rng(3).uniform(-3, 3, count)
+    vel = np.zeros((count, 3))
+    dt = 1.0 / 30.0
+    agree = []
+    with BatchSolver(params) as s:
+        s.set_costmap(*cmap)
+        db = DeviceBatch(probs, st, warm, "cuda:0")
+        for k in range(20):
+            if k == 10:
+                g = synthetic.make_problems(count, 500, seed=99)
+                probs["goal_xyz"][::2], probs["goal_q"][::2] = g["goal_xyz"][::2], g["goal_q"][::2]
+            probs["cur_xy"], probs["cur_q"], probs["cur_vel"] = pos, synthetic.yaw_quat(yaw), vel
+            probs["delta_t"] = dt if k else 1e9
+            db.problems.copy_(torch.from_numpy(probs.view(np.uint8).reshape(count, -1)))
+            s.solve_device(db.problems, db.states, db.warm, db.commands)
+            torch.cuda.synchronize()
+            cg = db.commands_host()
+            cc, _, _ = _mirror(params, cmap, probs, st_c, warm_c)
+            agree.append((np.abs(cg["vel"] - cc["vel"]).max(axis=1) <= 1e-3).mean())
+            vel = cc["vel"].copy()           # both chains are driven by the same (mirror) commands
+            yaw = yaw + vel[:, 2] * dt
+            pos = pos + dt * np.stack([vel[:, 0] * np.cos(yaw) - vel[:, 1] * np.sin(yaw),
+                                       vel[:, 0] * np.sin(yaw) + vel[:, 1] * np.cos(yaw)], 1)
+        sg = db.states_host()
+    assert min(agree) >= 0.95, agree
+    assert (sg["collision"] == st_c["collision"]).mean() >= 0.97
+    assert (sg["has_old_goal"] == 1).all()
