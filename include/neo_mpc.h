@@ -48,6 +48,12 @@ extern "C" {
 /* neo_mpc_params.compat_flags */
 #define NEO_MPC_COMPAT_ODOM_YAW_GOAL_W 1 /* py:213: odom_yaw takes quaternion w from the goal pose */
 
+/* neo_mpc_params.method */
+#define NEO_MPC_METHOD_AUTO 0   /* Newton where the kernel has it (control_steps == 3), else L-BFGS */
+#define NEO_MPC_METHOD_LBFGS 1  /* projected L-BFGS, any control_steps */
+#define NEO_MPC_METHOD_NEWTON 2 /* projected Newton (finite-difference Hessian of the analytic
+                                   gradient, one column per lane); control_steps == 3 only */
+
 #define NEO_MPC_MAX_CONTROL_STEPS 64
 #define NEO_MPC_MAX_FOOTPRINT_POINTS 16
 #define NEO_MPC_MAX_LBFGS_MEMORY 8
@@ -76,7 +82,8 @@ typedef struct neo_mpc_params {
   double kink_radius;     /* blocks with |u_i - v_cur| below this are moved by the proximal step of
                              the control norm and kept out of the L-BFGS model; <=0: 3e-3 */
   double stall_step;      /* <=0: 0.3 * opt_tolerance */
-  double reserved[1];
+  int32_t method;         /* NEO_MPC_METHOD_*: search direction of lanes 32-63 */
+  int32_t reserved_i;
 } neo_mpc_params;
 
 /* One Optimizer.srv request (cpp:240-246).  256 bytes. */

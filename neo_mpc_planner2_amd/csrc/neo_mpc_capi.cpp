@@ -87,6 +87,10 @@ int validate(const neo_mpc_params& p) {
   double ny = std::fmin(std::fmax(0.0, p.min_vel_y), p.max_vel_y);
   if (nx * nx + ny * ny > p.max_vel_trans * p.max_vel_trans)
     return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "velocity box does not intersect the max_vel_trans disc");
+  if (p.method < 0 || p.method > NEO_MPC_METHOD_NEWTON) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "unknown method %d", p.method);
+  if (p.method == NEO_MPC_METHOD_NEWTON && p.control_steps != 3)
+    return fail(NEO_MPC_ERR_UNSUPPORTED, "NEO_MPC_METHOD_NEWTON is built for control_steps == 3 only (got %d)",
+                p.control_steps);
   if (p.lbfgs_memory > NEO_MPC_MAX_LBFGS_MEMORY)
     return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "lbfgs_memory > %d", NEO_MPC_MAX_LBFGS_MEMORY);
   return NEO_MPC_OK;
@@ -127,7 +131,7 @@ void derive(neo_mpc_handle* h) {
   d.compat = p.compat_flags;
   d.disc_in_box = (p.min_vel_x <= -p.max_vel_trans && p.max_vel_x >= p.max_vel_trans &&
                    p.min_vel_y <= -p.max_vel_trans && p.max_vel_y >= p.max_vel_trans) ? 1 : 0;
-  d.pad_ = 0;
+  d.newton = ((p.method == NEO_MPC_METHOD_NEWTON || p.method == NEO_MPC_METHOD_AUTO) && n == 3) ? 1 : 0;
 
   // LDS carve-up (shared with the kernel specialisations) + reach tile geometry
   LdsLayout& l = h->lds;
@@ -291,6 +295,7 @@ int neo_mpc_default_params(neo_mpc_params* p) {
   p->cost_tolerance = 0.0;
   p->kink_radius = 0.0;
   p->stall_step = 0.0;
+  p->method = NEO_MPC_METHOD_AUTO;
   return NEO_MPC_OK;
 }
 

@@ -32,7 +32,7 @@ struct DevParams {
   int32_t mem;               // L-BFGS pairs
   int32_t compat;
   int32_t disc_in_box;       // the max_vel_trans disc lies inside the vx/vy box (README params)
-  int32_t pad_;
+  int32_t newton;            // lanes 32-63 walk the projected Newton direction (control_steps == 3)
 };
 
 // Device costmap written by the ingest kernel (K3): raw nav2 costs with a lethal border of
@@ -48,6 +48,7 @@ struct DevMap {
 struct LdsLayout {
   int32_t prob, state, term, u, gs, gt, gr, d, u_prev, gt_prev, u_new, S, Y, rho;
   int32_t cs, sn, dxs, dys, rx, ry, rt, nx, ny, mode;  // per-step scratch
+  int32_t hess;        // Newton: (3N)^2 Hessian, only when 3N <= 24
   int32_t tile;        // byte tile starts here (double index)
   int32_t total_bytes;
   int32_t tile_w;      // row stride of the tile in bytes (power of two), 0: no tile
@@ -86,6 +87,7 @@ constexpr LdsLayout make_lds_layout(int n, int mem) {
   l.nx = off; off += n;
   l.ny = off; off += n;
   l.mode = off; off += 2 * n;  // int[4n]: mode, omega-frozen, near-kink, near-kink at the previous iterate
+  l.hess = off; off += (nv <= 24) ? nv * nv : 0;
   off = (off + 1) & ~1;        // 16-byte align the tile
   l.tile = off;
   l.total_bytes = off * 8;

@@ -468,8 +468,9 @@ __device__ void load_records(const SolveArgs& a, double* L, uint32_t b, int lane
 // kSteps > 0: specialisation for control_steps == kSteps -- every lane keeps its candidate's controls
 // and sin/cos in registers, so the winner is stored without being recomputed and the next adjoint
 // sweep needs no trigonometry.  kSteps == 0: any control_steps (LDS-only path).
-template <int kMinWavesPerSimd, int kSteps>
+template <int kMinWavesPerSimd, int kSteps, bool kNewton = false>
 __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveArgs args) {
+  static_assert(!kNewton || kSteps > 0, "the Newton path needs a compile-time control_steps");
   extern __shared__ __align__(16) double L[];
   SolveArgs a = args;
   if (kSteps) {  // compile-time LDS offsets (lbfgs_memory is 4 in the specialisations' layout)
@@ -538,7 +539,50 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   int npairs = 0, head = 0, nfev = 1, it = 0, status = NEO_MPC_STATUS_MAX_ITER, stall = 0;
   for (it = 0; it < p.max_it; ++it) {
     // ---- adjoint gradient of the tracking + terminal cost
-    if (!kSteps) {
+    constexpr int kVars = 3 * kRegSteps;
+    double hcol[kVars];  // Newton: column `lane` of the Hessian, then row `lane`
+    if (kNewton) {
+      // Every lane runs the rollout + adjoint sweep on its own copy of u: lane k < 3N perturbs
+      // coordinate k by h, the other lanes leave u alone.  One pass therefore yields the gradient
+      // (any unperturbed lane) and all 3N Hessian columns by forward differences -- the sweep
+      // costs the same whether the lanes agree or not.
+      const double hstep = 1e-6;
+      double pcs[kRegSteps], psn[kRegSteps], pdx[kRegSteps], pdy[kRegSteps], prx[kRegSteps], pry[kRegSteps],
+          prt[kRegSteps];
+      double x = 0.0, y = 0.0, th = 0.0;
+#pragma unroll
+      for (int i = 0; i < kRegSteps; ++i) {
+        const double vx = u[3 * i] + (lane == 3 * i ? hstep : 0.0);
+        const double vy = u[3 * i + 1] + (lane == 3 * i + 1 ? hstep : 0.0);
+        const double w = u[3 * i + 2] + (lane == 3 * i + 2 ? hstep : 0.0);
+        th += w * p.dt;
+        sincos_fast(th, &psn[i], &pcs[i]);
+        pdx[i] = (vx * pcs[i] - vy * psn[i]) * p.dt;
+        pdy[i] = (vx * psn[i] + vy * pcs[i]) * p.dt;
+        x += pdx[i]; y += pdy[i];
+        prx[i] = -2.0 * p.wt_n * (c.cx - x);
+        pry[i] = -2.0 * p.wt_n * (c.cy - y);
+        prt[i] = -2.0 * p.wo_n * (c.tyaw - th);
+        if (i == kRegSteps - 1) prt[i] += -2.0 * p.wterm_o * (c.fyaw - th);
+      }
+      double SX = 0.0, SY = 0.0, ST = 0.0;
+#pragma unroll
+      for (int k = kRegSteps - 1; k >= 0; --k) {
+        SX += prx[k]; SY += pry[k];
+        ST += prt[k] - pdy[k] * SX + pdx[k] * SY;
+        hcol[3 * k] = p.dt * (pcs[k] * SX + psn[k] * SY);
+        hcol[3 * k + 1] = p.dt * (-psn[k] * SX + pcs[k] * SY);
+        hcol[3 * k + 2] = p.dt * ST;
+      }
+      const double inv_h = 1.0 / hstep;
+#pragma unroll
+      for (int j = 0; j < kVars; ++j) {
+        const double base = lane_value(hcol[j], 63);
+        if (lane == 63) gs[j] = base;
+        hcol[j] = (hcol[j] - base) * inv_h;
+      }
+      WAVE_SYNC();
+    } else if (!kSteps) {
       // any control_steps <= 64: lane i owns step i; the rollout recursion (py:230-232) is three
       // prefix sums, the adjoint three suffix sums -- one sincos per lane instead of N in a row
       const bool on = lane < n;
@@ -635,32 +679,128 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       if (nvv > 0.0 && nvv >= p.r * (1.0 - 1e-12)) { nx2 = u0 / nvv; ny2 = u1 / nvv; v2 = true; }
       const double dx = -t0, dy = -t1;
       const double dn0 = nx0 * dx + ny0 * dy, dn1 = nx1 * dx + ny1 * dy, dn2 = nx2 * dx + ny2 * dy;
-      int mode = 0;
-      double mnx = 0.0, mny = 0.0;
+      int mode = 0, mslot = -1;
+      double mnx = 0.0, mny = 0.0, mlam = 0.0;
       if ((v0 && dn0 > 0.0) || (v1 && dn1 > 0.0) || (v2 && dn2 > 0.0)) {
         // slide along one violated constraint if that keeps the others satisfied; longest slide wins
         double bestn = -1.0;
         mode = 2;
-#define NEO_TRY_SLIDE(vk, dnk, nxk, nyk, va, nxa, nya, vb, nxb, nyb)                                   \
+#define NEO_TRY_SLIDE(sk, vk, dnk, nxk, nyk, va, nxa, nya, vb, nxb, nyb)                               \
         if (vk && dnk > 0.0) {                                                                         \
           const double px = dx - dnk * nxk, py = dy - dnk * nyk;                                       \
           const double tol = 1e-14 * (fabs(px) + fabs(py));                                            \
           const bool ok = !(va && nxa * px + nya * py > tol) && !(vb && nxb * px + nyb * py > tol);    \
           const double pn = px * px + py * py;                                                         \
-          if (ok && pn > bestn) { bestn = pn; mode = 1; mnx = nxk; mny = nyk; r0 = -px; r1 = -py; }    \
+          if (ok && pn > bestn) {                                                                      \
+            bestn = pn; mode = 1; mnx = nxk; mny = nyk; r0 = -px; r1 = -py; mslot = sk; mlam = dnk;     \
+          }                                                                                            \
         }
-        NEO_TRY_SLIDE(v0, dn0, nx0, ny0, v1, nx1, ny1, v2, nx2, ny2)
-        NEO_TRY_SLIDE(v1, dn1, nx1, ny1, v0, nx0, ny0, v2, nx2, ny2)
-        NEO_TRY_SLIDE(v2, dn2, nx2, ny2, v0, nx0, ny0, v1, nx1, ny1)
+        NEO_TRY_SLIDE(0, v0, dn0, nx0, ny0, v1, nx1, ny1, v2, nx2, ny2)
+        NEO_TRY_SLIDE(1, v1, dn1, nx1, ny1, v0, nx0, ny0, v2, nx2, ny2)
+        NEO_TRY_SLIDE(2, v2, dn2, nx2, ny2, v0, nx0, ny0, v1, nx1, ny1)
 #undef NEO_TRY_SLIDE
         if (mode == 2) { r0 = 0.0; r1 = 0.0; }
       }
       gr[3 * i] = r0; gr[3 * i + 1] = r1; gr[3 * i + 2] = wfroz ? 0.0 : t2;
       ANX[i] = mnx; ANY[i] = mny; AMODE[4 * i] = mode; AMODE[4 * i + 1] = wfroz; AMODE[4 * i + 2] = 0;
+      if (kNewton) {  // projector onto the tangent cone's face + curvature of a binding disc
+        ADX[i] = mode == 0 ? 1.0 : mode == 1 ? 1.0 - mnx * mnx : 0.0;   // P00
+        ADY[i] = mode == 1 ? -mnx * mny : 0.0;                          // P01
+        ARX[i] = mode == 0 ? 1.0 : mode == 1 ? 1.0 - mny * mny : 0.0;   // P11
+        ARY[i] = wfroz ? 0.0 : 1.0;                                     // PW
+        ART[i] = (mode == 1 && mslot == 2) ? mlam / p.r : 0.0;          // lambda / r
+      }
     }
     WAVE_SYNC();
+    if (kNewton) {
+      double* Hm = L + a.lds.hess;
+      // ---- lane k < 3N holds Hessian column k: add the control norm's Hessian and the disc
+      //      curvature on its diagonal block, apply P on the row index, store the column
+#pragma unroll
+      for (int bk = 0; bk < kRegSteps; ++bk) {
+        const bool near_b = AMODE[4 * bk + 2] != 0;
+        const double e0 = u[3 * bk] - c.v0, e1 = u[3 * bk + 1] - c.v1, e2 = u[3 * bk + 2] - c.v2;
+        const double ne = sqrt(e0 * e0 + e1 * e1 + e2 * e2);
+        const int q = lane - 3 * bk;  // column inside block bk
+        if (q >= 0 && q < 3 && !near_b) {
+          if (ne > 0.0) {  // (w/|e|)(I - e e^T / |e|^2)
+            const double sN = p.wc_n / ne, h0 = e0 / ne, h1 = e1 / ne, h2 = e2 / ne;
+            const double hq = q == 0 ? h0 : q == 1 ? h1 : h2;
+            hcol[3 * bk] += sN * ((q == 0 ? 1.0 : 0.0) - h0 * hq);
+            hcol[3 * bk + 1] += sN * ((q == 1 ? 1.0 : 0.0) - h1 * hq);
+            hcol[3 * bk + 2] += sN * ((q == 2 ? 1.0 : 0.0) - h2 * hq);
+          }
+          const double k2 = ART[bk];
+          if (k2 != 0.0 && q < 2) {  // tangent (-ny, nx)
+            const double tx = -ANY[bk], ty = ANX[bk], tq = q == 0 ? tx : ty;
+            hcol[3 * bk] += k2 * tx * tq;
+            hcol[3 * bk + 1] += k2 * ty * tq;
+          }
+        }
+        const double P00 = near_b ? 0.0 : ADX[bk], P01 = near_b ? 0.0 : ADY[bk], P11 = near_b ? 0.0 : ARX[bk],
+                     PW = near_b ? 0.0 : ARY[bk];
+        const double hx = hcol[3 * bk], hy = hcol[3 * bk + 1];
+        hcol[3 * bk] = P00 * hx + P01 * hy;
+        hcol[3 * bk + 1] = P01 * hx + P11 * hy;
+        hcol[3 * bk + 2] *= PW;
+      }
+      if (lane < kVars) {
+#pragma unroll
+        for (int j = 0; j < kVars; ++j) Hm[j * kVars + lane] = hcol[j];
+      }
+      WAVE_SYNC();
+      // ---- lane j < 3N holds row j: apply P on the column index, add I - P, eliminate
+      double rhs = 0.0, diag = 0.0;
+      if (lane < kVars) {
+#pragma unroll
+        for (int q = 0; q < kVars; ++q) hcol[q] = Hm[lane * kVars + q];
+        rhs = -gr[lane];
+      } else {
+#pragma unroll
+        for (int q = 0; q < kVars; ++q) hcol[q] = 0.0;
+      }
+#pragma unroll
+      for (int bk = 0; bk < kRegSteps; ++bk) {
+        const bool near_b = AMODE[4 * bk + 2] != 0;
+        const double P00 = near_b ? 0.0 : ADX[bk], P01 = near_b ? 0.0 : ADY[bk], P11 = near_b ? 0.0 : ARX[bk],
+                     PW = near_b ? 0.0 : ARY[bk];
+        const double hx = hcol[3 * bk], hy = hcol[3 * bk + 1];
+        hcol[3 * bk] = hx * P00 + hy * P01;
+        hcol[3 * bk + 1] = hx * P01 + hy * P11;
+        hcol[3 * bk + 2] *= PW;
+        const int r = lane - 3 * bk;  // + (I - P) on the diagonal block
+        if (r == 0) { hcol[3 * bk] += 1.0 - P00; hcol[3 * bk + 1] -= P01; diag = hcol[3 * bk]; }
+        if (r == 1) { hcol[3 * bk] -= P01; hcol[3 * bk + 1] += 1.0 - P11; diag = hcol[3 * bk + 1]; }
+        if (r == 2) { hcol[3 * bk + 2] += 1.0 - PW; diag = hcol[3 * bk + 2]; }
+      }
+      const double delta = fmax(1e-10 * wave_max(fabs(diag)), 1e-300);
+      double pinv[kVars];
+#pragma unroll
+      for (int pv = 0; pv < kVars; ++pv) {  // Gaussian elimination, rows in registers, pivot row by readlane
+        double piv = lane_value(hcol[pv], pv);
+        if (!(piv > delta)) piv = fmax(fabs(piv), delta);
+        pinv[pv] = 1.0 / piv;
+        const double fac = (lane > pv && lane < kVars) ? hcol[pv] * pinv[pv] : 0.0;
+#pragma unroll
+        for (int q = pv + 1; q < kVars; ++q) hcol[q] -= fac * lane_value(hcol[q], pv);
+        rhs -= fac * lane_value(rhs, pv);
+      }
+      double dsol[kVars];
+#pragma unroll
+      for (int pv = kVars - 1; pv >= 0; --pv) {  // back substitution; every lane ends with the whole d
+        double acc = rhs;
+#pragma unroll
+        for (int q = pv + 1; q < kVars; ++q) acc -= hcol[q] * dsol[q];
+        dsol[pv] = lane_value(acc * pinv[pv], pv);
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < kVars; ++q) d[q] = dsol[q];
+      }
+      WAVE_SYNC();
+    }
     // ---- new curvature pair
-    if (it > 0) {
+    if (!kNewton && it > 0) {
       double* s = Sm + head * nv;
       double* yv = Ym + head * nv;
       double sy = 0.0, ss = 0.0, yy = 0.0;
@@ -682,7 +822,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     }
     // ---- L-BFGS two-loop recursion on the reduced gradient; lanes take vector elements.
     //      Pair slots are walked with compile-time indices so the alphas stay in registers.
-    {
+    if (!kNewton) {
       constexpr bool kWide = (kSteps == 0) || (3 * kSteps > 64);  // more than 64 variables
       double al[kPairs];
       double q0 = lane < nv ? gr[lane] : 0.0;
@@ -734,7 +874,9 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       if (lane + 64 < nv) d[lane + 64] = -q1;
       if (lane + 128 < nv) d[lane + 128] = -q2;
       WAVE_SYNC();
-      for (int i = lane; i < n; i += kLanes) {  // restrict to the tangent cone's face
+    }
+    {
+      for (int i = lane; i < n; i += kLanes) {  // restrict the direction to the tangent cone's face
         if (AMODE[4 * i + 2]) { d[3 * i] = 0.0; d[3 * i + 1] = 0.0; d[3 * i + 2] = 0.0; continue; }
         if (AMODE[4 * i + 1]) d[3 * i + 2] = 0.0;
         const int mode = AMODE[4 * i];
@@ -757,7 +899,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
           if (kSteps) { cand[3 * i] = b0; cand[3 * i + 1] = b1; cand[3 * i + 2] = b2; }
         },
         [&](int i, double sn, double cs) {
-          if (kSteps) { cand_sn[i] = sn; cand_cs[i] = cs; }
+          if (kSteps && !kNewton) { cand_sn[i] = sn; cand_cs[i] = cs; }
         });
     if (!(fc == fc)) fc = INFINITY;
     double fb = fc;
@@ -770,7 +912,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
 #pragma unroll
         for (int i = 0; i < kRegSteps; ++i) {
           u_new[3 * i] = cand[3 * i]; u_new[3 * i + 1] = cand[3 * i + 1]; u_new[3 * i + 2] = cand[3 * i + 2];
-          ASN[i] = cand_sn[i]; ACS[i] = cand_cs[i];
+          if (!kNewton) { ASN[i] = cand_sn[i]; ACS[i] = cand_cs[i]; }
         }
       }
     } else {
@@ -975,7 +1117,11 @@ void launch_solve(const SolveArgs& a, void* stream) {
   const int w = solve_variant();
   const bool generic = getenv("NEO_MPC_GENERIC_STEPS") != nullptr || a.p.mem != 4;  // A/B: LDS-only path
   const size_t lds = a.lds.total_bytes;
-  if (a.p.n == 3 && !generic) {
+  if (a.p.n == 3 && a.p.newton) {  // projected Newton (its layout does not depend on lbfgs_memory)
+    if (w == 4) hipLaunchKernelGGL((k_solve<4, 3, true>), grid, block, lds, st, a);
+    else if (w == 3) hipLaunchKernelGGL((k_solve<3, 3, true>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((k_solve<2, 3, true>), grid, block, lds, st, a);
+  } else if (a.p.n == 3 && !generic) {
     if (w == 4) hipLaunchKernelGGL((k_solve<4, 3>), grid, block, lds, st, a);
     else if (w == 3) hipLaunchKernelGGL((k_solve<3, 3>), grid, block, lds, st, a);
     else hipLaunchKernelGGL((k_solve<2, 3>), grid, block, lds, st, a);

@@ -351,7 +351,9 @@ typedef struct orc_active {
   uint8_t near[ORC_MAXN];  /* block within kink_radius of the control-norm kink u_i = v_cur: it is
                               moved by the proximal step in every candidate and kept out of the
                               quasi-Newton model (the norm's curvature wc/|u_i - v| is unbounded there) */
+  uint8_t disc[ORC_MAXN];  /* mode 1 and the binding constraint is the disc (curved) */
   double nx[ORC_MAXN], ny[ORC_MAXN];
+  double lambda[ORC_MAXN]; /* mode 1: n . (-g) > 0, the multiplier estimate of the binding constraint */
 } orc_active;
 
 
@@ -374,7 +376,7 @@ static void orc_reduce(const orc_ctx* c, const double* u, const double* gs, doub
     a->near[i] = ne < c->kink_radius;
     if (a->near[i]) {
       for (int k = 0; k < 3; ++k) { gt[3 * i + k] = 0.0; gr[3 * i + k] = 0.0; }
-      a->wfroz[i] = 0; a->mode[i] = 0; a->nx[i] = 0.0; a->ny[i] = 0.0;
+      a->wfroz[i] = 0; a->mode[i] = 0; a->nx[i] = 0.0; a->ny[i] = 0.0; a->disc[i] = 0; a->lambda[i] = 0.0;
       continue;
     }
     /* omega: plain bound */
@@ -382,15 +384,16 @@ static void orc_reduce(const orc_ctx* c, const double* u, const double* gs, doub
     if (a->wfroz[i]) gr[3 * i + 2] = 0.0;
     /* (vx, vy): outward normals of the constraints active at u */
     double nx[3], ny[3];
+    int isdisc[3] = {0, 0, 0};
     int na = 0;
     if (ui[0] <= c->lo[0]) { nx[na] = -1.0; ny[na] = 0.0; ++na; }
     else if (ui[0] >= c->hi[0]) { nx[na] = 1.0; ny[na] = 0.0; ++na; }
     if (ui[1] <= c->lo[1]) { nx[na] = 0.0; ny[na] = -1.0; ++na; }
     else if (ui[1] >= c->hi[1]) { nx[na] = 0.0; ny[na] = 1.0; ++na; }
     double nv = sqrt(ui[0] * ui[0] + ui[1] * ui[1]);
-    if (nv > 0.0 && nv >= c->r * (1.0 - 1e-12)) { nx[na] = ui[0] / nv; ny[na] = ui[1] / nv; ++na; }
+    if (nv > 0.0 && nv >= c->r * (1.0 - 1e-12)) { nx[na] = ui[0] / nv; ny[na] = ui[1] / nv; isdisc[na] = 1; ++na; }
     const double dx = -gi[0], dy = -gi[1]; /* steepest descent */
-    a->mode[i] = 0; a->nx[i] = 0.0; a->ny[i] = 0.0;
+    a->mode[i] = 0; a->nx[i] = 0.0; a->ny[i] = 0.0; a->disc[i] = 0; a->lambda[i] = 0.0;
     int violated = 0;
     for (int k = 0; k < na; ++k) if (nx[k] * dx + ny[k] * dy > 0.0) violated = 1;
     if (violated) {
@@ -409,6 +412,7 @@ static void orc_reduce(const orc_ctx* c, const double* u, const double* gs, doub
       if (bestk >= 0) {
         double dn = nx[bestk] * dx + ny[bestk] * dy;
         a->mode[i] = 1; a->nx[i] = nx[bestk]; a->ny[i] = ny[bestk];
+        a->disc[i] = (uint8_t)isdisc[bestk]; a->lambda[i] = dn;
         gr[3 * i] = -(dx - dn * nx[bestk]);
         gr[3 * i + 1] = -(dy - dn * ny[bestk]);
       } else {
@@ -429,6 +433,87 @@ static void orc_apply_active(const orc_ctx* c, const orc_active* a, double* d) {
     } else if (a->mode[i] == 2) {
       d[3 * i] = 0.0; d[3 * i + 1] = 0.0;
     }
+  }
+}
+
+/* Projected Newton direction (method NEWTON): Hessian of the smooth part by forward differences
+ * of the analytic gradient (one column per perturbed coordinate -- one lane each on the GPU),
+ * plus the control norm's Hessian on blocks away from the kink and the curvature lambda/r of a
+ * binding disc; restricted to the tangent cone's face with the projector P (H_r = P H P + I - P)
+ * and solved by Gaussian elimination without pivoting, non-positive pivots replaced. */
+#define ORC_NEWTON_MAXV 24
+static void orc_newton_direction(const orc_ctx* c, const double* u, const double* gs, const double* gr,
+                                 const orc_active* a, double* d) {
+  const int n = c->n, nv = 3 * n;
+  const double h = 1e-6;
+  double H[ORC_NEWTON_MAXV][ORC_NEWTON_MAXV], rhs[ORC_NEWTON_MAXV], up[ORC_NEWTON_MAXV], gk[ORC_NEWTON_MAXV];
+  for (int k = 0; k < nv; ++k) {
+    memcpy(up, u, sizeof(double) * nv);
+    up[k] += h;
+    orc_grad_smooth(c, up, gk);
+    for (int j = 0; j < nv; ++j) H[j][k] = (gk[j] - gs[j]) / h;
+  }
+  double P00[ORC_MAXN], P01[ORC_MAXN], P11[ORC_MAXN], PW[ORC_MAXN];
+  for (int i = 0; i < n; ++i) {
+    const double* ui = u + 3 * i;
+    if (a->near[i]) { P00[i] = P01[i] = P11[i] = PW[i] = 0.0; continue; }
+    double e[3] = {ui[0] - c->v[0], ui[1] - c->v[1], ui[2] - c->v[2]};
+    double ne = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    if (ne > 0.0) { /* Hessian of (w_control/N) |u_i - v|: (w/|e|)(I - e e^T/|e|^2) */
+      const double s = c->wc_n / ne;
+      for (int r = 0; r < 3; ++r)
+        for (int q = 0; q < 3; ++q)
+          H[3 * i + r][3 * i + q] += s * ((r == q ? 1.0 : 0.0) - (e[r] / ne) * (e[q] / ne));
+    }
+    PW[i] = a->wfroz[i] ? 0.0 : 1.0;
+    if (a->mode[i] == 0) { P00[i] = 1.0; P01[i] = 0.0; P11[i] = 1.0; }
+    else if (a->mode[i] == 1) {
+      const double nx = a->nx[i], ny = a->ny[i];
+      P00[i] = 1.0 - nx * nx; P01[i] = -nx * ny; P11[i] = 1.0 - ny * ny;
+      if (a->disc[i]) { /* moving along the circle: second-order term lambda/r on the tangent */
+        const double k2 = a->lambda[i] / c->r, tx = -ny, ty = nx;
+        H[3 * i][3 * i] += k2 * tx * tx; H[3 * i][3 * i + 1] += k2 * tx * ty;
+        H[3 * i + 1][3 * i] += k2 * ty * tx; H[3 * i + 1][3 * i + 1] += k2 * ty * ty;
+      }
+    } else { P00[i] = P01[i] = P11[i] = 0.0; }
+  }
+  for (int j = 0; j < nv; ++j) /* H <- H P (row j) */
+    for (int i = 0; i < n; ++i) {
+      const double hx = H[j][3 * i], hy = H[j][3 * i + 1];
+      H[j][3 * i] = hx * P00[i] + hy * P01[i];
+      H[j][3 * i + 1] = hx * P01[i] + hy * P11[i];
+      H[j][3 * i + 2] *= PW[i];
+    }
+  for (int k = 0; k < nv; ++k) /* H <- P H (column k) */
+    for (int i = 0; i < n; ++i) {
+      const double hx = H[3 * i][k], hy = H[3 * i + 1][k];
+      H[3 * i][k] = P00[i] * hx + P01[i] * hy;
+      H[3 * i + 1][k] = P01[i] * hx + P11[i] * hy;
+      H[3 * i + 2][k] *= PW[i];
+    }
+  double dmax = 0.0;
+  for (int i = 0; i < n; ++i) { /* + (I - P) */
+    H[3 * i][3 * i] += 1.0 - P00[i]; H[3 * i][3 * i + 1] -= P01[i];
+    H[3 * i + 1][3 * i] -= P01[i]; H[3 * i + 1][3 * i + 1] += 1.0 - P11[i];
+    H[3 * i + 2][3 * i + 2] += 1.0 - PW[i];
+  }
+  for (int j = 0; j < nv; ++j) { rhs[j] = -gr[j]; dmax = fmax(dmax, fabs(H[j][j])); }
+  const double delta = fmax(1e-10 * dmax, 1e-300);
+  for (int p = 0; p < nv; ++p) {
+    double piv = H[p][p];
+    if (!(piv > delta)) piv = fmax(fabs(piv), delta);
+    H[p][p] = piv;
+    const double inv = 1.0 / piv;
+    for (int j = p + 1; j < nv; ++j) {
+      const double fac = H[j][p] * inv;
+      for (int q = p + 1; q < nv; ++q) H[j][q] -= fac * H[p][q];
+      rhs[j] -= fac * rhs[p];
+    }
+  }
+  for (int p = nv - 1; p >= 0; --p) {
+    double acc = rhs[p];
+    for (int q = p + 1; q < nv; ++q) acc -= H[p][q] * d[q];
+    d[p] = acc / H[p][p];
   }
 }
 
@@ -487,6 +572,8 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
   const double xtol = p->step_tolerance > 0.0 ? p->step_tolerance : 1e-3 * p->opt_tolerance;
   const double ftol = p->cost_tolerance > 0.0 ? p->cost_tolerance : 3e-6 * p->opt_tolerance;
   const double stall_step = p->stall_step > 0.0 ? p->stall_step : 0.3 * p->opt_tolerance;
+  const int newton = (p->method == NEO_MPC_METHOD_NEWTON || (p->method == NEO_MPC_METHOD_AUTO && p->control_steps == 3)) &&
+                     3 * p->control_steps <= ORC_NEWTON_MAXV;
 
   double u[ORC_MAXV], gs[ORC_MAXV], gt[ORC_MAXV], gr[ORC_MAXV], d[ORC_MAXV];
   double u_prev[ORC_MAXV], gt_prev[ORC_MAXV], cand[ORC_MAXV], best_c[ORC_MAXV];
@@ -508,7 +595,11 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
   for (it = 0; it < max_it; ++it) {
     orc_grad_smooth(&c, u, gs);
     orc_reduce(&c, u, gs, gt, gr, &act);
-    if (it > 0) {
+    if (newton) {
+      orc_newton_direction(&c, u, gs, gr, &act, d);
+      orc_apply_active(&c, &act, d);
+    }
+    if (!newton && it > 0) {
       double* s = S[head];
       double* y = Y[head];
       for (int k = 0; k < nv; ++k) {
@@ -524,7 +615,7 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
       }
     }
     /* two-loop recursion on the reduced gradient */
-    {
+    if (!newton) {
       double al[NEO_MPC_MAX_LBFGS_MEMORY];
       for (int k = 0; k < nv; ++k) d[k] = gr[k];
       for (int j = 0; j < npairs; ++j) {

@@ -69,16 +69,22 @@ def _g3():
     return g, params, probs, hm
 
 
+@pytest.fixture(params=[0, 1], ids=["newton", "lbfgs"])
+def method(request):
+    return request.param
+
+
 def _cold_solve(params, cmap, probs):
     st, warm = synthetic.make_states(probs, params["control_steps"])
     cmds, x, _ = c_oracle.solve_batch(params, cmap, probs, st, warm)
     return cmds, x
 
 
-def test_p2_solver_mirror_matches_tight_slsqp_where_unique():
+def test_p2_solver_mirror_matches_tight_slsqp_where_unique(method):
     """P2: zero costmap (unique minimiser): first control within 1e-3 of SciPy SLSQP at
     ftol=1e-12 run on the REFERENCE's objective; objective not worse."""
     g, params, probs, hm = _g3()
+    params["method"] = method
     zero = (np.zeros_like(g["cells"]),) + tuple(g["map_meta"])
     cmds, x = _cold_solve(params, zero, probs[~hm])
     du0 = np.abs(x[:, :3] - g["x_tight"][~hm][:, :3]).max(axis=1)
@@ -88,9 +94,10 @@ def test_p2_solver_mirror_matches_tight_slsqp_where_unique():
     assert (cmds["status"] == 0).all()
 
 
-def test_p3_solver_mirror_not_worse_than_reference_tolerance():
+def test_p3_solver_mirror_not_worse_than_reference_tolerance(method):
     """P3: all cases incl. costmaps: f(build) <= f(SciPy @ ftol=1e-3) + 1e-3, feasible."""
     g, params, probs, hm = _g3()
+    params["method"] = method
     for mask, cells in ((~hm, np.zeros_like(g["cells"])), (hm, g["cells"])):
         cmap = (cells,) + tuple(g["map_meta"])
         cmds, x = _cold_solve(params, cmap, probs[mask])

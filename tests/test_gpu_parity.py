@@ -86,14 +86,16 @@ def test_footprint_raster_on_device_matches_oracle(solver_mod):
 
 
 # ------------------------------------------------------------------ solver vs CPU mirror
-@pytest.mark.parametrize("n_steps,count,map_size", [(3, 1024, 500), (8, 256, 200), (32, 64, 200)])
-def test_solver_kernel_matches_cpu_mirror(solver_mod, n_steps, count, map_size):
+@pytest.mark.parametrize("n_steps,count,map_size,method", [(3, 1024, 500, 0), (3, 1024, 500, 1), (8, 256, 200, 0),
+                                                           (32, 64, 200, 0)])
+def test_solver_kernel_matches_cpu_mirror(solver_mod, n_steps, count, map_size, method):
     """Same algorithm, same inputs, f64 on both sides: GPU vs oracle/mpc_oracle.c.
     Differences come only from sincos/atan2 implementations, FMA contraction and the
     summation order of the wave reductions."""
     from oracle import c_oracle
     # control_steps=32 needs more than SLSQP's 100 iterations (96 variables, L-BFGS memory 4)
-    params = util.orc.make_params(control_steps=n_steps, max_iterations=100 if n_steps < 32 else 600)
+    # method 0 = auto: projected Newton at control_steps 3, projected L-BFGS otherwise; 1 = L-BFGS
+    params = util.orc.make_params(control_steps=n_steps, max_iterations=100 if n_steps < 32 else 600, method=method)
     cmap = synthetic.make_costmap(map_size, seed=11)
     probs = synthetic.make_problems(count, map_size, seed=12 + n_steps)
     st_g, warm_g = synthetic.make_states(probs, n_steps)
@@ -114,9 +116,11 @@ def test_solver_kernel_matches_cpu_mirror(solver_mod, n_steps, count, map_size):
 
 
 # ------------------------------------------------------------------ P2 / P3 vs SciPy on the reference
-def test_p2_p3_against_reference_slsqp_solves(solver_mod):
+@pytest.mark.parametrize("method", [0, 1])
+def test_p2_p3_against_reference_slsqp_solves(solver_mod, method):
     g = util.load("g3_solves.npz")
     params = util.params_from(g["param_keys"], g["params"])
+    params["method"] = method
     probs = util.problems_from(g["problems"])
     hm = g["has_map"].astype(bool)
     for mask, cells in ((~hm, np.zeros_like(g["cells"])), (hm, g["cells"])):
