@@ -109,8 +109,21 @@ struct Ctx {
 // sin and cos of a moderate argument: three-term Cody-Waite reduction by pi/2 (exact products for
 // |x| < 1e6) and the degree-13/14 minimax kernels on [-pi/4, pi/4]; ~40 f64 operations, no
 // table, no branch -- the library sincos carries a Payne-Hanek path the rollout never needs.
+// huge or non-finite arguments (never produced by a feasible rollout): the library routine, kept
+// out of line so its Payne-Hanek reduction is not replicated at every call site (I-cache)
+__device__ __attribute__((noinline)) void sincos_slow(double x, double* sn, double* cs) { sincos(x, sn, cs); }
+
+// 1/x by v_rcp_f64 and two Newton steps (error ~1 ulp, no scaling/fix-up for denormals or
+// infinities): used where only a search direction or a unit vector depends on it
+__device__ __forceinline__ double rcp_fast(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
 __device__ __forceinline__ void sincos_fast(double x, double* sn, double* cs) {
-  if (!(fabs(x) < 1.0e6)) { sincos(x, sn, cs); return; }
+  if (!(fabs(x) < 1.0e6)) { sincos_slow(x, sn, cs); return; }
   const double k = rint(x * 6.36619772367581382433e-01);
   double r = fma(-k, 1.57079632673412561417e+00, x);
   r = fma(-k, 6.07710050630396597660e-11, r);
@@ -724,7 +737,8 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         const int q = lane - 3 * bk;  // column inside block bk
         if (q >= 0 && q < 3 && !near_b) {
           if (ne > 0.0) {  // (w/|e|)(I - e e^T / |e|^2)
-            const double sN = p.wc_n / ne, h0 = e0 / ne, h1 = e1 / ne, h2 = e2 / ne;
+            const double ine = rcp_fast(ne);
+            const double sN = p.wc_n * ine, h0 = e0 * ine, h1 = e1 * ine, h2 = e2 * ine;
             const double hq = q == 0 ? h0 : q == 1 ? h1 : h2;
             hcol[3 * bk] += sN * ((q == 0 ? 1.0 : 0.0) - h0 * hq);
             hcol[3 * bk + 1] += sN * ((q == 1 ? 1.0 : 0.0) - h1 * hq);
@@ -779,7 +793,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       for (int pv = 0; pv < kVars; ++pv) {  // Gaussian elimination, rows in registers, pivot row by readlane
         double piv = lane_value(hcol[pv], pv);
         if (!(piv > delta)) piv = fmax(fabs(piv), delta);
-        pinv[pv] = 1.0 / piv;
+        pinv[pv] = rcp_fast(piv);
         const double fac = (lane > pv && lane < kVars) ? hcol[pv] * pinv[pv] : 0.0;
 #pragma unroll
         for (int q = pv + 1; q < kVars; ++q) hcol[q] -= fac * lane_value(hcol[q], pv);
