@@ -108,11 +108,7 @@ struct Ctx {
 
 // sin and cos of a moderate argument: three-term Cody-Waite reduction by pi/2 (exact products for
 // |x| < 1e6) and the degree-13/14 minimax kernels on [-pi/4, pi/4]; ~40 f64 operations, no
-// table, no branch -- the library sincos carries a Payne-Hanek path the rollout never needs.
-// huge or non-finite arguments (never produced by a feasible rollout): the library routine, kept
-// out of line so its Payne-Hanek reduction is not replicated at every call site (I-cache)
-__device__ __attribute__((noinline)) void sincos_slow(double x, double* sn, double* cs) { sincos(x, sn, cs); }
-
+// table, no branch, no call -- the library sincos carries a Payne-Hanek path the rollout never needs.
 // 1/x by v_rcp_f64 and two Newton steps (error ~1 ulp, no scaling/fix-up for denormals or
 // infinities): used where only a search direction or a unit vector depends on it
 __device__ __forceinline__ double rcp_fast(double x) {
@@ -123,7 +119,8 @@ __device__ __forceinline__ double rcp_fast(double x) {
 }
 
 __device__ __forceinline__ void sincos_fast(double x, double* sn, double* cs) {
-  if (!(fabs(x) < 1.0e6)) { sincos_slow(x, sn, cs); return; }
+  // (|x| beyond ~1e6 -- never produced by a feasible rollout, |theta| <= max_vel_theta * horizon
+  // plus a yaw -- only loses accuracy; a non-finite x gives NaN, which the arc search discards)
   const double k = rint(x * 6.36619772367581382433e-01);
   double r = fma(-k, 1.57079632673412561417e+00, x);
   r = fma(-k, 6.07710050630396597660e-11, r);
@@ -141,7 +138,7 @@ __device__ __forceinline__ void sincos_fast(double x, double* sn, double* cs) {
   pc = fma(z, pc, -1.38888888888741095749e-03);
   pc = fma(z, pc, 4.16666666666666019037e-02);
   const double cr = fma(z * z, pc, fma(z, -0.5, 1.0));
-  const int q = (int)k & 3;
+  const int q = (int)fmin(fmax(k, -2.0e9), 2.0e9) & 3;
   const double s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
   *sn = (q & 2) ? -s0 : s0;
   *cs = ((q + 1) & 2) ? -c0 : c0;
@@ -336,7 +333,7 @@ __device__ void make_ctx(const DevParams& p, const DevMap& m, const double* P, d
   double q[4] = {P[P_CUR_Q], P[P_CUR_Q + 1], P[P_CUR_Q + 2],
                  (p.compat & NEO_MPC_COMPAT_ODOM_YAW_GOAL_W) ? P[P_GOAL_Q + 3] : P[P_CUR_Q + 3]};
   const double psi0 = yaw_of(q);                          // py:213 (goal's w: reference quirk)
-  sincos(psi0, &c.s0, &c.c0);
+  sincos_fast(psi0, &c.s0, &c.c0);
   c.true_yaw = yaw_of(P + P_CUR_Q);                      // py:317
   c.X0 = P[P_CUR_X]; c.Y0 = P[P_CUR_Y];
   c.v0 = P[P_VEL]; c.v1 = P[P_VEL + 1]; c.v2 = P[P_VEL + 2];
