@@ -94,8 +94,14 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
-    if world > 1:
+    # NEO_MPC_BENCH_FORCE_DIST=1 exercises the RCCL path with a single rank (used to smoke-test the
+    # multi-GPU code on a 1-GPU box); the JSON line then still reports n_gpus = 1
+    use_dist = world > 1 or os.environ.get("NEO_MPC_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device(dev))
 
     cfg = dict(synthetic.CONFIGS[args.workload])
@@ -116,18 +122,37 @@ def main():
     # inside the timed region; the problems themselves are read-only and shared
     base = DeviceBatch(probs, st, warm, dev, want_solution=False)
     sets = [base.fresh_state() for _ in range(args.steps)]
-    warm_sets = [base.fresh_state() for _ in range(min(args.warmup, 8))]
-    gathered = torch.empty((world, cfg["batch"], 3), dtype=torch.float64, device=dev) if world > 1 else None
+    warm_sets = [base.fresh_state() for _ in range(max(1, min(args.warmup, 8)))]
+    # RCCL all-gather of the commands: a ring of output buffers so that tick i's gather (on RCCL's
+    # stream) overlaps tick i+1's solve kernel; a buffer is reused only after its gather completed
+    ring = 4
+    gathered = [torch.empty((world, cfg["batch"], 3), dtype=torch.float64, device=dev) for _ in range(ring)] \
+        if use_dist else None
     stream = torch.cuda.current_stream()
+    pending = []
 
+    def exchange(i, b):
+        if len(pending) >= ring - 1:
+            pending.pop(0).wait()
+        _, work = gather_commands(b.velocities(), gathered[i % ring], async_op=True)
+        pending.append(work)
+
+    def drain():
+        while pending:
+            pending.pop(0).wait()
+
+    if use_dist:   # communicator set-up happens here, never inside the timed region
+        exchange(0, warm_sets[0] if warm_sets else sets[0])
+        drain()
     for i in range(args.warmup):
         b = warm_sets[i % len(warm_sets)]
         solver.solve_device(base.problems, b.states, b.warm, b.commands)
-        if world > 1:
-            gather_commands(b.velocities(), gathered)
+        if use_dist:
+            exchange(i, b)
+    drain()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -135,16 +160,17 @@ def main():
         evs[i][0].record(stream)
         solver.solve_device(base.problems, b.states, b.warm, b.commands)
         evs[i][1].record(stream)
-        if world > 1:
-            gather_commands(b.velocities(), gathered)
+        if use_dist:
+            exchange(i, b)
+    drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = [a.elapsed_time(b) for a, b in evs]
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -192,7 +218,7 @@ def main():
             except Exception as e:  # the mirror is informational
                 out["cpu_mirror"] = {"error": str(e)}
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

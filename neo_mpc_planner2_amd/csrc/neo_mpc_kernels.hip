@@ -557,8 +557,9 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       // (any unperturbed lane) and all 3N Hessian columns by forward differences -- the sweep
       // costs the same whether the lanes agree or not.
       const double hstep = 1e-6;
-      double pcs[kRegSteps], psn[kRegSteps], pdx[kRegSteps], pdy[kRegSteps], prx[kRegSteps], pry[kRegSteps],
-          prt[kRegSteps];
+      // forward: keep only sin/cos per step; the reverse pass rebuilds increments and residuals
+      // while it unwinds x, y, theta (fewer live registers -> one more wave per SIMD)
+      double pcs[kRegSteps], psn[kRegSteps];
       double x = 0.0, y = 0.0, th = 0.0;
 #pragma unroll
       for (int i = 0; i < kRegSteps; ++i) {
@@ -567,22 +568,24 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         const double w = u[3 * i + 2] + (lane == 3 * i + 2 ? hstep : 0.0);
         th += w * p.dt;
         sincos_fast(th, &psn[i], &pcs[i]);
-        pdx[i] = (vx * pcs[i] - vy * psn[i]) * p.dt;
-        pdy[i] = (vx * psn[i] + vy * pcs[i]) * p.dt;
-        x += pdx[i]; y += pdy[i];
-        prx[i] = -2.0 * p.wt_n * (c.cx - x);
-        pry[i] = -2.0 * p.wt_n * (c.cy - y);
-        prt[i] = -2.0 * p.wo_n * (c.tyaw - th);
-        if (i == kRegSteps - 1) prt[i] += -2.0 * p.wterm_o * (c.fyaw - th);
+        x += (vx * pcs[i] - vy * psn[i]) * p.dt;
+        y += (vx * psn[i] + vy * pcs[i]) * p.dt;
       }
       double SX = 0.0, SY = 0.0, ST = 0.0;
 #pragma unroll
       for (int k = kRegSteps - 1; k >= 0; --k) {
-        SX += prx[k]; SY += pry[k];
-        ST += prt[k] - pdy[k] * SX + pdx[k] * SY;
+        const double vx = u[3 * k] + (lane == 3 * k ? hstep : 0.0);
+        const double vy = u[3 * k + 1] + (lane == 3 * k + 1 ? hstep : 0.0);
+        const double w = u[3 * k + 2] + (lane == 3 * k + 2 ? hstep : 0.0);
+        const double pdx = (vx * pcs[k] - vy * psn[k]) * p.dt, pdy = (vx * psn[k] + vy * pcs[k]) * p.dt;
+        double prt = -2.0 * p.wo_n * (c.tyaw - th);
+        if (k == kRegSteps - 1) prt += -2.0 * p.wterm_o * (c.fyaw - th);
+        SX += -2.0 * p.wt_n * (c.cx - x); SY += -2.0 * p.wt_n * (c.cy - y);
+        ST += prt - pdy * SX + pdx * SY;
         hcol[3 * k] = p.dt * (pcs[k] * SX + psn[k] * SY);
         hcol[3 * k + 1] = p.dt * (-psn[k] * SX + pcs[k] * SY);
         hcol[3 * k + 2] = p.dt * ST;
+        x -= pdx; y -= pdy; th -= w * p.dt;
       }
       const double inv_h = 1.0 / hstep;
 #pragma unroll

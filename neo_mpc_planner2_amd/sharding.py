@@ -17,9 +17,11 @@ def partition(count, world_size, rank):
     return start, min(count, start + per)
 
 
-def gather_commands(local, out=None, group=None):
+def gather_commands(local, out=None, group=None, async_op=False):
     """All-gather the local (n_local, 3) command tensor of every rank into
-    out[world, n_local, 3] (allocated when None).  Equal shard sizes are required."""
+    out[world, n_local, 3] (allocated when None).  Equal shard sizes are required.
+    With `async_op` the collective runs on the backend's own stream and the work handle is
+    returned as well, so the next tick's solve kernel overlaps this tick's gather."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -27,8 +29,9 @@ def gather_commands(local, out=None, group=None):
     if out is None:
         out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
     # concatenated layout [world * n_local, 3] (the form both RCCL and gloo accept)
-    dist.all_gather_into_tensor(out.view((-1,) + tuple(local.shape[1:])), local, group=group)
-    return out
+    work = dist.all_gather_into_tensor(out.view((-1,) + tuple(local.shape[1:])), local, group=group,
+                                       async_op=async_op)
+    return (out, work) if async_op else out
 
 
 def solve_sharded(solve_fn, problems, states, warm, group=None):
