@@ -134,7 +134,7 @@ def main():
     def exchange(i, b):
         if len(pending) >= ring - 1:
             pending.pop(0).wait()
-        _, work = gather_commands(b.velocities(), gathered[i % ring], async_op=True)
+        _, work = gather_commands(b.vel, gathered[i % ring], async_op=True)   # packed by K1, no copy
         pending.append(work)
 
     def drain():
@@ -146,7 +146,7 @@ def main():
         drain()
     for i in range(args.warmup):
         b = warm_sets[i % len(warm_sets)]
-        solver.solve_device(base.problems, b.states, b.warm, b.commands)
+        solver.solve_device(base.problems, b.states, b.warm, b.commands, velocities=b.vel)
         if use_dist:
             exchange(i, b)
     drain()
@@ -158,7 +158,7 @@ def main():
     for i in range(args.steps):
         b = sets[i]
         evs[i][0].record(stream)
-        solver.solve_device(base.problems, b.states, b.warm, b.commands)
+        solver.solve_device(base.problems, b.states, b.warm, b.commands, velocities=b.vel)
         evs[i][1].record(stream)
         if use_dist:
             exchange(i, b)

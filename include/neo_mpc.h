@@ -142,6 +142,8 @@ typedef struct neo_mpc_batch {
                                       polygon, global frame (py:140-144) */
   uint32_t footprint_points;       /* 0: use problems[i].footprint_cost */
   uint32_t reserved;
+  double* velocities;              /* optional out [count][3]: packed copy of commands[i].vel (the
+                                      buffer a multi-GPU caller hands to the all-gather) */
 } neo_mpc_batch;
 
 /* ---- next row of the path: the carrot (look-ahead) selection that feeds the solver ---------- */

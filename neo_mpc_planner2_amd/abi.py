@@ -103,7 +103,7 @@ class NeoMpcBatch(_C.Structure):
     _fields_ = [("count", _C.c_size_t), ("problems", _C.c_void_p), ("states", _C.c_void_p),
                 ("warm_start", _C.c_void_p), ("commands", _C.c_void_p), ("solution", _C.c_void_p),
                 ("predicted_path", _C.c_void_p), ("footprints", _C.c_void_p),
-                ("footprint_points", _C.c_uint32), ("reserved", _C.c_uint32)]
+                ("footprint_points", _C.c_uint32), ("reserved", _C.c_uint32), ("velocities", _C.c_void_p)]
 
 
 class NeoMpcLookaheadParams(_C.Structure):

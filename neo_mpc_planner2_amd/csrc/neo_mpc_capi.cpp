@@ -69,7 +69,7 @@ struct neo_mpc_handle {
   LdsLayout lds{};
   DeviceBuffer map_buf, raw_buf, term_buf;
   DeviceBuffer problems, states, warm, commands, solution, path, footprints, success, u, cost;
-  DeviceBuffer plan_poses, plan_offsets, robot_poses, fp_costs, slow_down, carrots;
+  DeviceBuffer plan_poses, plan_offsets, robot_poses, fp_costs, slow_down, carrots, vel;
 };
 
 namespace {
@@ -211,7 +211,7 @@ int fill_args(neo_mpc_handle* h, const neo_mpc_batch* b, SolveArgs& a) {
     return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "footprint_points > %d", NEO_MPC_MAX_FOOTPRINT_POINTS);
   std::memset(&a, 0, sizeof(a));
   a.problems = b->problems; a.states = b->states; a.warm = b->warm_start; a.commands = b->commands;
-  a.solution = b->solution; a.path = b->predicted_path;
+  a.solution = b->solution; a.path = b->predicted_path; a.velocities = b->velocities;
   a.footprints = b->footprint_points ? b->footprints : nullptr;
   a.footprint_points = b->footprints ? b->footprint_points : 0;
   a.count = (uint32_t)b->count;
@@ -245,6 +245,10 @@ int stage_in(neo_mpc_handle* h, const neo_mpc_batch* b, neo_mpc_batch& d, bool s
     if ((rc = h->path.reserve(n * nv * 8))) return rc;
     d.predicted_path = (double*)h->path.ptr;
   }
+  if (b->velocities) {
+    if ((rc = h->vel.reserve(n * 24))) return rc;
+    d.velocities = (double*)h->vel.ptr;
+  }
   if (b->footprints && b->footprint_points) {
     const size_t bytes = n * b->footprint_points * 2 * 8;
     if ((rc = h->footprints.reserve(bytes))) return rc;
@@ -263,6 +267,7 @@ int stage_out(neo_mpc_handle* h, const neo_mpc_batch* b, bool solution_is_output
     HIP_TRY(hipMemcpy(b->solution, h->solution.ptr, n * nv * 8, hipMemcpyDeviceToHost));
   if (b->predicted_path)
     HIP_TRY(hipMemcpy(b->predicted_path, h->path.ptr, n * nv * 8, hipMemcpyDeviceToHost));
+  if (b->velocities) HIP_TRY(hipMemcpy(b->velocities, h->vel.ptr, n * 24, hipMemcpyDeviceToHost));
   return NEO_MPC_OK;
 }
 
@@ -322,7 +327,7 @@ void neo_mpc_destroy(neo_mpc_handle* h) {
   (void)hipSetDevice(h->device);
   DeviceBuffer* all[] = {&h->map_buf, &h->raw_buf, &h->term_buf, &h->problems, &h->states, &h->warm, &h->commands,
                          &h->solution, &h->path, &h->footprints, &h->success, &h->u, &h->cost, &h->plan_poses,
-                         &h->plan_offsets, &h->robot_poses, &h->fp_costs, &h->slow_down, &h->carrots};
+                         &h->plan_offsets, &h->robot_poses, &h->fp_costs, &h->slow_down, &h->carrots, &h->vel};
   for (DeviceBuffer* b : all) b->release();
   delete h;
 }

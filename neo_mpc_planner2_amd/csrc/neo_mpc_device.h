@@ -103,6 +103,7 @@ struct SolveArgs {
   double* path;            // optional
   const double* footprints;  // optional
   const int32_t* success;    // postprocess only, optional
+  double* velocities;        // optional packed [count][3] copy of the commands
   const double* term_table;  // [256] per-step costmap term by raw cell value
   uint32_t footprint_points;
   uint32_t count;

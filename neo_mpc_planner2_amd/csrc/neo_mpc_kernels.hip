@@ -445,6 +445,7 @@ __device__ void postprocess(const SolveArgs& a, const Ctx& c, double* L, uint32_
     cmd.vel[0] = out0; cmd.vel[1] = out1; cmd.vel[2] = out2;
     cmd.cost = cost; cmd.status = status; cmd.iterations = nit; cmd.evaluations = nfev; cmd.flags = flags;
     a.commands[b] = cmd;
+    if (a.velocities) { double* v = a.velocities + 3 * (size_t)b; v[0] = out0; v[1] = out1; v[2] = out2; }
   }
   WAVE_SYNC();
   if (lane < 16) reinterpret_cast<double*>(a.states + b)[lane] = S[lane];

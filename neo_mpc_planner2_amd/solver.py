@@ -173,7 +173,7 @@ class BatchSolver:
 
     # -- device-resident batches (torch tensors as plain device memory) ----------------
     def solve_device(self, problems, states, warm, commands, solution=None, path=None, footprints=None,
-                     stream=None):
+                     stream=None, velocities=None):
         """All arguments are CUDA uint8/float64 torch tensors holding the C records
         (`DeviceBatch` builds them).  Enqueues K1 on `stream` (default: torch's current)."""
         import torch
@@ -189,6 +189,8 @@ class BatchSolver:
         if footprints is not None:
             b.footprints = footprints.data_ptr()
             b.footprint_points = footprints.shape[1]
+        if velocities is not None:
+            b.velocities = velocities.data_ptr()
         if stream is None:
             stream = torch.cuda.current_stream(problems.device).cuda_stream
         _lib.check(self._lib.neo_mpc_solve_batch_device(self._handle, C.byref(b), C.c_void_p(stream)))
@@ -206,6 +208,7 @@ class DeviceBatch:
         self.warm = torch.from_numpy(np.ascontiguousarray(warm)).to(dev)
         self.commands = torch.zeros((self.count, abi.COMMAND_DTYPE.itemsize), dtype=torch.uint8, device=dev)
         self.solution = torch.zeros_like(self.warm) if want_solution else None
+        self.vel = torch.zeros((self.count, 3), dtype=torch.float64, device=dev)   # packed (vx, vy, w)
 
     def fresh_state(self):
         """Another (states, warm, commands) set for the same problems (shares `problems`)."""
@@ -217,6 +220,7 @@ class DeviceBatch:
         other.warm = self.warm.clone()
         other.commands = torch.zeros_like(self.commands)
         other.solution = None
+        other.vel = torch.zeros_like(self.vel)
         return other
 
     def commands_host(self):

@@ -756,6 +756,7 @@ void orc_solve_batch(const neo_mpc_params* p, const uint8_t* cells, int32_t sx, 
     if (b->solution) memcpy(b->solution + i * nv, x, sizeof(double) * nv);
     orc_postprocess(p, &m, &b->problems[i], &b->states[i], warm, x, out->status == NEO_MPC_STATUS_CONVERGED,
                     fc, out, b->predicted_path ? b->predicted_path + i * nv : NULL);
+    if (b->velocities) for (int k = 0; k < 3; ++k) b->velocities[3 * i + k] = out->vel[k];
   }
 }
 

@@ -48,7 +48,7 @@ int main(void) {
   P(neo_mpc_state, old_goal); P(neo_mpc_state, waiting_time); P(neo_mpc_state, has_old_goal);
   P(neo_mpc_state, collision_footprint);
   P(neo_mpc_command, cost); P(neo_mpc_command, status); P(neo_mpc_command, flags);
-  P(neo_mpc_batch, footprints); P(neo_mpc_batch, footprint_points);
+  P(neo_mpc_batch, footprints); P(neo_mpc_batch, footprint_points); P(neo_mpc_batch, velocities);
   return 0;
 }''')
     exe = tmp_path / "probe"
@@ -68,7 +68,7 @@ int main(void) {
         assert got["neo_mpc_state." + f] == abi.STATE_DTYPE.fields[f][1]
     for f in ("cost", "status", "flags"):
         assert got["neo_mpc_command." + f] == abi.COMMAND_DTYPE.fields[f][1]
-    for f in ("footprints", "footprint_points"):
+    for f in ("footprints", "footprint_points", "velocities"):
         assert got["neo_mpc_batch." + f] == getattr(abi.NeoMpcBatch, f).offset
 
 

@@ -182,8 +182,9 @@ def test_device_resident_batch_matches_host_batch(solver_mod):
     params = util.orc.make_params()
     with _solver(solver_mod, params, cmap) as s:
         db = solver_mod.DeviceBatch(probs, st, warm, "cuda:0")
-        s.solve_device(db.problems, db.states, db.warm, db.commands, db.solution)
+        s.solve_device(db.problems, db.states, db.warm, db.commands, db.solution, velocities=db.vel)
         torch.cuda.synchronize()
+        assert (db.vel.cpu().numpy() == db.commands_host()["vel"]).all()
         cmds, x = s.solve(probs, st, warm)
         assert (db.commands_host()["vel"] == cmds["vel"]).all()
         assert (db.solution.cpu().numpy() == x).all()
