@@ -124,7 +124,7 @@ def main():
     sets = [base.fresh_state() for _ in range(args.steps)]
     warm_sets = [base.fresh_state() for _ in range(max(1, min(args.warmup, 8)))]
     # RCCL all-gather of the commands: a ring of output buffers so that tick i's gather (on RCCL's
-    # stream) overlaps tick i+1's solve kernel; a buffer is reused only after its gather completed
+    # stream) overlaps tick i+1's solve kernel
     ring = 4
     gathered = [torch.empty((world, cfg["batch"], 3), dtype=torch.float64, device=dev) for _ in range(ring)] \
         if use_dist else None
@@ -132,8 +132,9 @@ def main():
     pending = []
 
     def exchange(i, b):
-        if len(pending) >= ring - 1:
-            pending.pop(0).wait()
+        # no per-tick wait on the solve stream: gathers are ordered among themselves on RCCL's
+        # stream, so a ring buffer is rewritten only after its previous gather; handles are
+        # waited for once, before the timed region closes
         _, work = gather_commands(b.vel, gathered[i % ring], async_op=True)   # packed by K1, no copy
         pending.append(work)
 
