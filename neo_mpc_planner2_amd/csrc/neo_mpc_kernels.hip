@@ -118,6 +118,14 @@ __device__ __forceinline__ double rcp_fast(double x) {
   return r;
 }
 
+// 1/sqrt(x), x > 0: v_rsq_f64 and two Newton steps
+__device__ __forceinline__ double rsq_fast(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * fma(fma(-x * r, r, 1.0), 0.5, 1.0);
+  r = r * fma(fma(-x * r, r, 1.0), 0.5, 1.0);
+  return r;
+}
+
 __device__ __forceinline__ void sincos_fast(double x, double* sn, double* cs) {
   // (|x| beyond ~1e6 -- never produced by a feasible rollout, |theta| <= max_vel_theta * horizon
   // plus a yaw -- only loses accuracy; a non-finite x gives NaN, which the arc search discards)
@@ -230,7 +238,7 @@ __device__ __forceinline__ void project_block(const DevParams& p, double& b0, do
   const double zx = b0, zy = b1, r = p.r;
   if (p.disc_in_box) {  // README parameters: the box never binds, the projection is radial
     const double n2 = zx * zx + zy * zy;
-    if (n2 > r * r) { const double sc = r / sqrt(n2); b0 = zx * sc; b1 = zy * sc; }
+    if (n2 > r * r) { const double sc = r * rsq_fast(n2); b0 = zx * sc; b1 = zy * sc; }
     return;
   }
   const double px = clampd(zx, p.lo[0], p.hi[0]), py = clampd(zy, p.lo[1], p.hi[1]);
@@ -280,7 +288,7 @@ __device__ __forceinline__ void candidate_block(const SolveArgs& a, const Ctx& c
     const double e0 = (u[0] - step * gs[0]) - c.v0, e1 = (u[1] - step * gs[1]) - c.v1,
                  e2 = (u[2] - step * gs[2]) - c.v2;
     const double ne = sqrt(e0 * e0 + e1 * e1 + e2 * e2);
-    const double sh = (ne > 0.0) ? fmax(0.0, 1.0 - step * a.p.wc_n / ne) : 0.0;
+    const double sh = (ne > 0.0) ? fmax(0.0, 1.0 - step * a.p.wc_n * rcp_fast(ne)) : 0.0;
     b0 = c.v0 + sh * e0; b1 = c.v1 + sh * e1; b2 = c.v2 + sh * e2;
   } else {          // quasi-Newton direction
     const double* d = L + a.lds.d + 3 * i;
@@ -663,7 +671,8 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       const double ne = sqrt(e0 * e0 + e1 * e1 + e2 * e2);
       double t0, t1, t2;
       if (ne > 0.0) {
-        t0 = g0 + p.wc_n * (e0 / ne); t1 = g1 + p.wc_n * (e1 / ne); t2 = g2 + p.wc_n * (e2 / ne);
+        const double wn = p.wc_n * rcp_fast(ne);
+        t0 = g0 + wn * e0; t1 = g1 + wn * e1; t2 = g2 + wn * e2;
       } else {
         const double ng = sqrt(g0 * g0 + g1 * g1 + g2 * g2);
         const double sh = (ng > p.wc_n) ? 1.0 - p.wc_n / ng : 0.0;
@@ -690,7 +699,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         else if (u1 >= p.hi[1]) { ny1 = 1.0; v1 = true; }
       }
       const double nvv = sqrt(u0 * u0 + u1 * u1);
-      if (nvv > 0.0 && nvv >= p.r * (1.0 - 1e-12)) { nx2 = u0 / nvv; ny2 = u1 / nvv; v2 = true; }
+      if (nvv > 0.0 && nvv >= p.r * (1.0 - 1e-12)) { const double iv = rcp_fast(nvv); nx2 = u0 * iv; ny2 = u1 * iv; v2 = true; }
       const double dx = -t0, dy = -t1;
       const double dn0 = nx0 * dx + ny0 * dy, dn1 = nx1 * dx + ny1 * dy, dn2 = nx2 * dx + ny2 * dy;
       int mode = 0, mslot = -1;
