@@ -10,16 +10,20 @@
 //   K1 k_solve        one 64-lane wavefront per instance.  Per iteration the wave
 //                     evaluates 64 candidate control sequences at once (one rollout per
 //                     lane): lanes 0-31 walk the projected proximal-gradient arc at 32
-//                     step sizes, lanes 32-63 the projected L-BFGS direction at 32 step
-//                     lengths; the lowest objective wins (wave arg-min).  Iterates,
-//                     gradients, L-BFGS pairs and the adjoint sweep's per-step state live
-//                     in LDS; the (2R+1)^2 costmap reach tile is staged into LDS once per
-//                     solve with coalesced dword loads.  float64 throughout (the arc
+//                     step sizes, lanes 32-63 a projected second-order direction at 32 step
+//                     lengths -- Newton at control_steps 3 (finite-difference Hessian of the
+//                     analytic gradient, one column per lane, solved in registers), L-BFGS
+//                     otherwise (rollout/adjoint as DPP prefix scans, lane = step); the lowest
+//                     objective wins (wave arg-min).  Iterates, gradients and the quasi-Newton
+//                     state live in LDS; the (2R+1)^2 costmap reach tile is staged into LDS
+//                     once per solve with coalesced dword loads.  float64 throughout (the arc
 //                     search compares objective values, which resolves the minimiser to
 //                     sqrt(eps); MI355X has full-rate vector f64).
 //   K2 postprocess    py:365-403, fused as the epilogue of K1 and launchable on its own.
 //   K3 k_ingest       raw nav2 costmap -> device map with a lethal border and 128-byte
 //                     row pitch (16 B per lane, HBM-streaming).
+//   K4 k_carrot       the step before the solver: plan pruning + look-ahead point
+//                     (src/NeoMpcPlanner.cpp:83-104, 157-189, 221-232), HBM-streaming.
 //   k_objective       py:204-269 for given controls (parity checks of the objective).
 //
 // No MFMA: a 3*control_steps-variable problem has no dense contraction.
