@@ -1,0 +1,65 @@
+"""Randomised configurations: the HIP solver against the CPU mirror over random parameter
+sets (weights, bounds incl. box-cuts-disc and asymmetric boxes, horizons, tolerances,
+control_steps, costmap resolution) -- the agreement bars are the north star's 1e-3 on the
+velocity command and "not worse than the mirror" on the objective."""
+import numpy as np
+import pytest
+
+from neo_mpc_planner2_amd import synthetic
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def random_params(rng):
+    vmax = rng.uniform(0.2, 1.5)
+    p = util.orc.make_params(
+        control_steps=int(rng.choice([1, 2, 3, 3, 3, 4, 6, 8])),
+        prediction_horizon=float(rng.uniform(0.3, 1.5)),
+        w_trans=float(rng.uniform(0.1, 2.0)), w_orient=float(rng.uniform(0.05, 1.0)),
+        w_control=float(rng.choice([0.0, 0.02, 0.05, 0.3])), w_terminal=float(rng.uniform(0.0, 0.5)),
+        w_costmap=float(rng.uniform(0.0, 0.5)), w_footprint=float(rng.choice([0, 2000])),
+        max_vel_trans=vmax, low_pass_gain=float(rng.uniform(0.2, 1.0)),
+        acc_x_limit=float(rng.uniform(0.5, 3)), acc_y_limit=float(rng.uniform(0.5, 3)),
+        acc_theta_limit=float(rng.uniform(0.5, 3)), opt_tolerance=float(rng.choice([1e-3, 1e-4, 1e-5])),
+        max_vel_theta=float(rng.uniform(0.3, 1.2)))
+    p["min_vel_theta"] = -p["max_vel_theta"] * float(rng.choice([1.0, 0.5]))
+    kind = rng.integers(0, 3)
+    if kind == 0:      # disc inside the box
+        p.update(max_vel_x=vmax * 1.2, min_vel_x=-vmax * 1.2, max_vel_y=vmax, min_vel_y=-vmax)
+    elif kind == 1:    # box cuts the disc, asymmetric (no reverse driving)
+        p.update(max_vel_x=vmax * 0.8, min_vel_x=-vmax * 0.1, max_vel_y=vmax * 0.6, min_vel_y=-vmax * 0.9)
+    else:              # box inside the disc
+        p.update(max_vel_x=vmax * 0.5, min_vel_x=-vmax * 0.5, max_vel_y=vmax * 0.4, min_vel_y=-vmax * 0.4)
+    return p
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_configuration_matches_cpu_mirror(seed):
+    from neo_mpc_planner2_amd.solver import BatchSolver
+    from oracle import c_oracle
+    rng = np.random.default_rng(1000 + seed)
+    params = random_params(rng)
+    n = params["control_steps"]
+    res = float(rng.choice([0.025, 0.05, 0.1]))
+    cmap = synthetic.make_costmap(240, seed=seed, resolution=res)
+    probs = synthetic.make_problems(192, 240, seed=seed + 50, resolution=res)
+    probs["cur_vel"] *= params["max_vel_trans"]
+    probs["footprint_cost"] = rng.choice([0.0, 0.5, 1.0], size=len(probs), p=[0.8, 0.1, 0.1])
+    st, warm = synthetic.make_states(probs, n)
+    warm[:] = rng.uniform(-1, 1, warm.shape) * params["max_vel_trans"] * rng.choice([0.0, 1.0])   # cold or warm
+    st_c, warm_c = st.copy(), warm.copy()
+    with BatchSolver(params) as s:
+        s.set_costmap(*cmap)
+        cg, xg = s.solve(probs, st, warm)
+    cc, xc, _ = c_oracle.solve_batch(params, cmap, probs, st_c, warm_c)
+    f_at = c_oracle.objective_batch(params, cmap, probs, xg)
+    assert np.allclose(f_at, cg["cost"], rtol=1e-11, atol=1e-11)
+    dv = np.abs(cg["vel"] - cc["vel"]).max(axis=1)
+    assert (dv <= 1e-3).mean() >= 0.95, ((dv <= 1e-3).mean(), params)
+    assert (cg["cost"] <= cc["cost"] + 1e-5).mean() >= 0.95
+    assert (st["collision"] == st_c["collision"]).mean() >= 0.97
+    xs = xg.reshape(len(xg), n, 3)
+    assert (xs[:, :, 0] <= params["max_vel_x"] + 1e-12).all() and (xs[:, :, 0] >= params["min_vel_x"] - 1e-12).all()
+    assert (xs[:, :, 1] <= params["max_vel_y"] + 1e-12).all() and (xs[:, :, 1] >= params["min_vel_y"] - 1e-12).all()
+    assert (np.hypot(xs[:, :, 0], xs[:, :, 1]) <= params["max_vel_trans"] * (1 + 1e-9)).all()
