@@ -1067,7 +1067,20 @@ __global__ __launch_bounds__(kLanes) void k_carrot(const CarrotArgs a) {
   // closest pose, first minimum (min_by, cpp:83-88)
   double best = INFINITY;
   uint32_t besti = 0xffffffffu;
-  for (uint32_t k = lane; k < np; k += kLanes) {
+  uint32_t k = lane;
+  for (; k + 3 * kLanes < np; k += 4 * kLanes) {  // four independent pose loads in flight per lane
+    const double x0 = poses[3 * k], y0 = poses[3 * k + 1];
+    const double x1 = poses[3 * (k + kLanes)], y1 = poses[3 * (k + kLanes) + 1];
+    const double x2 = poses[3 * (k + 2 * kLanes)], y2 = poses[3 * (k + 2 * kLanes) + 1];
+    const double x3 = poses[3 * (k + 3 * kLanes)], y3 = poses[3 * (k + 3 * kLanes) + 1];
+    const double d0 = hypot(x0 - rx, y0 - ry), d1 = hypot(x1 - rx, y1 - ry);
+    const double d2 = hypot(x2 - rx, y2 - ry), d3 = hypot(x3 - rx, y3 - ry);
+    if (d0 < best) { best = d0; besti = k; }
+    if (d1 < best) { best = d1; besti = k + kLanes; }
+    if (d2 < best) { best = d2; besti = k + 2 * kLanes; }
+    if (d3 < best) { best = d3; besti = k + 3 * kLanes; }
+  }
+  for (; k < np; k += kLanes) {
     const double d = hypot(poses[3 * k] - rx, poses[3 * k + 1] - ry);
     if (d < best) { best = d; besti = k; }
   }
