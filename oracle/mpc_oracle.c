@@ -318,7 +318,7 @@ static double orc_eval(const orc_ctx* c, const double* u) {
 /* gradient of the smooth (tracking + terminal) part, adjoint sweep */
 static void orc_grad_smooth(const orc_ctx* c, const double* u, double* g) {
   const int n = c->n;
-  double cs[ORC_MAXN], sn[ORC_MAXN], dxs[ORC_MAXN], dys[ORC_MAXN], rx[ORC_MAXN], ry[ORC_MAXN], rt[ORC_MAXN];
+  double cs[ORC_MAXN], sn[ORC_MAXN], dxs[ORC_MAXN], dys[ORC_MAXN], rx[ORC_MAXN], ry[ORC_MAXN], rt[ORC_MAXN] = {0.0};
   double x = 0.0, y = 0.0, th = 0.0;
   for (int i = 0; i < n; ++i) {
     double vx = u[3 * i], vy = u[3 * i + 1], w = u[3 * i + 2];
