@@ -368,6 +368,7 @@ int neo_mpc_solve_batch_device(neo_mpc_handle* h, const neo_mpc_batch* batch, vo
   SolveArgs a;
   int rc = fill_args(h, batch, a);
   if (rc) return rc;
+  HIP_TRY(hipSetDevice(h->device));  // the stream and the buffers must belong to the handle's device
   launch_solve(a, stream);
   HIP_TRY(hipGetLastError());
   return NEO_MPC_OK;
@@ -451,6 +452,7 @@ int neo_mpc_select_carrots_device(neo_mpc_handle* h, const neo_mpc_lookahead_par
   CarrotArgs a;
   a.lp = *lp;
   a.b = *b;
+  HIP_TRY(hipSetDevice(h->device));
   launch_carrots(a, stream);
   HIP_TRY(hipGetLastError());
   return NEO_MPC_OK;
