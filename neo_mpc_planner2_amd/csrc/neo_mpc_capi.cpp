@@ -135,7 +135,10 @@ void derive(neo_mpc_handle* h) {
 
   // LDS carve-up (shared with the kernel specialisations) + reach tile geometry
   LdsLayout& l = h->lds;
-  l = make_lds_layout(n, d.mem);
+  // the control_steps == 3 specialisations carve LDS at compile time with 4 pair slots; the host
+  // must reserve exactly that layout whenever launch_solve() will pick them
+  const bool specialised = n == 3 && (d.newton || d.mem == 4);
+  l = make_lds_layout(n, specialised ? 4 : d.mem);
   const int off = l.tile;
   l.tile_w = 0; l.tile_h = 0; l.reach = 0;
   if (h->has_map) {

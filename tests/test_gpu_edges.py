@@ -201,3 +201,31 @@ def test_multi_tick_state_stays_resident_on_the_device():
     assert min(agree) >= 0.95, agree
     assert (sg["collision"] == st_c["collision"]).mean() >= 0.97
     assert (sg["has_old_goal"] == 1).all()
+
+
+@pytest.mark.parametrize("method,mem", [(0, 2), (0, 8), (1, 2), (1, 6), (1, 4)])
+def test_lbfgs_memory_and_method_combinations_at_three_steps(method, mem):
+    """control_steps 3 picks a compile-time LDS layout (4 pair slots) for the Newton and the
+    memory-4 L-BFGS specialisations and the runtime layout otherwise: every combination must agree
+    with the mirror."""
+    from neo_mpc_planner2_amd.solver import BatchSolver
+    params = util.orc.make_params(method=method, lbfgs_memory=mem)
+    cmap = synthetic.make_costmap(500, seed=31)
+    probs = synthetic.make_problems(512, 500, seed=32)
+    st, warm = synthetic.make_states(probs, 3)
+    st_c, warm_c = st.copy(), warm.copy()
+    with BatchSolver(params) as s:
+        s.set_costmap(*cmap)
+        cg, xg = s.solve(probs, st, warm)
+    cc, xc, _ = _mirror(params, cmap, probs, st_c, warm_c)
+    _close(cg, cc, frac=0.97)
+    assert (cg["cost"] <= cc["cost"] + 1e-6).mean() >= 0.97
+    assert (cg["status"] == 0).mean() >= 0.99
+
+
+def test_newton_is_refused_for_other_control_steps():
+    from neo_mpc_planner2_amd import _lib
+    from neo_mpc_planner2_amd.solver import BatchSolver
+    with pytest.raises(_lib.NeoMpcError) as e:
+        BatchSolver(util.orc.make_params(control_steps=5, method=2))
+    assert e.value.code == -1 or "control_steps == 3" in str(e.value)
