@@ -77,7 +77,8 @@ typedef struct neo_mpc_params {
   int32_t compat_flags;   /* NEO_MPC_COMPAT_*; neo_mpc_default_params sets all (parity mode) */
   double step_tolerance;  /* stop when max|du| < this; <=0: 1e-3 * opt_tolerance */
   double cost_tolerance;  /* an iteration is "stalled" when it lowers the objective by less than
-                             cost_tolerance * max(1, |f|) (<=0: 3e-6 * opt_tolerance) or moves less
+                             cost_tolerance * max(1, |f|) (<=0: 3e-6 * opt_tolerance with L-BFGS, 3e-4 *
+                             opt_tolerance with Newton) or moves less
                              than stall_step; 5 stalled iterations in a row end the search */
   double kink_radius;     /* blocks with |u_i - v_cur| below this are moved by the proximal step of
                              the control norm and kept out of the L-BFGS model; <=0: 3e-3 */

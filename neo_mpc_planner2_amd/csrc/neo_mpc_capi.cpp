@@ -123,7 +123,6 @@ void derive(neo_mpc_handle* h) {
   d.acc[0] = p.acc_x_limit; d.acc[1] = p.acc_y_limit; d.acc[2] = p.acc_theta_limit;
   d.low_pass_gain = p.low_pass_gain;
   d.xtol = p.step_tolerance > 0.0 ? p.step_tolerance : 1e-3 * p.opt_tolerance;
-  d.ftol = p.cost_tolerance > 0.0 ? p.cost_tolerance : 3e-6 * p.opt_tolerance;
   d.kink_radius = p.kink_radius > 0.0 ? p.kink_radius : 3e-3;
   d.stall_step = p.stall_step > 0.0 ? p.stall_step : 0.3 * p.opt_tolerance;
   d.max_it = p.max_iterations > 0 ? p.max_iterations : 100;
@@ -132,6 +131,7 @@ void derive(neo_mpc_handle* h) {
   d.disc_in_box = (p.min_vel_x <= -p.max_vel_trans && p.max_vel_x >= p.max_vel_trans &&
                    p.min_vel_y <= -p.max_vel_trans && p.max_vel_y >= p.max_vel_trans) ? 1 : 0;
   d.newton = ((p.method == NEO_MPC_METHOD_NEWTON || p.method == NEO_MPC_METHOD_AUTO) && n == 3) ? 1 : 0;
+  d.ftol = p.cost_tolerance > 0.0 ? p.cost_tolerance : (d.newton ? 3e-4 : 3e-6) * p.opt_tolerance;
 
   // LDS carve-up (shared with the kernel specialisations) + reach tile geometry
   LdsLayout& l = h->lds;
