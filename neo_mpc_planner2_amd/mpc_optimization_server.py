@@ -39,6 +39,11 @@ README_PARAMS = dict(
 DYNAMIC_PARAMS = ("min_vel_x", "min_vel_y", "min_vel_trans", "min_vel_theta", "max_vel_x", "max_vel_y",
                   "max_vel_trans", "max_vel_theta", "w_trans", "w_orient", "w_control", "w_terminal",
                   "w_costmap", "w_footprint")
+#: ... of which only these change the reference's behaviour: the velocity box is baked into
+#: `self.bnds` at construction (py:125-133, never rebuilt), `min_vel_trans` is unused, and the
+#: w_costmap / w_footprint branches assign attributes nothing reads (py:433, 435; the objective
+#: uses `w_costmap_scale` / `w_footprint_scale`, py:260, 263).  SURVEY.md Appendix A #12, #13.
+EFFECTIVE_DYNAMIC_PARAMS = ("max_vel_trans", "w_trans", "w_orient", "w_control", "w_terminal")
 
 
 def load_params_yaml(path, node="mpc_optimization_server"):
@@ -106,7 +111,10 @@ class MpcOptimizationServer:
     parameters: dict of the reference's ROS parameter names (missing ones take py:49-75
     defaults).  `clock` replaces `time.time` (py:369) for deterministic tests."""
 
-    def __init__(self, parameters=None, device=0, clock=time.time):
+    def __init__(self, parameters=None, device=0, clock=time.time, reference_quirks=True):
+        """reference_quirks: reproduce the reference's dynamic-reconfigure behaviour, where only
+        EFFECTIVE_DYNAMIC_PARAMS reach the optimisation; False makes every accepted name effective."""
+        self.reference_quirks = bool(reference_quirks)
         p = dict(DEFAULT_PARAMS)
         p.update(parameters or {})
         for name, value in p.items():                       # py:78-103
@@ -157,12 +165,16 @@ class MpcOptimizationServer:
     def cb_params(self, data):                               # py:405-439
         changes = {}
         for parameter in data:
+            if getattr(parameter, "type_", 3) != 3:      # py:407: Parameter.Type.DOUBLE only
+                continue
             if parameter.name in DYNAMIC_PARAMS:
                 changes[parameter.name] = float(parameter.value)
+        for k, v in changes.items():                    # the node's attributes always change ...
+            setattr(self, k, v)
+        if self.reference_quirks:                       # ... the optimisation only sees these
+            changes = {k: v for k, v in changes.items() if k in EFFECTIVE_DYNAMIC_PARAMS}
         if changes:
             self._params.update(changes)
-            for k, v in changes.items():
-                setattr(self, k, v)
             self._solver.set_params(**changes)
         return types.SimpleNamespace(successful=True)
 

@@ -257,6 +257,15 @@ def test_server_mirror_episode_matches_oracle_wrapper():
                               vel[0] * math.sin(yaw) + vel[1] * math.cos(yaw)]) / 30.0
     # dynamic reconfigure through the reference's callback name (py:405-439)
     from types import SimpleNamespace as NS
-    node.cb_params([NS(name="w_trans", value=0.5, type_=3), NS(name="not_dynamic", value=1.0, type_=3)])
-    assert node.w_trans == 0.5
+    node.cb_params([NS(name="w_trans", value=0.5, type_=3), NS(name="not_dynamic", value=1.0, type_=3),
+                    NS(name="max_vel_x", value=0.1, type_=3), NS(name="w_costmap", value=9.0, type_=3),
+                    NS(name="w_orient", value=7, type_=2)])
+    assert node.w_trans == 0.5 and node.max_vel_x == 0.1 and node.w_costmap == 9.0 and node.w_orient == 0.5
+    # like the reference, the baked velocity box and w_costmap_scale do not change (py:125-133, 433)
+    assert node._solver.params["w_trans"] == 0.5 and node._solver.params["max_vel_x"] == 0.7
+    assert node._solver.params["w_costmap"] == 0.05
     node.close()
+    node2 = srv.MpcOptimizationServer(params, reference_quirks=False)
+    node2.cb_params([NS(name="max_vel_x", value=0.1, type_=3)])
+    assert node2._solver.params["max_vel_x"] == 0.1
+    node2.close()
