@@ -218,9 +218,20 @@ def main():
                                      "what": "the build's own algorithm in C with OpenMP (oracle/mpc_oracle.c)"}
             except Exception as e:  # the mirror is informational
                 out["cpu_mirror"] = {"error": str(e)}
-        print(json.dumps(out))
+        result_line = json.dumps(out)
+    else:
+        result_line = None
     if use_dist:
         dist.destroy_process_group()
+    # RCCL prints its banner through C stdio, which (when stdout is a pipe) is flushed only at
+    # exit -- after Python's own output.  Flush it first so that the JSON line is the last line.
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if result_line is not None:
+        print(result_line, flush=True)
 
 
 if __name__ == "__main__":
