@@ -217,10 +217,9 @@ class FakeClock:
         return self.t
 
 
-def gen_g4(mod):
-    """8 episodes x 50 sequential optimizer() calls through the reference wrapper."""
-    n_ep, n_calls = 8, 50
-    params = dict(README_PARAMS)
+def gen_g4(mod, n_steps=3, n_ep=8, n_calls=50, fname="g4_episodes.npz"):
+    """`n_ep` episodes x `n_calls` sequential optimizer() calls through the reference wrapper."""
+    params = dict(README_PARAMS, control_steps=n_steps)
     cmap = synthetic.make_costmap(200, seed=4)
     cells, res, ox, oy = cmap
     clock = FakeClock()
@@ -302,15 +301,15 @@ def gen_g4(mod):
                                             vel[0] * math.sin(yaw) + vel[1] * math.cos(yaw)])
     shape = (n_ep, n_calls)
     np.savez_compressed(
-        os.path.join(OUT, "g4_episodes.npz"), versions=np.array(repr(versions())),
+        os.path.join(OUT, fname), versions=np.array(repr(versions())),
         param_keys=np.array(PARAM_KEYS), params=params_vec(params), cells=cells,
         map_meta=np.array(cmap[1:]),
         problems=np.array(rec["problems"]).reshape(shape + (PROBLEM_DTYPE.itemsize,)),
         delta_t=np.array(rec["delta_t"]).reshape(shape),
-        raw_x=np.array(rec["raw_x"]).reshape(shape + (9,)),
+        raw_x=np.array(rec["raw_x"]).reshape(shape + (3 * n_steps,)),
         success=np.array(rec["success"]).reshape(shape),
         out=np.array(rec["out"]).reshape(shape + (3,)),
-        init_guess=np.array(rec["init_guess"]).reshape(shape + (9,)),
+        init_guess=np.array(rec["init_guess"]).reshape(shape + (3 * n_steps,)),
         last_control=np.array(rec["last_control"]).reshape(shape + (3,)),
         collision=np.array(rec["collision"]).reshape(shape),
         collision_footprint=np.array(rec["collision_footprint"]).reshape(shape),
@@ -318,8 +317,8 @@ def gen_g4(mod):
         footprint=np.array(rec["footprint"]).reshape(shape + (4, 2)))
     n_col = int(np.sum(rec["collision"]))
     n_fp = int(np.sum(rec["collision_footprint"]))
-    print("G4: %d episodes x %d calls; collision-latched calls %d, footprint-collision calls %d"
-          % (n_ep, n_calls, n_col, n_fp))
+    print("G4 (%s, control_steps %d): %d episodes x %d calls; collision-latched calls %d, footprint-collision "
+          "calls %d" % (fname, n_steps, n_ep, n_calls, n_col, n_fp))
 
 
 def gen_g5(mod):
@@ -367,6 +366,7 @@ def main():
     gen_g2(mod)
     gen_g3(mod)
     gen_g4(mod)
+    gen_g4(mod, n_steps=8, n_ep=4, n_calls=30, fname="g4_episodes_n8.npz")
     gen_g5(mod)
     gen_g6(mod)
 

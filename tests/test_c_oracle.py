@@ -34,14 +34,15 @@ def test_g2_yaw():
         assert c_oracle.yaw(*q) == rpy[2]
 
 
-def test_g4_wrapper_episodes_injected():
-    """P5 for the C wrapper: responses and state over 8 x 50 calls, reference x.x injected."""
-    g = util.load("g4_episodes.npz")
+@pytest.mark.parametrize("fixture", ["g4_episodes.npz", "g4_episodes_n8.npz"])
+def test_g4_wrapper_episodes_injected(fixture):
+    """P5 for the C wrapper: responses and state over the recorded episodes, reference x.x injected."""
+    g = util.load(fixture)
     params = util.params_from(g["param_keys"], g["params"])
     cmap = (g["cells"],) + tuple(g["map_meta"])
     probs = util.problems_from(g["problems"])
     n_ep, n_calls = probs.shape
-    states, warm = abi.new_states(n_ep, 3)
+    states, warm = abi.new_states(n_ep, params["control_steps"])
     for k in range(n_calls):
         fp = g["footprint"][:, k]
         rows = probs[:, k].copy()
@@ -59,6 +60,7 @@ def test_g4_wrapper_episodes_injected():
         assert np.allclose(states["waiting_time"], g["waiting_time"][:, k], rtol=0, atol=1e-12)
         assert ((cmds["flags"] & abi.FLAG_RESET) != 0).tolist() == \
             [k == 0 or (k == 25 and ep % 2 == 1) for ep in range(n_ep)]
+    assert warm.shape[1] == 3 * params["control_steps"]
 
 
 def _g3():

@@ -43,14 +43,15 @@ def test_objective_kernel_matches_reference_golden(solver_mod, n_steps):
 
 
 # ------------------------------------------------------------------ P5: wrapper episodes
-def test_postprocess_kernel_reproduces_reference_episodes(solver_mod):
+@pytest.mark.parametrize("fixture", ["g4_episodes.npz", "g4_episodes_n8.npz"])
+def test_postprocess_kernel_reproduces_reference_episodes(solver_mod, fixture):
     from oracle import c_oracle
-    g = util.load("g4_episodes.npz")
+    g = util.load(fixture)
     params = util.params_from(g["param_keys"], g["params"])
     cmap = (g["cells"],) + tuple(g["map_meta"])
     probs = util.problems_from(g["problems"])
     n_ep, n_calls = probs.shape
-    states, warm = abi.new_states(n_ep, 3)
+    states, warm = abi.new_states(n_ep, params["control_steps"])
     with _solver(solver_mod, params, cmap) as s:
         for k in range(n_calls):
             fp = g["footprint"][:, k]

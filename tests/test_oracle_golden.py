@@ -76,16 +76,17 @@ def test_g3_slsqp_restated_objective_reproduces_reference_solves():
         assert abs(r.fun - g["f_loose"][j]) <= 1e-8 * max(1.0, abs(r.fun))
 
 
-def test_g4_wrapper_episodes_with_injected_solver_output():
+@pytest.mark.parametrize("fixture", ["g4_episodes.npz", "g4_episodes_n8.npz"])
+def test_g4_wrapper_episodes_with_injected_solver_output(fixture):
     """P5: given the reference's raw solver output, the restated optimizer() wrapper
-    reproduces responses and state across 8 x 50 sequential calls."""
-    g = util.load("g4_episodes.npz")
+    reproduces responses and state across the recorded episodes (control_steps 3 and 8)."""
+    g = util.load(fixture)
     params = util.params_from(g["param_keys"], g["params"])
     cmap = util.oracle_costmap(g["cells"], g["map_meta"])
     probs = util.problems_from(g["problems"])
     n_ep, n_calls = probs.shape
     for ep in range(n_ep):
-        state = orc.ServerState(3)
+        state = orc.ServerState(params["control_steps"])
         for k in range(n_calls):
             prob = util.oracle_problem(probs[ep, k], g["footprint"][ep, k])
             inject = (g["raw_x"][ep, k].copy(), bool(g["success"][ep, k]))
