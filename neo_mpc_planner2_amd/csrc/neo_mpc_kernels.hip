@@ -556,6 +556,8 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     b0 = u[3 * i]; b1 = u[3 * i + 1]; b2 = u[3 * i + 2];
   });
   f = lane_value(f, 0);
+  bool cold = true;  // x0 == 0 (wave-uniform: every lane scans the same LDS values)
+  for (int k = 0; k < nv; ++k) cold = cold && (u[k] == 0.0);
 
   for (int i = lane; i < n; i += kLanes) { AMODE[4 * i + 2] = 0; AMODE[4 * i + 3] = 0; }
   double alpha = 1.0;
@@ -739,7 +741,12 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       }
     }
     WAVE_SYNC();
-    if (kNewton) {
+    if (kNewton && it == 0 && cold) {
+      // a cold start (x0 = 0, the reference's reset state py:359) is far from the minimiser and the
+      // Newton step almost never wins there: steepest descent on the face for this one iteration
+      if (lane < kVars) d[lane] = -gr[lane];
+      WAVE_SYNC();
+    } else if (kNewton) {
       double* Hm = L + a.lds.hess;
       // ---- lane k < 3N holds Hessian column k: add the control norm's Hessian and the disc
       //      curvature on its diagonal block, apply P on the row index, store the column

