@@ -1147,13 +1147,14 @@ __global__ __launch_bounds__(kLanes) void k_carrot(const CarrotArgs a) {
 
 }  // namespace
 
-// Register budget of K1: 2 waves/SIMD (default; measured 5.0 vs 4.1 M solves/s on C2) or 4 waves/SIMD (128 VGPRs,
-// scratch spills).  NEO_MPC_SOLVE_WAVES=2|4 selects the variant for A/B measurements.
+// Register budget of K1: __launch_bounds__(64, 3) by default -- the kernels sit just under the
+// 168-VGPR step (Newton 166, generic 143), and pinning 3 waves/SIMD keeps a later edit from silently
+// falling to 2.  NEO_MPC_SOLVE_WAVES=2|3|4 selects the variant for A/B measurements (4 spills).
 static int solve_variant() {
   static int v = 0;
   if (v == 0) {
     const char* e = getenv("NEO_MPC_SOLVE_WAVES");
-    v = (e && atoi(e) == 4) ? 4 : (e && atoi(e) == 3) ? 3 : 2;
+    v = (e && atoi(e) == 4) ? 4 : (e && atoi(e) == 2) ? 2 : 3;
   }
   return v;
 }
@@ -1176,6 +1177,7 @@ void launch_solve(const SolveArgs& a, void* stream) {
   } else {  // any other control_steps (measured: at N = 8 the scan-based generic path beats a register
             // specialisation, 8.5 vs 10.1 ms per 65 536 instances)
     if (w == 4) hipLaunchKernelGGL((k_solve<4, 0>), grid, block, lds, st, a);
+    else if (w == 3) hipLaunchKernelGGL((k_solve<3, 0>), grid, block, lds, st, a);
     else hipLaunchKernelGGL((k_solve<2, 0>), grid, block, lds, st, a);
   }
 }
