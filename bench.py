@@ -61,6 +61,16 @@ def cpu_baseline(params, cmap, probs, seconds=15.0):
     return done / dt, done, dt
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_mirror_rate(params, cmap, probs, st, warm):
     """Secondary: the build's own algorithm on the host cores (oracle/mpc_oracle.c, OpenMP)."""
     from oracle import c_oracle
@@ -208,6 +218,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             rate, cnt, secs = cpu_baseline(params, cmap, probs)
             out["cpu_baseline"] = {"value": rate, "unit": "solves/s", "cores": 1, "kind": "port",
+                                   "cpu_model": cpu_model(), "host_threads_available": os.cpu_count(),
                                    "sample": "first %d of the %d %s instances, SciPy SLSQP ftol=%g on the restated "
                                              "Python objective (oracle/mpc_oracle.py), cold start, %.1f s"
                                              % (cnt, cfg["batch"], args.workload, params["opt_tolerance"], secs)}
