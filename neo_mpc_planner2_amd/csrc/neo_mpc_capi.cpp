@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -131,6 +132,7 @@ void derive(neo_mpc_handle* h) {
   d.disc_in_box = (p.min_vel_x <= -p.max_vel_trans && p.max_vel_x >= p.max_vel_trans &&
                    p.min_vel_y <= -p.max_vel_trans && p.max_vel_y >= p.max_vel_trans) ? 1 : 0;
   d.newton = ((p.method == NEO_MPC_METHOD_NEWTON || p.method == NEO_MPC_METHOD_AUTO) && n == 3) ? 1 : 0;
+  d.early_tol = getenv("NEO_MPC_NO_EARLY") ? 0.0 : d.xtol;
   d.ftol = p.cost_tolerance > 0.0 ? p.cost_tolerance : (d.newton ? 3e-4 : 3e-6) * p.opt_tolerance;
 
   // LDS carve-up (shared with the kernel specialisations) + reach tile geometry

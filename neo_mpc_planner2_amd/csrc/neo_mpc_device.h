@@ -24,6 +24,7 @@ struct DevParams {
   double acc[3];             // post clamp (py:385-391)
   double low_pass_gain;      // py:367
   double xtol;               // step tolerance
+  double early_tol;          // Newton: stop when the full step is below this (= xtol; 0 disables, A/B)
   double ftol;               // relative cost decrease below which an iteration counts as stalled
   double stall_step;         // ... or max|du| below this
   double kink_radius;        // |u_i - v_cur| below which a block is handled by the prox step only

@@ -924,6 +924,16 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       }
       WAVE_SYNC();
     }
+    if (kNewton && it > 0) {
+      // the full Newton step is already below the step tolerance: u is the answer (blocks next to
+      // the kink are moved by the prox step, which d does not describe -- keep iterating then)
+      double dm = 0.0;
+      int anynear = 0;
+      if (lane < kVars) { dm = fabs(d[lane]); anynear = AMODE[4 * (lane / 3) + 2]; }
+      dm = wave_max(dm);
+      const bool near_any = __ballot(anynear != 0) != 0ull;
+      if (dm < p.early_tol && !near_any) { status = NEO_MPC_STATUS_CONVERGED; break; }
+    }
     // ---- 64 candidates, one rollout per lane; lowest objective wins
     const double pstep = alpha * lane_scale(lane);
     const double step = lane < 32 ? pstep : lane_scale(lane);

@@ -606,6 +606,14 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
       if (it == 0 && cold) for (int k = 0; k < nv; ++k) d[k] = -gr[k];
       else orc_newton_direction(&c, u, gs, gr, &act, d);
       orc_apply_active(&c, &act, d);
+      if (it > 0) { /* the full Newton step is already below the step tolerance: u is the answer
+                     * (the prox-moved blocks next to the kink are not covered by d) */
+        double dm = 0.0;
+        int anynear = 0;
+        for (int k = 0; k < nv; ++k) dm = fmax(dm, fabs(d[k]));
+        for (int i = 0; i < n; ++i) anynear |= act.near[i];
+        if (dm < xtol && !anynear) { status = NEO_MPC_STATUS_CONVERGED; break; }
+      }
     }
     if (!newton && it > 0) {
       double* s = S[head];
