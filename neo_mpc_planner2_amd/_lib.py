@@ -10,7 +10,9 @@ import os
 from . import abi
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libneo_mpc.so")
+#: NEO_MPC_LIB selects another build of the same library (development A/B runs inside one gpurun
+#: call: box-to-box variance is ~5 %, so two builds are only comparable on the same box)
+LIB_PATH = os.environ.get("NEO_MPC_LIB") or os.path.join(HERE, "libneo_mpc.so")
 
 #: every symbol include/neo_mpc.h declares
 EXPORTS = (
