@@ -808,25 +808,32 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         if (r == 1) { hcol[3 * bk] -= P01; hcol[3 * bk + 1] += 1.0 - P11; diag = hcol[3 * bk + 1]; }
         if (r == 2) { hcol[3 * bk + 2] += 1.0 - PW; diag = hcol[3 * bk + 2]; }
       }
-      const double delta = fmax(1e-10 * wave_max(fabs(diag)), 1e-300);
-      double pinv[kVars];
+      // the reduced system is solved in float32: it only yields a search direction (the arc search
+      // and the f64 objective decide), and single precision halves the readlanes and the VALU time
+      const float deltaf = fmaxf(1e-6f * (float)wave_max(fabs(diag)), 1e-30f);
+      float hr[kVars], rhsf = (float)rhs, pinvf[kVars];
 #pragma unroll
-      for (int pv = 0; pv < kVars; ++pv) {  // Gaussian elimination, rows in registers, pivot row by readlane
-        double piv = lane_value(hcol[pv], pv);
-        if (!(piv > delta)) piv = fmax(fabs(piv), delta);
-        pinv[pv] = rcp_fast(piv);
-        const double fac = (lane > pv && lane < kVars) ? hcol[pv] * pinv[pv] : 0.0;
+      for (int q = 0; q < kVars; ++q) hr[q] = (float)hcol[q];
 #pragma unroll
-        for (int q = pv + 1; q < kVars; ++q) hcol[q] -= fac * lane_value(hcol[q], pv);
-        rhs -= fac * lane_value(rhs, pv);
+      for (int pv = 0; pv < kVars; ++pv) {
+        float piv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hr[pv]), pv));
+        if (!(piv > deltaf)) piv = fmaxf(fabsf(piv), deltaf);
+        pinvf[pv] = __builtin_amdgcn_rcpf(piv);
+        const float fac = (lane > pv && lane < kVars) ? hr[pv] * pinvf[pv] : 0.0f;
+#pragma unroll
+        for (int q = pv + 1; q < kVars; ++q)
+          hr[q] -= fac * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hr[q]), pv));
+        rhsf -= fac * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rhsf), pv));
       }
       double dsol[kVars];
+      float dsf[kVars];
 #pragma unroll
-      for (int pv = kVars - 1; pv >= 0; --pv) {  // back substitution; every lane ends with the whole d
-        double acc = rhs;
+      for (int pv = kVars - 1; pv >= 0; --pv) {
+        float acc = rhsf;
 #pragma unroll
-        for (int q = pv + 1; q < kVars; ++q) acc -= hcol[q] * dsol[q];
-        dsol[pv] = lane_value(acc * pinv[pv], pv);
+        for (int q = pv + 1; q < kVars; ++q) acc -= hr[q] * dsf[q];
+        dsf[pv] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc * pinvf[pv]), pv));
+        dsol[pv] = (double)dsf[pv];
       }
       if (lane == 0) {
 #pragma unroll

@@ -498,22 +498,26 @@ static void orc_newton_direction(const orc_ctx* c, const double* u, const double
     H[3 * i + 2][3 * i + 2] += 1.0 - PW[i];
   }
   for (int j = 0; j < nv; ++j) { rhs[j] = -gr[j]; dmax = fmax(dmax, fabs(H[j][j])); }
-  const double delta = fmax(1e-10 * dmax, 1e-300);
+  /* the reduced system is solved in float32 (as the kernel does): it only yields a search direction */
+  float Hf[ORC_NEWTON_MAXV][ORC_NEWTON_MAXV], rf[ORC_NEWTON_MAXV], df[ORC_NEWTON_MAXV];
+  for (int j = 0; j < nv; ++j) { rf[j] = (float)rhs[j]; for (int q = 0; q < nv; ++q) Hf[j][q] = (float)H[j][q]; }
+  const float delta = fmaxf(1e-6f * (float)dmax, 1e-30f);
   for (int p = 0; p < nv; ++p) {
-    double piv = H[p][p];
-    if (!(piv > delta)) piv = fmax(fabs(piv), delta);
-    H[p][p] = piv;
-    const double inv = 1.0 / piv;
+    float piv = Hf[p][p];
+    if (!(piv > delta)) piv = fmaxf(fabsf(piv), delta);
+    Hf[p][p] = piv;
+    const float inv = 1.0f / piv;
     for (int j = p + 1; j < nv; ++j) {
-      const double fac = H[j][p] * inv;
-      for (int q = p + 1; q < nv; ++q) H[j][q] -= fac * H[p][q];
-      rhs[j] -= fac * rhs[p];
+      const float fac = Hf[j][p] * inv;
+      for (int q = p + 1; q < nv; ++q) Hf[j][q] -= fac * Hf[p][q];
+      rf[j] -= fac * rf[p];
     }
   }
   for (int p = nv - 1; p >= 0; --p) {
-    double acc = rhs[p];
-    for (int q = p + 1; q < nv; ++q) acc -= H[p][q] * d[q];
-    d[p] = acc / H[p][p];
+    float acc = rf[p];
+    for (int q = p + 1; q < nv; ++q) acc -= Hf[p][q] * df[q];
+    df[p] = acc * (1.0f / Hf[p][p]);
+    d[p] = (double)df[p];
   }
 }
 
