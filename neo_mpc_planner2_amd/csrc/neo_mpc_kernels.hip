@@ -565,7 +565,8 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   for (it = 0; it < p.max_it; ++it) {
     // ---- adjoint gradient of the tracking + terminal cost
     constexpr int kVars = 3 * kRegSteps;
-    double hcol[kVars];  // Newton: column `lane` of the Hessian, then row `lane`
+    double hcol[kVars];  // Newton: gradient of this lane's perturbed copy
+    float hc[kVars];     // Newton: column `lane` of the Hessian, then row `lane` (float32, see below)
     if (kNewton) {
       // Every lane runs the rollout + adjoint sweep on its own copy of u: lane k < 3N perturbs
       // coordinate k by h, the other lanes leave u alone.  One pass therefore yields the gradient
@@ -607,7 +608,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       for (int j = 0; j < kVars; ++j) {
         const double base = lane_value(hcol[j], 63);
         if (lane == 63) gs[j] = base;
-        hcol[j] = (hcol[j] - base) * inv_h;
+        hc[j] = (float)((hcol[j] - base) * inv_h);
       }
       WAVE_SYNC();
     } else if (!kSteps) {
@@ -747,92 +748,93 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       if (lane < kVars) d[lane] = -gr[lane];
       WAVE_SYNC();
     } else if (kNewton) {
-      double* Hm = L + a.lds.hess;
+      // From here on the Newton system lives in float32: it only yields a search direction (the arc
+      // search and the float64 objective decide), and single precision halves registers, readlanes
+      // and VALU time of this section.
+      float* Hm = reinterpret_cast<float*>(L + a.lds.hess);
       // ---- lane k < 3N holds Hessian column k: add the control norm's Hessian and the disc
       //      curvature on its diagonal block, apply P on the row index, store the column
 #pragma unroll
       for (int bk = 0; bk < kRegSteps; ++bk) {
         const bool near_b = AMODE[4 * bk + 2] != 0;
-        const double e0 = u[3 * bk] - c.v0, e1 = u[3 * bk + 1] - c.v1, e2 = u[3 * bk + 2] - c.v2;
-        const double ne = sqrt(e0 * e0 + e1 * e1 + e2 * e2);
+        const float e0 = (float)(u[3 * bk] - c.v0), e1 = (float)(u[3 * bk + 1] - c.v1), e2 = (float)(u[3 * bk + 2] - c.v2);
+        const float ne = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
         const int q = lane - 3 * bk;  // column inside block bk
         if (q >= 0 && q < 3 && !near_b) {
-          if (ne > 0.0) {  // (w/|e|)(I - e e^T / |e|^2)
-            const double ine = rcp_fast(ne);
-            const double sN = p.wc_n * ine, h0 = e0 * ine, h1 = e1 * ine, h2 = e2 * ine;
-            const double hq = q == 0 ? h0 : q == 1 ? h1 : h2;
-            hcol[3 * bk] += sN * ((q == 0 ? 1.0 : 0.0) - h0 * hq);
-            hcol[3 * bk + 1] += sN * ((q == 1 ? 1.0 : 0.0) - h1 * hq);
-            hcol[3 * bk + 2] += sN * ((q == 2 ? 1.0 : 0.0) - h2 * hq);
+          if (ne > 0.0f) {  // (w/|e|)(I - e e^T / |e|^2)
+            const float ine = __builtin_amdgcn_rcpf(ne);
+            const float sN = (float)p.wc_n * ine, h0 = e0 * ine, h1 = e1 * ine, h2 = e2 * ine;
+            const float hq = q == 0 ? h0 : q == 1 ? h1 : h2;
+            hc[3 * bk] += sN * ((q == 0 ? 1.0f : 0.0f) - h0 * hq);
+            hc[3 * bk + 1] += sN * ((q == 1 ? 1.0f : 0.0f) - h1 * hq);
+            hc[3 * bk + 2] += sN * ((q == 2 ? 1.0f : 0.0f) - h2 * hq);
           }
-          const double k2 = ART[bk];
-          if (k2 != 0.0 && q < 2) {  // tangent (-ny, nx)
-            const double tx = -ANY[bk], ty = ANX[bk], tq = q == 0 ? tx : ty;
-            hcol[3 * bk] += k2 * tx * tq;
-            hcol[3 * bk + 1] += k2 * ty * tq;
+          const float k2 = (float)ART[bk];
+          if (k2 != 0.0f && q < 2) {  // tangent (-ny, nx)
+            const float tx = -(float)ANY[bk], ty = (float)ANX[bk], tq = q == 0 ? tx : ty;
+            hc[3 * bk] += k2 * tx * tq;
+            hc[3 * bk + 1] += k2 * ty * tq;
           }
         }
-        const double P00 = near_b ? 0.0 : ADX[bk], P01 = near_b ? 0.0 : ADY[bk], P11 = near_b ? 0.0 : ARX[bk],
-                     PW = near_b ? 0.0 : ARY[bk];
-        const double hx = hcol[3 * bk], hy = hcol[3 * bk + 1];
-        hcol[3 * bk] = P00 * hx + P01 * hy;
-        hcol[3 * bk + 1] = P01 * hx + P11 * hy;
-        hcol[3 * bk + 2] *= PW;
+        const float P00 = near_b ? 0.0f : (float)ADX[bk], P01 = near_b ? 0.0f : (float)ADY[bk],
+                    P11 = near_b ? 0.0f : (float)ARX[bk], PW = near_b ? 0.0f : (float)ARY[bk];
+        const float hx = hc[3 * bk], hy = hc[3 * bk + 1];
+        hc[3 * bk] = P00 * hx + P01 * hy;
+        hc[3 * bk + 1] = P01 * hx + P11 * hy;
+        hc[3 * bk + 2] *= PW;
       }
       if (lane < kVars) {
 #pragma unroll
-        for (int j = 0; j < kVars; ++j) Hm[j * kVars + lane] = hcol[j];
+        for (int j = 0; j < kVars; ++j) Hm[j * kVars + lane] = hc[j];
       }
       WAVE_SYNC();
       // ---- lane j < 3N holds row j: apply P on the column index, add I - P, eliminate
-      double rhs = 0.0, diag = 0.0;
+      float rhsf = 0.0f, diag = 0.0f;
       if (lane < kVars) {
 #pragma unroll
-        for (int q = 0; q < kVars; ++q) hcol[q] = Hm[lane * kVars + q];
-        rhs = -gr[lane];
+        for (int q = 0; q < kVars; ++q) hc[q] = Hm[lane * kVars + q];
+        rhsf = -(float)gr[lane];
       } else {
 #pragma unroll
-        for (int q = 0; q < kVars; ++q) hcol[q] = 0.0;
+        for (int q = 0; q < kVars; ++q) hc[q] = 0.0f;
       }
 #pragma unroll
       for (int bk = 0; bk < kRegSteps; ++bk) {
         const bool near_b = AMODE[4 * bk + 2] != 0;
-        const double P00 = near_b ? 0.0 : ADX[bk], P01 = near_b ? 0.0 : ADY[bk], P11 = near_b ? 0.0 : ARX[bk],
-                     PW = near_b ? 0.0 : ARY[bk];
-        const double hx = hcol[3 * bk], hy = hcol[3 * bk + 1];
-        hcol[3 * bk] = hx * P00 + hy * P01;
-        hcol[3 * bk + 1] = hx * P01 + hy * P11;
-        hcol[3 * bk + 2] *= PW;
+        const float P00 = near_b ? 0.0f : (float)ADX[bk], P01 = near_b ? 0.0f : (float)ADY[bk],
+                    P11 = near_b ? 0.0f : (float)ARX[bk], PW = near_b ? 0.0f : (float)ARY[bk];
+        const float hx = hc[3 * bk], hy = hc[3 * bk + 1];
+        hc[3 * bk] = hx * P00 + hy * P01;
+        hc[3 * bk + 1] = hx * P01 + hy * P11;
+        hc[3 * bk + 2] *= PW;
         const int r = lane - 3 * bk;  // + (I - P) on the diagonal block
-        if (r == 0) { hcol[3 * bk] += 1.0 - P00; hcol[3 * bk + 1] -= P01; diag = hcol[3 * bk]; }
-        if (r == 1) { hcol[3 * bk] -= P01; hcol[3 * bk + 1] += 1.0 - P11; diag = hcol[3 * bk + 1]; }
-        if (r == 2) { hcol[3 * bk + 2] += 1.0 - PW; diag = hcol[3 * bk + 2]; }
+        if (r == 0) { hc[3 * bk] += 1.0f - P00; hc[3 * bk + 1] -= P01; diag = hc[3 * bk]; }
+        if (r == 1) { hc[3 * bk] -= P01; hc[3 * bk + 1] += 1.0f - P11; diag = hc[3 * bk + 1]; }
+        if (r == 2) { hc[3 * bk + 2] += 1.0f - PW; diag = hc[3 * bk + 2]; }
       }
-      // the reduced system is solved in float32: it only yields a search direction (the arc search
-      // and the f64 objective decide), and single precision halves the readlanes and the VALU time
-      const float deltaf = fmaxf(1e-6f * (float)wave_max(fabs(diag)), 1e-30f);
-      float hr[kVars], rhsf = (float)rhs, pinvf[kVars];
+      const float deltaf = fmaxf(1e-6f * (float)wave_max((double)fabsf(diag)), 1e-30f);
+      float pinvf[kVars];
+      auto lane_f = [](float v, int src) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+      };
 #pragma unroll
-      for (int q = 0; q < kVars; ++q) hr[q] = (float)hcol[q];
-#pragma unroll
-      for (int pv = 0; pv < kVars; ++pv) {
-        float piv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hr[pv]), pv));
+      for (int pv = 0; pv < kVars; ++pv) {  // Gaussian elimination, rows in registers, pivot row by readlane
+        float piv = lane_f(hc[pv], pv);
         if (!(piv > deltaf)) piv = fmaxf(fabsf(piv), deltaf);
         pinvf[pv] = __builtin_amdgcn_rcpf(piv);
-        const float fac = (lane > pv && lane < kVars) ? hr[pv] * pinvf[pv] : 0.0f;
+        const float fac = (lane > pv && lane < kVars) ? hc[pv] * pinvf[pv] : 0.0f;
 #pragma unroll
-        for (int q = pv + 1; q < kVars; ++q)
-          hr[q] -= fac * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hr[q]), pv));
-        rhsf -= fac * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rhsf), pv));
+        for (int q = pv + 1; q < kVars; ++q) hc[q] -= fac * lane_f(hc[q], pv);
+        rhsf -= fac * lane_f(rhsf, pv);
       }
       double dsol[kVars];
       float dsf[kVars];
 #pragma unroll
-      for (int pv = kVars - 1; pv >= 0; --pv) {
+      for (int pv = kVars - 1; pv >= 0; --pv) {  // back substitution; every lane ends with the whole d
         float acc = rhsf;
 #pragma unroll
-        for (int q = pv + 1; q < kVars; ++q) acc -= hr[q] * dsf[q];
-        dsf[pv] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc * pinvf[pv]), pv));
+        for (int q = pv + 1; q < kVars; ++q) acc -= hc[q] * dsf[q];
+        dsf[pv] = lane_f(acc * pinvf[pv], pv);
         dsol[pv] = (double)dsf[pv];
       }
       if (lane == 0) {
