@@ -1166,23 +1166,25 @@ __global__ __launch_bounds__(kLanes) void k_carrot(const CarrotArgs a) {
 
 }  // namespace
 
-// Register budget of K1: __launch_bounds__(64, 3) by default -- the kernels sit just under the
-// 168-VGPR step (Newton 166, generic 143), and pinning 3 waves/SIMD keeps a later edit from silently
-// falling to 2.  NEO_MPC_SOLVE_WAVES=2|3|4 selects the variant for A/B measurements (4 spills).
-static int solve_variant() {
-  static int v = 0;
-  if (v == 0) {
+// Register budget of K1 (measured on the same box): the Newton kernel is fastest pinned to
+// 4 waves/SIMD (128 VGPRs, 88 B of scratch; +5.5 % over its spill-free 160-VGPR form at 3), the
+// L-BFGS / generic kernels at 3 waves/SIMD (141-143 VGPRs, spill-free).  Pinning the occupancy
+// with __launch_bounds__ also keeps a later edit from silently dropping a wave per SIMD.
+// NEO_MPC_SOLVE_WAVES=2|3|4 overrides both defaults for A/B measurements.
+static int solve_variant(int fallback) {
+  static int v = -1;
+  if (v < 0) {
     const char* e = getenv("NEO_MPC_SOLVE_WAVES");
-    v = (e && atoi(e) == 4) ? 4 : (e && atoi(e) == 2) ? 2 : 3;
+    v = (e && atoi(e) >= 2 && atoi(e) <= 4) ? atoi(e) : 0;
   }
-  return v;
+  return v ? v : fallback;
 }
 
 void launch_solve(const SolveArgs& a, void* stream) {
   if (a.count == 0) return;
   const dim3 grid(a.count), block(kLanes);
   hipStream_t st = (hipStream_t)stream;
-  const int w = solve_variant();
+  const int w = solve_variant((a.p.n == 3 && a.p.newton) ? 4 : 3);
   const bool generic = getenv("NEO_MPC_GENERIC_STEPS") != nullptr || a.p.mem != 4;  // A/B: LDS-only path
   const size_t lds = a.lds.total_bytes;
   if (a.p.n == 3 && a.p.newton) {  // projected Newton (its layout does not depend on lbfgs_memory)
