@@ -85,6 +85,10 @@ typedef struct neo_mpc_params {
   double stall_step;      /* <=0: 0.3 * opt_tolerance */
   int32_t method;         /* NEO_MPC_METHOD_*: search direction of lanes 32-63 */
   int32_t reserved_i;
+  double window_tolerance; /* the search also ends when three iterations in a row lower the objective by
+                              less than window_tolerance * max(1, |f|) together (SLSQP ends on ONE
+                              iteration gaining less than opt_tolerance); 0: 3e-3 * opt_tolerance with
+                              Newton, off with L-BFGS (whose normal progress is that slow); <0: off */
 } neo_mpc_params;
 
 /* One Optimizer.srv request (cpp:240-246).  256 bytes. */

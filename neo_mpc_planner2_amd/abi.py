@@ -91,7 +91,8 @@ class NeoMpcParams(_C.Structure):
         ("lbfgs_memory", _C.c_int32), ("compat_flags", _C.c_int32),
         ("step_tolerance", _C.c_double), ("cost_tolerance", _C.c_double),
         ("kink_radius", _C.c_double), ("stall_step", _C.c_double),
-        ("method", _C.c_int32), ("reserved_i", _C.c_int32)]
+        ("method", _C.c_int32), ("reserved_i", _C.c_int32),
+        ("window_tolerance", _C.c_double)]
 
 
 ROS_PARAM_NAMES = tuple(n for n, _ in NeoMpcParams._fields_[:22])
@@ -130,7 +131,8 @@ def params_struct(params=None, **over):
         w_footprint=2000.0, waiting_time=3.0, low_pass_gain=0.5, opt_tolerance=1e-5,
         prediction_horizon=0.5, control_steps=3,
         max_iterations=100, lbfgs_memory=4, compat_flags=COMPAT_ODOM_YAW_GOAL_W,
-        step_tolerance=0.0, cost_tolerance=0.0, kink_radius=0.0, stall_step=0.0, method=0, reserved_i=0)
+        step_tolerance=0.0, cost_tolerance=0.0, kink_radius=0.0, stall_step=0.0, method=0, reserved_i=0,
+        window_tolerance=0.0)
     if params:
         d.update(params)
     d.update(over)

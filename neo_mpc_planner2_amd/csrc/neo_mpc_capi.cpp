@@ -134,6 +134,8 @@ void derive(neo_mpc_handle* h) {
   d.newton = ((p.method == NEO_MPC_METHOD_NEWTON || p.method == NEO_MPC_METHOD_AUTO) && n == 3) ? 1 : 0;
   d.early_tol = getenv("NEO_MPC_NO_EARLY") ? 0.0 : d.xtol;
   d.ftol = p.cost_tolerance > 0.0 ? p.cost_tolerance : (d.newton ? 3e-4 : 3e-6) * p.opt_tolerance;
+  d.wtol = p.window_tolerance > 0.0 ? p.window_tolerance
+           : (p.window_tolerance == 0.0 && d.newton) ? 3e-3 * p.opt_tolerance : 0.0;
 
   // LDS carve-up (shared with the kernel specialisations) + reach tile geometry
   LdsLayout& l = h->lds;
@@ -305,6 +307,7 @@ int neo_mpc_default_params(neo_mpc_params* p) {
   p->cost_tolerance = 0.0;
   p->kink_radius = 0.0;
   p->stall_step = 0.0;
+  p->window_tolerance = 0.0;
   p->method = NEO_MPC_METHOD_AUTO;
   return NEO_MPC_OK;
 }

@@ -27,6 +27,7 @@ struct DevParams {
   double early_tol;          // Newton: stop when the full step is below this (= xtol; 0 disables, A/B)
   double ftol;               // relative cost decrease below which an iteration counts as stalled
   double stall_step;         // ... or max|du| below this
+  double wtol;               // three iterations in a row gaining less than this (relative) end the search; 0: off
   double kink_radius;        // |u_i - v_cur| below which a block is handled by the prox step only
   int32_t n;                 // control_steps
   int32_t max_it;

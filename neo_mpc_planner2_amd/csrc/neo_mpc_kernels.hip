@@ -562,7 +562,14 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   for (int i = lane; i < n; i += kLanes) { AMODE[4 * i + 2] = 0; AMODE[4 * i + 3] = 0; }
   double alpha = 1.0;
   int npairs = 0, head = 0, nfev = 1, it = 0, status = NEO_MPC_STATUS_MAX_ITER, stall = 0;
+  double gain1 = INFINITY, gain2 = INFINITY;  // objective decrease of the previous two iterations
+  const int lane_id = lane;
   for (it = 0; it < p.max_it; ++it) {
+    // The lane index is re-read opaquely every iteration: otherwise the compiler hoists two dozen
+    // lane-derived constants (step multipliers, compare masks, LDS addresses) out of the loop and,
+    // at 4 waves/SIMD, parks them in scratch -- recomputing them costs a few integer operations.
+    int lane = lane_id;
+    asm volatile("" : "+v"(lane));
     // ---- adjoint gradient of the tracking + terminal cost
     constexpr int kVars = 3 * kRegSteps;
     double hcol[kVars];  // Newton: gradient of this lane's perturbed copy
@@ -987,14 +994,18 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       u_prev[k] = ou; gt_prev[k] = gt[k]; u[k] = nu;
     }
     stepmax = wave_max(stepmax);
-    stall = (f - fb <= p.ftol * fmax(1.0, fabs(fb)) || stepmax <= p.stall_step) ? stall + 1 : 0;
+    const double gain = f - fb;
+    stall = (gain <= p.ftol * fmax(1.0, fabs(fb)) || stepmax <= p.stall_step) ? stall + 1 : 0;
+    // three iterations that together gained less than wtol: creeping along a costmap cell edge
+    const bool creeping = p.wtol > 0.0 && gain + gain1 + gain2 <= p.wtol * fmax(1.0, fabs(fb));
+    gain2 = gain1; gain1 = gain;
     f = fb;
     if (best < 32) {
       alpha = lane_value(step, best);
       alpha = clampd(alpha, 1e-6, 1e6);
     }
     WAVE_SYNC();
-    if (stepmax < p.xtol || stall >= kStallIterations) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
+    if (stepmax < p.xtol || stall >= kStallIterations || creeping) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
   }
 
   if (a.solution)
@@ -1166,11 +1177,11 @@ __global__ __launch_bounds__(kLanes) void k_carrot(const CarrotArgs a) {
 
 }  // namespace
 
-// Register budget of K1 (measured on the same box): the Newton kernel is fastest pinned to
-// 4 waves/SIMD (128 VGPRs, 88 B of scratch; +5.5 % over its spill-free 160-VGPR form at 3), the
-// L-BFGS / generic kernels at 3 waves/SIMD (141-143 VGPRs, spill-free).  Pinning the occupancy
-// with __launch_bounds__ also keeps a later edit from silently dropping a wave per SIMD.
-// NEO_MPC_SOLVE_WAVES=2|3|4 overrides both defaults for A/B measurements.
+// Register budget of K1: with the per-iteration opaque lane index (see the top of the solver loop)
+// the Newton kernel needs 124 VGPRs and the generic kernel 118, both spill-free at 4 waves/SIMD; the
+// control_steps == 3 L-BFGS kernel needs 130 (3 waves/SIMD).  __launch_bounds__ pins the occupancy
+// each was measured at, so that a later edit cannot silently drop a wave per SIMD (it would spill
+// instead, which `make resource-usage` shows).  NEO_MPC_SOLVE_WAVES=2|3|4 overrides, for A/B runs.
 static int solve_variant(int fallback) {
   static int v = -1;
   if (v < 0) {
@@ -1184,7 +1195,7 @@ void launch_solve(const SolveArgs& a, void* stream) {
   if (a.count == 0) return;
   const dim3 grid(a.count), block(kLanes);
   hipStream_t st = (hipStream_t)stream;
-  const int w = solve_variant((a.p.n == 3 && a.p.newton) ? 4 : 3);
+  const int w = solve_variant((a.p.n == 3 && !a.p.newton) ? 3 : 4);
   const bool generic = getenv("NEO_MPC_GENERIC_STEPS") != nullptr || a.p.mem != 4;  // A/B: LDS-only path
   const size_t lds = a.lds.total_bytes;
   if (a.p.n == 3 && a.p.newton) {  // projected Newton (its layout does not depend on lbfgs_memory)

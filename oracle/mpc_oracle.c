@@ -600,6 +600,10 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
   for (int k = 0; k < nv; ++k) cold = cold && (u[k] == 0.0);
   double alpha = 1.0;
   int nfev = 1, it = 0, status = NEO_MPC_STATUS_MAX_ITER, stall = 0;
+  /* three iterations in a row that together gain less than wtol end the search (Newton only by default) */
+  const double wtol = p->window_tolerance > 0.0 ? p->window_tolerance
+                      : (p->window_tolerance == 0.0 && newton) ? 3e-3 * p->opt_tolerance : 0.0;
+  double gain1 = INFINITY, gain2 = INFINITY;
   for (it = 0; it < max_it; ++it) {
     orc_grad_smooth(&c, u, gs);
     orc_reduce(&c, u, gs, gt, gr, &act);
@@ -702,7 +706,9 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
      * slow tail next to the control-norm kink) end the search once ORC_STALL_ITERATIONS of them
      * are in a row */
     stall = (decrease <= ftol * fmax(1.0, fabs(fb)) || step <= stall_step) ? stall + 1 : 0;
-    if (step < xtol || stall >= ORC_STALL_ITERATIONS) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
+    const int creeping = wtol > 0.0 && decrease + gain1 + gain2 <= wtol * fmax(1.0, fabs(fb));
+    gain2 = gain1; gain1 = decrease;
+    if (step < xtol || stall >= ORC_STALL_ITERATIONS || creeping) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
   }
   memcpy(x_out, u, sizeof(double) * nv);
   *f_out = f;

@@ -42,7 +42,7 @@ int main(void) {
   printf("sizeof.params %zu\nsizeof.problem %zu\nsizeof.state %zu\nsizeof.command %zu\nsizeof.batch %zu\n",
          sizeof(neo_mpc_params), sizeof(neo_mpc_problem), sizeof(neo_mpc_state), sizeof(neo_mpc_command),
          sizeof(neo_mpc_batch));
-  P(neo_mpc_params, control_steps); P(neo_mpc_params, step_tolerance); P(neo_mpc_params, kink_radius); P(neo_mpc_params, stall_step); P(neo_mpc_params, method);
+  P(neo_mpc_params, control_steps); P(neo_mpc_params, step_tolerance); P(neo_mpc_params, kink_radius); P(neo_mpc_params, stall_step); P(neo_mpc_params, method); P(neo_mpc_params, window_tolerance);
   P(neo_mpc_problem, carrot_xy); P(neo_mpc_problem, goal_xyz); P(neo_mpc_problem, cur_vel);
   P(neo_mpc_problem, control_interval); P(neo_mpc_problem, footprint_cost);
   P(neo_mpc_state, old_goal); P(neo_mpc_state, waiting_time); P(neo_mpc_state, has_old_goal);
@@ -60,7 +60,7 @@ int main(void) {
     assert got["sizeof.state"] == abi.STATE_DTYPE.itemsize == 128
     assert got["sizeof.command"] == abi.COMMAND_DTYPE.itemsize == 48
     assert got["sizeof.batch"] == C.sizeof(abi.NeoMpcBatch)
-    for f in ("control_steps", "step_tolerance", "kink_radius", "stall_step", "method"):
+    for f in ("control_steps", "step_tolerance", "kink_radius", "stall_step", "method", "window_tolerance"):
         assert got["neo_mpc_params." + f] == getattr(abi.NeoMpcParams, f).offset
     for f in ("carrot_xy", "goal_xyz", "cur_vel", "control_interval", "footprint_cost"):
         assert got["neo_mpc_problem." + f] == abi.PROBLEM_DTYPE.fields[f][1]

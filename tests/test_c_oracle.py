@@ -130,3 +130,28 @@ def test_projection_box_cuts_disc():
         r = orc.solve_slsqp(util.oracle_problem(probs[j]), params, cm, np.zeros(9), ftol=1e-12, maxiter=500)
         assert cmds["cost"][j] <= r.fun + 1e-8
         assert np.abs(x[j, :3] - r.x[:3]).max() <= 1e-3
+
+
+def test_window_tolerance_only_shortens_creeping_searches():
+    """The windowed stop (three iterations gaining < 3e-3 * opt_tolerance together, Newton only by
+    default) never lengthens a search, keeps the objective within 1e-4 of the run without it and
+    leaves the zero-costmap (unique minimiser) solutions untouched."""
+    cmap = synthetic.make_costmap(500, seed=41)
+    probs = synthetic.make_problems(1024, 500, seed=42)
+    res = {}
+    for wt in (-1.0, 0.0):
+        res[wt] = _cold_solve(orc.make_params(window_tolerance=wt), cmap, probs)[0]
+    off, on = res[-1.0], res[0.0]
+    assert (on["iterations"] <= off["iterations"]).all()
+    assert on["iterations"].max() < off["iterations"].max()
+    assert (on["cost"] <= off["cost"] + 1e-4).all()
+    zero = (np.zeros_like(cmap[0]),) + tuple(cmap[1:])
+    z_off = _cold_solve(orc.make_params(window_tolerance=-1.0), zero, probs[:256])[1]
+    z_on = _cold_solve(orc.make_params(window_tolerance=0.0), zero, probs[:256])[1]
+    assert np.abs(z_on[:, :3] - z_off[:, :3]).max() <= 2e-4    # the command (first control)
+    assert np.abs(z_on - z_off).max() <= 1e-3
+    # L-BFGS (any other control_steps): off by default
+    p8 = orc.make_params(control_steps=8)
+    a = _cold_solve(p8, cmap, probs[:128])[0]
+    b = _cold_solve(orc.make_params(control_steps=8, window_tolerance=-1.0), cmap, probs[:128])[0]
+    assert (a["iterations"] == b["iterations"]).all()

@@ -229,3 +229,31 @@ def test_newton_is_refused_for_other_control_steps():
     with pytest.raises(_lib.NeoMpcError) as e:
         BatchSolver(util.orc.make_params(control_steps=5, method=2))
     assert e.value.code == -1 or "control_steps == 3" in str(e.value)
+
+
+def test_window_tolerance_trims_the_creeping_tail_only():
+    """`window_tolerance` (three iterations gaining less than 3e-3 * opt_tolerance together end the
+    search) trims instances that creep along a costmap cell edge: never more iterations, the
+    objective within 1e-4 (<< opt_tolerance, SLSQP's own single-iteration test) of the run without
+    it, the command unchanged on nearly every instance; < 0 switches it off, and both agree with
+    the mirror run with the same setting."""
+    from neo_mpc_planner2_amd.solver import BatchSolver
+    cmap = synthetic.make_costmap(500, seed=41)
+    probs = synthetic.make_problems(2048, 500, seed=42)
+    out = {}
+    for wt in (-1.0, 0.0):
+        params = util.orc.make_params(window_tolerance=wt)
+        st, warm = synthetic.make_states(probs, 3)
+        st_c, warm_c = st.copy(), warm.copy()
+        with BatchSolver(params) as s:
+            s.set_costmap(*cmap)
+            cg, xg = s.solve(probs, st, warm)
+        cc, xc, _ = _mirror(params, cmap, probs, st_c, warm_c)
+        _close(cg, cc, frac=0.97)
+        assert abs(cg["iterations"].mean() - cc["iterations"].mean()) < 0.15
+        out[wt] = cg
+    off, on = out[-1.0], out[0.0]
+    assert (on["iterations"] <= off["iterations"]).mean() >= 0.99
+    assert on["iterations"].max() < off["iterations"].max()
+    assert (on["cost"] <= off["cost"] + 1e-4).all()
+    assert (np.abs(on["vel"] - off["vel"]).max(axis=1) <= 1e-3).mean() >= 0.99

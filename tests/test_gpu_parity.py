@@ -247,10 +247,12 @@ def test_server_mirror_episode_matches_oracle_wrapper():
         rec = srv.request_record(req, delta_t=clock["t"] - last_time)
         last_time = clock["t"]
         cc, xc, path_c = c_oracle.solve_batch(params, cmap, rec, st_c, warm_c, want_path=True)
-        assert np.abs(out - cc["vel"][0]).max() <= 1e-6, k
-        assert np.abs(node.initial_guess - warm_c[0]).max() <= 1e-6
+        # (2e-5: the kernel and the mirror round the float32 Newton system differently and a search
+        # may end ~1e-6 -- the step tolerance -- away from where more iterations would take it)
+        assert np.abs(out - cc["vel"][0]).max() <= 2e-5, k
+        assert np.abs(node.initial_guess - warm_c[0]).max() <= 2e-5
         assert node.collision == bool(st_c["collision"][0])
-        assert np.abs(node.local_plan - path_c[0]).max() <= 1e-6
+        assert np.abs(node.local_plan - path_c[0]).max() <= 2e-5
         assert node.last_result.success == (cc["status"][0] == 0)
         vel = out.copy()
         yaw += vel[2] / 30.0

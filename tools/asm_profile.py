@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Static instruction count of one kernel per top-level source line (inlined code is attributed to
+the call site inside the kernel).  usage: asm_profile.py <kernel-mangled-substring> [lo hi]
+Compiles neo_mpc_kernels.hip with -gline-tables-only -S (device only) and parses the .loc chain."""
+import collections, os, re, subprocess, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "neo_mpc_planner2_amd/csrc/neo_mpc_kernels.hip")
+out = "/tmp/asm_profile.s"
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-pass-failed",
+                "-gline-tables-only", "-x", "hip", "--cuda-device-only", "-S", src, "-o", out],
+               check=True, stderr=subprocess.DEVNULL)
+key = sys.argv[1]
+lo, hi = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (0, 10**9)
+text = open(out).read().split("\n")
+start = next(i for i, l in enumerate(text) if l.startswith("_Z") and key in l and ":" in l)
+end = next(i for i in range(start, len(text)) if ".amdhsa_kernel" in text[i])
+cur = 0
+cnt = collections.defaultdict(collections.Counter)
+for l in text[start:end]:
+    m = re.match(r"\s*\.loc\s+(\d+)\s+(\d+)\s+\d+", l)
+    if m:
+        chain = re.findall(r"neo_mpc_kernels\.hip:(\d+):\d+", l)
+        if chain:
+            cur = int(chain[-1])        # outermost frame = the line inside the kernel
+        elif int(m.group(1)) <= 1:
+            cur = int(m.group(2))       # not inlined: the kernel's own line
+        continue
+    t = l.strip()
+    if not t or t[0] in ".;_" or t.endswith(":"):
+        continue
+    op = t.split()[0]
+    if op.startswith(("v_", "s_", "ds_", "global_", "scratch_", "buffer_")):
+        kind = "v64" if "f64" in op else op.split("_")[0]
+        cnt[cur][kind] += 1
+tot = collections.Counter()
+for k in sorted(cnt):
+    if lo <= k <= hi:
+        print(k, dict(cnt[k]))
+    tot.update(cnt[k])
+print("total", dict(tot))
