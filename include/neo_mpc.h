@@ -75,7 +75,8 @@ typedef struct neo_mpc_params {
   int32_t max_iterations; /* <=0: 100, SciPy SLSQP's maxiter */
   int32_t lbfgs_memory;   /* <=0: 4 */
   int32_t compat_flags;   /* NEO_MPC_COMPAT_*; neo_mpc_default_params sets all (parity mode) */
-  double step_tolerance;  /* stop when max|du| < this; <=0: 1e-3 * opt_tolerance */
+  double step_tolerance;  /* stop when max|du| < this; <=0: 1e-3 * opt_tolerance, and (Newton) a full step
+                             shorter than opt_tolerance -- SLSQP's step test -- is taken as the last one */
   double cost_tolerance;  /* an iteration is "stalled" when it lowers the objective by less than
                              cost_tolerance * max(1, |f|) (<=0: 3e-6 * opt_tolerance with L-BFGS, 3e-4 *
                              opt_tolerance with Newton) or moves less

@@ -133,6 +133,7 @@ void derive(neo_mpc_handle* h) {
                    p.min_vel_y <= -p.max_vel_trans && p.max_vel_y >= p.max_vel_trans) ? 1 : 0;
   d.newton = ((p.method == NEO_MPC_METHOD_NEWTON || p.method == NEO_MPC_METHOD_AUTO) && n == 3) ? 1 : 0;
   d.early_tol = getenv("NEO_MPC_NO_EARLY") ? 0.0 : d.xtol;
+  d.final_tol = getenv("NEO_MPC_NO_EARLY") ? 0.0 : (p.step_tolerance > 0.0 ? p.step_tolerance : p.opt_tolerance);
   d.ftol = p.cost_tolerance > 0.0 ? p.cost_tolerance : (d.newton ? 3e-4 : 3e-6) * p.opt_tolerance;
   d.wtol = p.window_tolerance > 0.0 ? p.window_tolerance
            : (p.window_tolerance == 0.0 && d.newton) ? 3e-3 * p.opt_tolerance : 0.0;

@@ -25,6 +25,7 @@ struct DevParams {
   double low_pass_gain;      // py:367
   double xtol;               // step tolerance
   double early_tol;          // Newton: stop when the full step is below this (= xtol; 0 disables, A/B)
+  double final_tol;          // Newton: a full step below this is the last one (= opt_tolerance)
   double ftol;               // relative cost decrease below which an iteration counts as stalled
   double stall_step;         // ... or max|du| below this
   double wtol;               // three iterations in a row gaining less than this (relative) end the search; 0: off

@@ -563,6 +563,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   double alpha = 1.0;
   int npairs = 0, head = 0, nfev = 1, it = 0, status = NEO_MPC_STATUS_MAX_ITER, stall = 0;
   double gain1 = INFINITY, gain2 = INFINITY;  // objective decrease of the previous two iterations
+  bool final_step = false;
   const int lane_id = lane;
   for (it = 0; it < p.max_it; ++it) {
     // The lane index is re-read opaquely every iteration: otherwise the compiler hoists two dozen
@@ -949,6 +950,9 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       dm = wave_max(dm);
       const bool near_any = __ballot(anynear != 0) != 0ull;
       if (dm < p.early_tol && !near_any) { status = NEO_MPC_STATUS_CONVERGED; break; }
+      // a full Newton step below opt_tolerance (SLSQP's own step test) is the last one: searched
+      // and taken like any other, but nothing re-checks the point it lands on
+      if (dm < p.final_tol && !near_any) final_step = true;
     }
     // ---- 64 candidates, one rollout per lane; lowest objective wins
     const double pstep = alpha * lane_scale(lane);
@@ -1005,7 +1009,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       alpha = clampd(alpha, 1e-6, 1e6);
     }
     WAVE_SYNC();
-    if (stepmax < p.xtol || stall >= kStallIterations || creeping) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
+    if (stepmax < p.xtol || stall >= kStallIterations || creeping || final_step) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
   }
 
   if (a.solution)

@@ -604,6 +604,8 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
   const double wtol = p->window_tolerance > 0.0 ? p->window_tolerance
                       : (p->window_tolerance == 0.0 && newton) ? 3e-3 * p->opt_tolerance : 0.0;
   double gain1 = INFINITY, gain2 = INFINITY;
+  const double final_tol = p->step_tolerance > 0.0 ? p->step_tolerance : p->opt_tolerance;
+  int final = 0;
   for (it = 0; it < max_it; ++it) {
     orc_grad_smooth(&c, u, gs);
     orc_reduce(&c, u, gs, gt, gr, &act);
@@ -621,6 +623,10 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
         for (int k = 0; k < nv; ++k) dm = fmax(dm, fabs(d[k]));
         for (int i = 0; i < n; ++i) anynear |= act.near[i];
         if (dm < xtol && !anynear) { status = NEO_MPC_STATUS_CONVERGED; break; }
+        /* a full Newton step below opt_tolerance (SLSQP's own step test) is the last one: it is
+         * searched and taken like any other, but nothing re-checks the point it lands on (the
+         * error left is of the order of the step squared) */
+        if (dm < final_tol && !anynear) final = 1;
       }
     }
     if (!newton && it > 0) {
@@ -708,7 +714,7 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
     stall = (decrease <= ftol * fmax(1.0, fabs(fb)) || step <= stall_step) ? stall + 1 : 0;
     const int creeping = wtol > 0.0 && decrease + gain1 + gain2 <= wtol * fmax(1.0, fabs(fb));
     gain2 = gain1; gain1 = decrease;
-    if (step < xtol || stall >= ORC_STALL_ITERATIONS || creeping) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
+    if (step < xtol || stall >= ORC_STALL_ITERATIONS || creeping || final) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
   }
   memcpy(x_out, u, sizeof(double) * nv);
   *f_out = f;
