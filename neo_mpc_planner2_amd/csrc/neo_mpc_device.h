@@ -49,7 +49,7 @@ struct DevMap {
 
 // LDS carve-up of the solve kernel, in doubles from the start of dynamic LDS.
 struct LdsLayout {
-  int32_t prob, state, term, u, gs, gt, gr, d, u_prev, gt_prev, u_new, S, Y, rho;
+  int32_t prob, state, tol, term, u, gs, gt, gr, d, u_prev, gt_prev, u_new, S, Y, rho;
   int32_t cs, sn, dxs, dys, rx, ry, rt, nx, ny, mode;  // per-step scratch
   int32_t hess;        // Newton: (3N)^2 Hessian, only when 3N <= 24
   int32_t tile;        // byte tile starts here (double index)
@@ -68,6 +68,7 @@ constexpr LdsLayout make_lds_layout(int n, int mem) {
   int off = 0;
   l.prob = off; off += 32;
   l.state = off; off += 16;
+  l.tol = off; off += 8;    // stop tolerances (read once per iteration; kept out of the scalar registers)
   l.term = off; off += 256;
   l.u = off; off += nv;
   l.gs = off; off += nv;

@@ -237,10 +237,12 @@ __device__ double footprint_cost(const SolveArgs& a, const double* L, uint32_t b
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // Euclidean projection of (vx, vy) onto box ∩ disc; omega clamped (py:125-134, 157-158)
+// kDisc: the caller knows at compile time that the disc lies inside the vx/vy box
+template <bool kDisc = false>
 __device__ __forceinline__ void project_block(const DevParams& p, double& b0, double& b1, double& b2) {
   b2 = clampd(b2, p.lo[2], p.hi[2]);
   const double zx = b0, zy = b1, r = p.r;
-  if (p.disc_in_box) {  // README parameters: the box never binds, the projection is radial
+  if (kDisc || p.disc_in_box) {  // README parameters: the box never binds, the projection is radial
     const double n2 = zx * zx + zy * zy;
     if (n2 > r * r) { const double sc = r * rsq_fast(n2); b0 = zx * sc; b1 = zy * sc; }
     return;
@@ -281,6 +283,7 @@ __device__ __forceinline__ double lane_scale(int lane) {
 // control block i of this lane's candidate
 // (`step`: this lane's step along its own family; `pstep`: its proximal-gradient step length, used
 // by the L-BFGS lanes for blocks sitting next to the control-norm kink)
+template <bool kDisc = false>
 __device__ __forceinline__ void candidate_block(const SolveArgs& a, const Ctx& c, const double* L, int lane,
                                                 double step, double pstep, int i, double& b0, double& b1,
                                                 double& b2) {
@@ -298,7 +301,7 @@ __device__ __forceinline__ void candidate_block(const SolveArgs& a, const Ctx& c
     const double* d = L + a.lds.d + 3 * i;
     b0 = u[0] + step * d[0]; b1 = u[1] + step * d[1]; b2 = u[2] + step * d[2];
   }
-  project_block(a.p, b0, b1, b2);
+  project_block<kDisc>(a.p, b0, b1, b2);
 }
 
 // rollout + cost of one control sequence (py:224-268); Block(i, b0, b1, b2) yields the controls
@@ -491,7 +494,9 @@ __device__ void load_records(const SolveArgs& a, double* L, uint32_t b, int lane
 // kSteps > 0: specialisation for control_steps == kSteps -- every lane keeps its candidate's controls
 // and sin/cos in registers, so the winner is stored without being recomputed and the next adjoint
 // sweep needs no trigonometry.  kSteps == 0: any control_steps (LDS-only path).
-template <int kMinWavesPerSimd, int kSteps, bool kNewton = false>
+// kDisc: instantiation for parameter sets whose max_vel_trans disc lies inside the vx/vy box (the
+// README's): the box/disc corner cases of the projection and of the tangent cone drop out.
+template <int kMinWavesPerSimd, int kSteps, bool kNewton = false, bool kDisc = false>
 __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveArgs args) {
   static_assert(!kNewton || kSteps > 0, "the Newton path needs a compile-time control_steps");
   extern __shared__ __align__(16) double L[];
@@ -527,6 +532,15 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   c.true_yaw = lane_value(c.true_yaw, 0);
   c.tile_x0 = uniform_int(c.tile_x0); c.tile_y0 = uniform_int(c.tile_y0);
 
+  // The stop tolerances are read once per iteration: from LDS, so that they do not sit in (and get
+  // spilled from) scalar registers all through the loop.
+  enum { T_XTOL, T_EARLY, T_FINAL, T_FTOL, T_STALL, T_WTOL, T_KINK };
+  if (lane == 0) {
+    double* t = L + a.lds.tol;
+    t[T_XTOL] = p.xtol; t[T_EARLY] = p.early_tol; t[T_FINAL] = p.final_tol; t[T_FTOL] = p.ftol;
+    t[T_STALL] = p.stall_step; t[T_WTOL] = p.wtol; t[T_KINK] = p.kink_radius;
+  }
+  const volatile double* TOL = L + a.lds.tol;
   double* u = L + a.lds.u;
   double* gs = L + a.lds.gs;
   double* gt = L + a.lds.gt;
@@ -550,7 +564,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   int* AMODE = reinterpret_cast<int*>(L + a.lds.mode);  // [4n]: mode, wfroz, near, near_prev
 
   // x0 clipped to the feasible set (SciPy clips x0 to the bounds, _slsqp_py.py:268)
-  for (int i = lane; i < n; i += kLanes) project_block(p, u[3 * i], u[3 * i + 1], u[3 * i + 2]);
+  for (int i = lane; i < n; i += kLanes) project_block<kDisc>(p, u[3 * i], u[3 * i + 1], u[3 * i + 2]);
   WAVE_SYNC();
   double f = rollout_cost<kSteps>(a, c, L, [&](int i, double& b0, double& b1, double& b2) {
     b0 = u[3 * i]; b1 = u[3 * i + 1]; b2 = u[3 * i + 2];
@@ -694,7 +708,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         t0 = g0 * sh; t1 = g1 * sh; t2 = g2 * sh;
       }
       AMODE[4 * i + 3] = AMODE[4 * i + 2];
-      if (ne < p.kink_radius) {  // next to the kink: prox-only block, outside the quasi-Newton model
+      if (ne < TOL[T_KINK]) {  // next to the kink: prox-only block, outside the quasi-Newton model
         gt[3 * i] = 0.0; gt[3 * i + 1] = 0.0; gt[3 * i + 2] = 0.0;
         gr[3 * i] = 0.0; gr[3 * i + 1] = 0.0; gr[3 * i + 2] = 0.0;
         ANX[i] = 0.0; ANY[i] = 0.0; AMODE[4 * i] = 0; AMODE[4 * i + 1] = 0; AMODE[4 * i + 2] = 1;
@@ -707,7 +721,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       // (fixed slots + validity flags: no dynamically indexed private arrays, i.e. no scratch)
       double nx0 = 0.0, ny0 = 0.0, nx1 = 0.0, ny1 = 0.0, nx2 = 0.0, ny2 = 0.0;
       bool v0 = false, v1 = false, v2 = false;
-      if (!p.disc_in_box) {  // (inside the box a bound can only touch where the disc touches too)
+      if (!kDisc && !p.disc_in_box) {  // (inside the box a bound can only touch where the disc touches too)
         if (u0 <= p.lo[0]) { nx0 = -1.0; v0 = true; }
         else if (u0 >= p.hi[0]) { nx0 = 1.0; v0 = true; }
         if (u1 <= p.lo[1]) { ny1 = -1.0; v1 = true; }
@@ -949,10 +963,10 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       if (lane < kVars) { dm = fabs(d[lane]); anynear = AMODE[4 * (lane / 3) + 2]; }
       dm = wave_max(dm);
       const bool near_any = __ballot(anynear != 0) != 0ull;
-      if (dm < p.early_tol && !near_any) { status = NEO_MPC_STATUS_CONVERGED; break; }
+      if (dm < TOL[T_EARLY] && !near_any) { status = NEO_MPC_STATUS_CONVERGED; break; }
       // a full Newton step below opt_tolerance (SLSQP's own step test) is the last one: searched
       // and taken like any other, but nothing re-checks the point it lands on
-      if (dm < p.final_tol && !near_any) final_step = true;
+      if (dm < TOL[T_FINAL] && !near_any) final_step = true;
     }
     // ---- 64 candidates, one rollout per lane; lowest objective wins
     const double pstep = alpha * lane_scale(lane);
@@ -960,7 +974,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     double fc = rollout_cost<kSteps>(
         a, c, L,
         [&](int i, double& b0, double& b1, double& b2) {
-          candidate_block(a, c, L, lane, step, pstep, i, b0, b1, b2);
+          candidate_block<kDisc>(a, c, L, lane, step, pstep, i, b0, b1, b2);
           if (kSteps) { cand[3 * i] = b0; cand[3 * i + 1] = b1; cand[3 * i + 2] = b2; }
         },
         [&](int i, double sn, double cs) {
@@ -985,7 +999,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       const double bstep = lane_value(step, best), bpstep = lane_value(pstep, best);
       for (int i = lane; i < n; i += kLanes) {
         double b0, b1, b2;
-        candidate_block(a, c, L, best, bstep, bpstep, i, b0, b1, b2);
+        candidate_block<kDisc>(a, c, L, best, bstep, bpstep, i, b0, b1, b2);
         u_new[3 * i] = b0; u_new[3 * i + 1] = b1; u_new[3 * i + 2] = b2;
       }
     }
@@ -999,9 +1013,10 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     }
     stepmax = wave_max(stepmax);
     const double gain = f - fb;
-    stall = (gain <= p.ftol * fmax(1.0, fabs(fb)) || stepmax <= p.stall_step) ? stall + 1 : 0;
+    stall = (gain <= TOL[T_FTOL] * fmax(1.0, fabs(fb)) || stepmax <= TOL[T_STALL]) ? stall + 1 : 0;
     // three iterations that together gained less than wtol: creeping along a costmap cell edge
-    const bool creeping = p.wtol > 0.0 && gain + gain1 + gain2 <= p.wtol * fmax(1.0, fabs(fb));
+    const double wtol = TOL[T_WTOL];
+    const bool creeping = wtol > 0.0 && gain + gain1 + gain2 <= wtol * fmax(1.0, fabs(fb));
     gain2 = gain1; gain1 = gain;
     f = fb;
     if (best < 32) {
@@ -1009,7 +1024,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       alpha = clampd(alpha, 1e-6, 1e6);
     }
     WAVE_SYNC();
-    if (stepmax < p.xtol || stall >= kStallIterations || creeping || final_step) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
+    if (stepmax < TOL[T_XTOL] || stall >= kStallIterations || creeping || final_step) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
   }
 
   if (a.solution)
@@ -1199,23 +1214,24 @@ void launch_solve(const SolveArgs& a, void* stream) {
   if (a.count == 0) return;
   const dim3 grid(a.count), block(kLanes);
   hipStream_t st = (hipStream_t)stream;
-  const int w = solve_variant((a.p.n == 3 && !a.p.newton) ? 3 : 4);
   const bool generic = getenv("NEO_MPC_GENERIC_STEPS") != nullptr || a.p.mem != 4;  // A/B: LDS-only path
+  const bool disc = a.p.disc_in_box != 0 && getenv("NEO_MPC_NO_DISC_SPECIALISATION") == nullptr;
   const size_t lds = a.lds.total_bytes;
+#define NEO_LAUNCH(...) hipLaunchKernelGGL((k_solve<__VA_ARGS__>), grid, block, lds, st, a)
   if (a.p.n == 3 && a.p.newton) {  // projected Newton (its layout does not depend on lbfgs_memory)
-    if (w == 4) hipLaunchKernelGGL((k_solve<4, 3, true>), grid, block, lds, st, a);
-    else if (w == 3) hipLaunchKernelGGL((k_solve<3, 3, true>), grid, block, lds, st, a);
-    else hipLaunchKernelGGL((k_solve<2, 3, true>), grid, block, lds, st, a);
+    const int w = solve_variant(disc ? 4 : 3);
+    if (disc) { if (w == 4) NEO_LAUNCH(4, 3, true, true); else if (w == 3) NEO_LAUNCH(3, 3, true, true); else NEO_LAUNCH(2, 3, true, true); }
+    else { if (w == 4) NEO_LAUNCH(4, 3, true); else if (w == 3) NEO_LAUNCH(3, 3, true); else NEO_LAUNCH(2, 3, true); }
   } else if (a.p.n == 3 && !generic) {
-    if (w == 4) hipLaunchKernelGGL((k_solve<4, 3>), grid, block, lds, st, a);
-    else if (w == 3) hipLaunchKernelGGL((k_solve<3, 3>), grid, block, lds, st, a);
-    else hipLaunchKernelGGL((k_solve<2, 3>), grid, block, lds, st, a);
+    const int w = solve_variant(3);
+    if (w == 4) NEO_LAUNCH(4, 3); else if (w == 3) NEO_LAUNCH(3, 3); else NEO_LAUNCH(2, 3);
   } else {  // any other control_steps (measured: at N = 8 the scan-based generic path beats a register
             // specialisation, 8.5 vs 10.1 ms per 65 536 instances)
-    if (w == 4) hipLaunchKernelGGL((k_solve<4, 0>), grid, block, lds, st, a);
-    else if (w == 3) hipLaunchKernelGGL((k_solve<3, 0>), grid, block, lds, st, a);
-    else hipLaunchKernelGGL((k_solve<2, 0>), grid, block, lds, st, a);
+    const int w = solve_variant(3);
+    if (disc) { if (w == 4) NEO_LAUNCH(4, 0, false, true); else if (w == 3) NEO_LAUNCH(3, 0, false, true); else NEO_LAUNCH(2, 0, false, true); }
+    else { if (w == 4) NEO_LAUNCH(4, 0); else if (w == 3) NEO_LAUNCH(3, 0); else NEO_LAUNCH(2, 0); }
   }
+#undef NEO_LAUNCH
 }
 void launch_carrots(const CarrotArgs& a, void* stream) {
   if (a.b.count == 0) return;

@@ -257,3 +257,25 @@ def test_window_tolerance_trims_the_creeping_tail_only():
     assert on["iterations"].max() < off["iterations"].max()
     assert (on["cost"] <= off["cost"] + 1e-4).all()
     assert (np.abs(on["vel"] - off["vel"]).max(axis=1) <= 1e-3).mean() >= 0.99
+
+
+@pytest.mark.parametrize("n_steps", [3, 8])
+def test_disc_in_box_specialisation_equals_the_general_kernel(n_steps, monkeypatch):
+    """README-like parameters (the max_vel_trans disc inside the vx/vy box) run kernels compiled
+    without the box/disc corner cases; NEO_MPC_NO_DISC_SPECIALISATION selects the general ones:
+    same iterates, bit for bit."""
+    from neo_mpc_planner2_amd.solver import BatchSolver
+    params = util.orc.make_params(control_steps=n_steps)
+    cmap = synthetic.make_costmap(500, seed=51)
+    probs = synthetic.make_problems(512, 500, seed=52)
+    res = []
+    for general in (False, True):
+        if general:
+            monkeypatch.setenv("NEO_MPC_NO_DISC_SPECIALISATION", "1")
+        st, warm = synthetic.make_states(probs, n_steps)
+        with BatchSolver(params) as s:
+            s.set_costmap(*cmap)
+            res.append(s.solve(probs, st, warm))
+    (c0, x0), (c1, x1) = res
+    assert (c0["iterations"] == c1["iterations"]).mean() >= 0.99
+    assert np.abs(x0 - x1).max() <= 1e-9

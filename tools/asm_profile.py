@@ -14,7 +14,8 @@ lo, hi = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (0, 10**
 text = open(out).read().split("\n")
 start = next(i for i, l in enumerate(text) if l.startswith("_Z") and key in l and ":" in l)
 end = next(i for i in range(start, len(text)) if ".amdhsa_kernel" in text[i])
-cur = 0
+cur = inner = 0
+by_inner = collections.defaultdict(collections.Counter)
 cnt = collections.defaultdict(collections.Counter)
 for l in text[start:end]:
     m = re.match(r"\s*\.loc\s+(\d+)\s+(\d+)\s+\d+", l)
@@ -22,8 +23,10 @@ for l in text[start:end]:
         chain = re.findall(r"neo_mpc_kernels\.hip:(\d+):\d+", l)
         if chain:
             cur = int(chain[-1])        # outermost frame = the line inside the kernel
+            inner = int(chain[0]) if "neo_mpc_kernels.hip:%s:" % chain[0] in l.split("@[")[0] else -int(m.group(2))
         elif int(m.group(1)) <= 1:
             cur = int(m.group(2))       # not inlined: the kernel's own line
+            inner = cur
         continue
     t = l.strip()
     if not t or t[0] in ".;_" or t.endswith(":"):
@@ -32,9 +35,15 @@ for l in text[start:end]:
     if op.startswith(("v_", "s_", "ds_", "global_", "scratch_", "buffer_")):
         kind = "v64" if "f64" in op else op.split("_")[0]
         cnt[cur][kind] += 1
+        if lo <= cur <= hi and len(sys.argv) > 4:
+            by_inner[inner][kind] += 1
 tot = collections.Counter()
 for k in sorted(cnt):
     if lo <= k <= hi:
         print(k, dict(cnt[k]))
     tot.update(cnt[k])
 print("total", dict(tot))
+if by_inner:
+    print("-- by innermost source line (negative: a line of a system header) inside [%d, %d]" % (lo, hi))
+    for k in sorted(by_inner):
+        print(k, sum(by_inner[k].values()), dict(by_inner[k]))
