@@ -358,6 +358,28 @@ __device__ void make_ctx(const DevParams& p, const DevMap& m, const double* P, d
   c.tile_x0 = 0; c.tile_y0 = 0;
 }
 
+// make_ctx for the wave-per-instance kernels: the four yaw extractions run side by side in lanes
+// 0-3 (one atan2 instead of four); every lane leaves with the same wave-uniform values
+__device__ void make_ctx_wave(const DevParams& p, const DevMap& m, const double* P, double fcost, Ctx& c, int lane) {
+  // lane 0: carrot (py:211), 1: goal (py:212), 2: current pose with the goal's w (py:213), 3: current pose (py:317)
+  const int base = lane == 0 ? P_CARROT_Q : lane == 1 ? P_GOAL_Q : P_CUR_Q;
+  const bool goal_w = lane == 2 && (p.compat & NEO_MPC_COMPAT_ODOM_YAW_GOAL_W);
+  const double q[4] = {P[base], P[base + 1], P[base + 2], goal_w ? P[P_GOAL_Q + 3] : P[base + 3]};
+  const double yaw = yaw_of(q);
+  c.tyaw = lane_value(yaw, 0);
+  c.fyaw = lane_value(yaw, 1);
+  const double psi0 = lane_value(yaw, 2);
+  c.true_yaw = lane_value(yaw, 3);
+  sincos_fast(psi0, &c.s0, &c.c0);
+  c.cx = P[P_CARROT_X]; c.cy = P[P_CARROT_Y];
+  c.X0 = P[P_CUR_X]; c.Y0 = P[P_CUR_Y];
+  c.v0 = P[P_VEL]; c.v1 = P[P_VEL + 1]; c.v2 = P[P_VEL + 2];
+  const double gdx = c.cx - P[P_GOAL], gdy = c.cy - P[P_GOAL + 1];
+  c.konst = p.wterm_t * (gdx * gdx + gdy * gdy);          // py:266, 268: constant in u
+  if (fcost == 1.0) c.konst += p.w_footprint;             // py:262-263: N steps * w_footprint/N
+  c.tile_x0 = 0; c.tile_y0 = 0;
+}
+
 // stage the reach tile: rows [my0-R, my0+R], columns from floor4(mx0-R), dword loads
 __device__ void load_tile(const SolveArgs& a, Ctx& c, double* L, int lane) {
   if (a.lds.tile_w == 0) { c.tile_x0 = 0; c.tile_y0 = 0; return; }
@@ -522,7 +544,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   int flags = reset_and_warm(a, L, b, lane) ? NEO_MPC_FLAG_RESET : 0;
   const double fcost = footprint_cost(a, L, b, lane);
   Ctx c;
-  make_ctx(p, a.map, L + a.lds.prob, fcost, c);
+  make_ctx_wave(p, a.map, L + a.lds.prob, fcost, c, lane);
   load_tile(a, c, L, lane);
   // the per-instance constants are wave-uniform: keep them in scalar registers
   c.cx = lane_value(c.cx, 0); c.cy = lane_value(c.cy, 0); c.tyaw = lane_value(c.tyaw, 0);
@@ -566,10 +588,8 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   // x0 clipped to the feasible set (SciPy clips x0 to the bounds, _slsqp_py.py:268)
   for (int i = lane; i < n; i += kLanes) project_block<kDisc>(p, u[3 * i], u[3 * i + 1], u[3 * i + 2]);
   WAVE_SYNC();
-  double f = rollout_cost<kSteps>(a, c, L, [&](int i, double& b0, double& b1, double& b2) {
-    b0 = u[3 * i]; b1 = u[3 * i + 1]; b2 = u[3 * i + 2];
-  });
-  f = lane_value(f, 0);
+  // f(x0) comes out of the first candidate pass: lane 0 evaluates x0 itself there
+  double f = INFINITY;
   bool cold = true;  // x0 == 0 (wave-uniform: every lane scans the same LDS values)
   for (int k = 0; k < nv; ++k) cold = cold && (u[k] == 0.0);
 
@@ -975,12 +995,14 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         a, c, L,
         [&](int i, double& b0, double& b1, double& b2) {
           candidate_block<kDisc>(a, c, L, lane, step, pstep, i, b0, b1, b2);
+          if (it == 0 && lane == 0) { b0 = u[3 * i]; b1 = u[3 * i + 1]; b2 = u[3 * i + 2]; }
           if (kSteps) { cand[3 * i] = b0; cand[3 * i + 1] = b1; cand[3 * i + 2] = b2; }
         },
         [&](int i, double sn, double cs) {
           if (kSteps && !kNewton) { cand_sn[i] = sn; cand_cs[i] = cs; }
         });
     if (!(fc == fc)) fc = INFINITY;
+    if (it == 0) f = lane_value(fc, 0);
     double fb = fc;
     int best = lane;
     wave_argmin(fb, best);
@@ -1044,7 +1066,7 @@ __global__ __launch_bounds__(kLanes) void k_postprocess(const SolveArgs a) {
   int flags = reset_and_warm(a, L, b, lane) ? NEO_MPC_FLAG_RESET : 0;
   const double fcost = footprint_cost(a, L, b, lane);
   Ctx c;
-  make_ctx(a.p, a.map, L + a.lds.prob, fcost, c);
+  make_ctx_wave(a.p, a.map, L + a.lds.prob, fcost, c, lane);
   load_tile(a, c, L, lane);
   double* u = L + a.lds.u;
   for (int k = lane; k < nv; k += kLanes) u[k] = a.solution[(size_t)b * nv + k];

@@ -672,6 +672,7 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
     int best = -1;
     for (int lane = 0; lane < ORC_LANES; ++lane) {
       orc_candidate(&c, &act, lane, alpha, u, gs, d, cand);
+      if (it == 0 && lane == 0) memcpy(cand, u, sizeof(double) * nv); /* the kernel gets f(x0) from this lane */
       double fc = orc_eval(&c, cand);
       if (fc < fb) { fb = fc; best = lane; memcpy(best_c, cand, sizeof(double) * nv); }
       if (orc_trace > 1 && it == orc_trace) {
