@@ -182,10 +182,10 @@ __device__ __forceinline__ int map_raw(const DevMap& m, int mx, int my) {
 }
 
 // normalised cost of a raw cell: nav2 occupancy translation / 100 (build's costmap contract)
-__device__ __forceinline__ double raw_cost(int raw) {
-  int occ = raw == 0 ? 0 : raw == 253 ? 99 : raw == 254 ? 100 : raw == 255 ? -1 : 1 + (97 * (raw - 1)) / 251;
-  return (double)occ / 100.0;
+__device__ __forceinline__ int raw_occupancy(int raw) {
+  return raw == 0 ? 0 : raw == 253 ? 99 : raw == 254 ? 100 : raw == 255 ? -1 : 1 + (97 * (raw - 1)) / 251;
 }
+__device__ __forceinline__ double raw_cost(int raw) { return (double)raw_occupancy(raw) / 100.0; }
 
 __device__ __forceinline__ double step_term(const SolveArgs& a, const Ctx& c, const double* L, double x, double y) {
   const double X = c.X0 + (c.c0 * x - c.s0 * y), Y = c.Y0 + (c.s0 * x + c.c0 * y);
@@ -402,6 +402,32 @@ __device__ void load_tile(const SolveArgs& a, Ctx& c, double* L, int lane) {
   }
 }
 
+// Global-frame rollout of the controls x from the request's pose and TRUE yaw (py:293-306, 320-327):
+// lane i < n leaves with pose i.  The three running sums are accumulated in the reference's order
+// (sequentially, every lane alike); only the trigonometry and the products run side by side, one
+// step per lane -- one sincos per wave instead of n in a row.
+__device__ __forceinline__ void rollout_global(const double* x, int n, double dt, const Ctx& c, int lane,
+                                               double& px_i, double& py_i, double& yaw_i) {
+  double yaw = c.true_yaw;
+  yaw_i = yaw;
+  for (int i = 0; i < n; ++i) {
+    yaw += x[3 * i + 2] * dt;
+    if (lane == i) yaw_i = yaw;
+  }
+  double sn, cs;
+  sincos_fast(yaw_i, &sn, &cs);
+  const int k = lane < n ? lane : 0;
+  const double inc_x = x[3 * k] * cs * dt - x[3 * k + 1] * sn * dt;   // py:326
+  const double inc_y = x[3 * k] * sn * dt + x[3 * k + 1] * cs * dt;   // py:327
+  double px = c.X0, py = c.Y0;
+  px_i = px; py_i = py;
+  for (int i = 0; i < n; ++i) {
+    px += lane_value(inc_x, i);
+    py += lane_value(inc_y, i);
+    if (lane == i) { px_i = px; py_i = py; }
+  }
+}
+
 // ---------------------------------------------------------------- K2: py:365-403
 // `x` (LDS, 3N doubles) is the raw solver output; modified in place like `x.x`.
 __device__ void postprocess(const SolveArgs& a, const Ctx& c, double* L, uint32_t b, int lane, double* x,
@@ -414,17 +440,11 @@ __device__ void postprocess(const SolveArgs& a, const Ctx& c, double* L, uint32_
   // the `local_plan` rollout of the UNFILTERED solution (publishLocalPlan, py:293-306, runs
   // before the low-pass at py:366) from the request's current pose
   if (a.path) {
-    double yaw = c.true_yaw, px = c.X0, py = c.Y0;
-    for (int i = 0; i < n; ++i) {
-      yaw += x[3 * i + 2] * p.dt;
-      double sn, cs;
-      sincos_fast(yaw, &sn, &cs);
-      px += x[3 * i] * cs * p.dt - x[3 * i + 1] * sn * p.dt;
-      py += x[3 * i] * sn * p.dt + x[3 * i + 1] * cs * p.dt;
-      if (lane == 0) {
-        double* o = a.path + ((size_t)b * n + i) * 3;
-        o[0] = px; o[1] = py; o[2] = yaw;
-      }
+    double px, py, yaw;
+    rollout_global(x, n, p.dt, c, lane, px, py, yaw);
+    if (lane < n) {
+      double* o = a.path + ((size_t)b * n + lane) * 3;
+      o[0] = px; o[1] = py; o[2] = yaw;
     }
   }
   // low-pass on the first control, in place (py:366-367)
@@ -438,17 +458,13 @@ __device__ void postprocess(const SolveArgs& a, const Ctx& c, double* L, uint32_
   // collision_check (py:312-341): global-frame rollout from the TRUE yaw
   int collision = Si[SI_COLLISION];
   {
-    double yaw = c.true_yaw, px = c.X0, py = c.Y0;
-    for (int i = 0; i < n; ++i) {
-      yaw += x[3 * i + 2] * p.dt;
-      double sn, cs;
-      sincos_fast(yaw, &sn, &cs);
-      px += x[3 * i] * cs * p.dt - x[3 * i + 1] * sn * p.dt;   // py:326
-      py += x[3 * i] * sn * p.dt + x[3 * i + 1] * cs * p.dt;   // py:327
-      const int mx = cell_of(px, a.map.origin_x, a.map.resolution, a.map.inv_resolution);
-      const int my = cell_of(py, a.map.origin_y, a.map.resolution, a.map.inv_resolution);
-      if (raw_cost(map_raw(a.map, mx, my)) >= 0.99) { collision = 1; break; }   // py:338-341
-    }
+    double px, py, yaw;
+    rollout_global(x, n, p.dt, c, lane, px, py, yaw);
+    const int mx = cell_of(px, a.map.origin_x, a.map.resolution, a.map.inv_resolution);
+    const int my = cell_of(py, a.map.origin_y, a.map.resolution, a.map.inv_resolution);
+    // cost >= 0.99 (py:338-341) <=> occupancy >= 99: 99 / 100.0 is the double the literal 0.99 denotes
+    const bool hit = lane < n && raw_occupancy(map_raw(a.map, mx, my)) >= 99;
+    if (__ballot(hit) != 0ull) collision = 1;
   }
   const int coll_fp = (fcost == 1.0) ? 1 : 0;                       // py:343-347
   double out0, out1, out2, waiting = S[S_WAIT];
