@@ -130,6 +130,20 @@ __device__ __forceinline__ double rsq_fast(double x) {
   return r;
 }
 
+// sqrt(x), x >= 0 and not huge: v_rsq_f64, one coupled Goldschmidt step and one residual correction.
+// Measured on gfx950 against the correctly rounded root (tools/sqrt_check.hip, 4 M arguments over
+// 2^-300..2^300): identical except 1 ulp on a denormal; 11 operations where the library's
+// sequence (input scaling, a second correction, class test) takes 18.
+__device__ __forceinline__ double sqrt_fast(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  g = fma(fma(-g, g, x), h, g);
+  return x > 0.0 ? g : 0.0;
+}
+
 __device__ __forceinline__ void sincos_fast(double x, double* sn, double* cs) {
   // (|x| beyond ~1e6 -- never produced by a feasible rollout, |theta| <= max_vel_theta * horizon
   // plus a yaw -- only loses accuracy; a non-finite x gives NaN, which the arc search discards)
@@ -294,7 +308,7 @@ __device__ __forceinline__ void candidate_block(const SolveArgs& a, const Ctx& c
     const double* gs = L + a.lds.gs + 3 * i;
     const double e0 = (u[0] - step * gs[0]) - c.v0, e1 = (u[1] - step * gs[1]) - c.v1,
                  e2 = (u[2] - step * gs[2]) - c.v2;
-    const double ne = sqrt(e0 * e0 + e1 * e1 + e2 * e2);
+    const double ne = sqrt_fast(e0 * e0 + e1 * e1 + e2 * e2);
     const double sh = (ne > 0.0) ? fmax(0.0, 1.0 - step * a.p.wc_n * rcp_fast(ne)) : 0.0;
     b0 = c.v0 + sh * e0; b1 = c.v1 + sh * e1; b2 = c.v2 + sh * e2;
   } else {          // quasi-Newton direction
@@ -329,7 +343,7 @@ __device__ __forceinline__ double rollout_cost(const SolveArgs& a, const Ctx& c,
     const double dx = c.cx - x, dy = c.cy - y, et = c.tyaw - th;
     const double e0 = c.v0 - vx, e1 = c.v1 - vy, e2 = c.v2 - w;
     f += p.wt_n * (dx * dx + dy * dy) + p.wo_n * (et * et);   // py:252
-    f += p.wc_n * sqrt(e0 * e0 + e1 * e1 + e2 * e2);           // py:253-254
+    f += p.wc_n * sqrt_fast(e0 * e0 + e1 * e1 + e2 * e2);      // py:253-254
     f += step_term(a, c, L, x, y);                             // py:246-247, 257-260
   }
   const double et = c.fyaw - th;
@@ -733,13 +747,13 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       const double u0 = u[3 * i], u1 = u[3 * i + 1], u2 = u[3 * i + 2];
       const double g0 = gs[3 * i], g1 = gs[3 * i + 1], g2 = gs[3 * i + 2];
       const double e0 = u0 - c.v0, e1 = u1 - c.v1, e2 = u2 - c.v2;
-      const double ne = sqrt(e0 * e0 + e1 * e1 + e2 * e2);
+      const double ne = sqrt_fast(e0 * e0 + e1 * e1 + e2 * e2);
       double t0, t1, t2;
       if (ne > 0.0) {
         const double wn = p.wc_n * rcp_fast(ne);
         t0 = g0 + wn * e0; t1 = g1 + wn * e1; t2 = g2 + wn * e2;
       } else {
-        const double ng = sqrt(g0 * g0 + g1 * g1 + g2 * g2);
+        const double ng = sqrt_fast(g0 * g0 + g1 * g1 + g2 * g2);
         const double sh = (ng > p.wc_n) ? 1.0 - p.wc_n / ng : 0.0;
         t0 = g0 * sh; t1 = g1 * sh; t2 = g2 * sh;
       }
@@ -763,7 +777,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         if (u1 <= p.lo[1]) { ny1 = -1.0; v1 = true; }
         else if (u1 >= p.hi[1]) { ny1 = 1.0; v1 = true; }
       }
-      const double nvv = sqrt(u0 * u0 + u1 * u1);
+      const double nvv = sqrt_fast(u0 * u0 + u1 * u1);
       if (nvv > 0.0 && nvv >= p.r * (1.0 - 1e-12)) { const double iv = rcp_fast(nvv); nx2 = u0 * iv; ny2 = u1 * iv; v2 = true; }
       const double dx = -t0, dy = -t1;
       const double dn0 = nx0 * dx + ny0 * dy, dn1 = nx1 * dx + ny1 * dy, dn2 = nx2 * dx + ny2 * dy;
