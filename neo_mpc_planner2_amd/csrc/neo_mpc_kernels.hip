@@ -89,6 +89,22 @@ __device__ __forceinline__ double wave_max(double v) {
   return lane_value(v, 63);
 }
 __device__ __forceinline__ double wave_min(double v) { return -wave_max(-v); }
+// maximum of non-negative float32 values (step lengths, pivots: compared against tolerances, single
+// precision is plenty): one DPP-fused v_max_f32 per hop instead of two moves and a 64-bit max
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ float dpp_move_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v),
+                                                              kCtrl, kRowMask, 0xf, false));
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+  v = fmaxf(v, dpp_move_f<0x111, 0xf>(v));
+  v = fmaxf(v, dpp_move_f<0x112, 0xf>(v));
+  v = fmaxf(v, dpp_move_f<0x114, 0xf>(v));
+  v = fmaxf(v, dpp_move_f<0x118, 0xf>(v));
+  v = fmaxf(v, dpp_move_f<0x142, 0xa>(v));
+  v = fmaxf(v, dpp_move_f<0x143, 0xc>(v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 // lowest value, ties to the lowest lane; every lane returns the same pair
 __device__ __forceinline__ void wave_argmin(double& v, int& idx) {
   const double m = wave_min(v);
@@ -754,7 +770,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         t0 = g0 + wn * e0; t1 = g1 + wn * e1; t2 = g2 + wn * e2;
       } else {
         const double ng = sqrt_fast(g0 * g0 + g1 * g1 + g2 * g2);
-        const double sh = (ng > p.wc_n) ? 1.0 - p.wc_n / ng : 0.0;
+        const double sh = (ng > p.wc_n) ? 1.0 - p.wc_n * rcp_fast(ng) : 0.0;
         t0 = g0 * sh; t1 = g1 * sh; t2 = g2 * sh;
       }
       AMODE[4 * i + 3] = AMODE[4 * i + 2];
@@ -810,7 +826,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         ADY[i] = mode == 1 ? -mnx * mny : 0.0;                          // P01
         ARX[i] = mode == 0 ? 1.0 : mode == 1 ? 1.0 - mny * mny : 0.0;   // P11
         ARY[i] = wfroz ? 0.0 : 1.0;                                     // PW
-        ART[i] = (mode == 1 && mslot == 2) ? mlam / p.r : 0.0;          // lambda / r
+        ART[i] = (mode == 1 && mslot == 2) ? mlam * rcp_fast(p.r) : 0.0;  // lambda / r
       }
     }
     WAVE_SYNC();
@@ -830,11 +846,11 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       for (int bk = 0; bk < kRegSteps; ++bk) {
         const bool near_b = AMODE[4 * bk + 2] != 0;
         const float e0 = (float)(u[3 * bk] - c.v0), e1 = (float)(u[3 * bk + 1] - c.v1), e2 = (float)(u[3 * bk + 2] - c.v2);
-        const float ne = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+        const float ne2 = e0 * e0 + e1 * e1 + e2 * e2;
         const int q = lane - 3 * bk;  // column inside block bk
         if (q >= 0 && q < 3 && !near_b) {
-          if (ne > 0.0f) {  // (w/|e|)(I - e e^T / |e|^2)
-            const float ine = __builtin_amdgcn_rcpf(ne);
+          if (ne2 > 0.0f) {  // (w/|e|)(I - e e^T / |e|^2)
+            const float ine = __builtin_amdgcn_rsqf(ne2);
             const float sN = (float)p.wc_n * ine, h0 = e0 * ine, h1 = e1 * ine, h2 = e2 * ine;
             const float hq = q == 0 ? h0 : q == 1 ? h1 : h2;
             hc[3 * bk] += sN * ((q == 0 ? 1.0f : 0.0f) - h0 * hq);
@@ -884,7 +900,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         if (r == 1) { hc[3 * bk] -= P01; hc[3 * bk + 1] += 1.0f - P11; diag = hc[3 * bk + 1]; }
         if (r == 2) { hc[3 * bk + 2] += 1.0f - PW; diag = hc[3 * bk + 2]; }
       }
-      const float deltaf = fmaxf(1e-6f * (float)wave_max((double)fabsf(diag)), 1e-30f);
+      const float deltaf = fmaxf(1e-6f * wave_max_f(fabsf(diag)), 1e-30f);
       float pinvf[kVars];
       auto lane_f = [](float v, int src) {
         return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
@@ -928,9 +944,9 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         sy += sk * yk; ss += sk * sk; yy += yk * yk;
       }
       sy = wave_sum(sy); ss = wave_sum(ss); yy = wave_sum(yy);
-      const int ok = uniform_int((ss > 0.0 && sy > 1e-10 * sqrt(ss * yy)) ? 1 : 0);
+      const int ok = uniform_int((ss > 0.0 && sy > 1e-10 * sqrt_fast(ss * yy)) ? 1 : 0);
       if (ok) {
-        if (lane == 0) rho[head] = 1.0 / sy;
+        if (lane == 0) rho[head] = rcp_fast(sy);
         head = (head + 1) % mem;
         if (npairs < mem) ++npairs;
       }
@@ -967,7 +983,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         if (lane < nv) part += yv[lane] * yv[lane];
         if (kWide && lane + 64 < nv) part += yv[lane + 64] * yv[lane + 64];
         if (kWide && lane + 128 < nv) part += yv[lane + 128] * yv[lane + 128];
-        const double gamma = 1.0 / (rho[idx] * wave_sum(part));
+        const double gamma = rcp_fast(rho[idx] * wave_sum(part));
         q0 *= gamma; q1 *= gamma; q2 *= gamma;
       }
 #pragma unroll
@@ -1008,15 +1024,15 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     if (kNewton && it > 0) {
       // the full Newton step is already below the step tolerance: u is the answer (blocks next to
       // the kink are moved by the prox step, which d does not describe -- keep iterating then)
-      double dm = 0.0;
+      float dm = 0.0f;
       int anynear = 0;
-      if (lane < kVars) { dm = fabs(d[lane]); anynear = AMODE[4 * (lane / 3) + 2]; }
-      dm = wave_max(dm);
+      if (lane < kVars) { dm = (float)fabs(d[lane]); anynear = AMODE[4 * (lane / 3) + 2]; }
+      dm = wave_max_f(dm);
       const bool near_any = __ballot(anynear != 0) != 0ull;
-      if (dm < TOL[T_EARLY] && !near_any) { status = NEO_MPC_STATUS_CONVERGED; break; }
+      if ((double)dm < TOL[T_EARLY] && !near_any) { status = NEO_MPC_STATUS_CONVERGED; break; }
       // a full Newton step below opt_tolerance (SLSQP's own step test) is the last one: searched
       // and taken like any other, but nothing re-checks the point it lands on
-      if (dm < TOL[T_FINAL] && !near_any) final_step = true;
+      if ((double)dm < TOL[T_FINAL] && !near_any) final_step = true;
     }
     // ---- 64 candidates, one rollout per lane; lowest objective wins
     const double pstep = alpha * lane_scale(lane);
@@ -1057,15 +1073,15 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     }
     have_trig = true;
     WAVE_SYNC();
-    double stepmax = 0.0;
+    float stepmax = 0.0f;
     for (int k = lane; k < nv; k += kLanes) {
       const double nu = u_new[k], ou = u[k];
-      stepmax = fmax(stepmax, fabs(nu - ou));
+      stepmax = fmaxf(stepmax, (float)fabs(nu - ou));
       u_prev[k] = ou; gt_prev[k] = gt[k]; u[k] = nu;
     }
-    stepmax = wave_max(stepmax);
+    stepmax = wave_max_f(stepmax);
     const double gain = f - fb;
-    stall = (gain <= TOL[T_FTOL] * fmax(1.0, fabs(fb)) || stepmax <= TOL[T_STALL]) ? stall + 1 : 0;
+    stall = (gain <= TOL[T_FTOL] * fmax(1.0, fabs(fb)) || (double)stepmax <= TOL[T_STALL]) ? stall + 1 : 0;
     // three iterations that together gained less than wtol: creeping along a costmap cell edge
     const double wtol = TOL[T_WTOL];
     const bool creeping = wtol > 0.0 && gain + gain1 + gain2 <= wtol * fmax(1.0, fabs(fb));
@@ -1076,7 +1092,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       alpha = clampd(alpha, 1e-6, 1e6);
     }
     WAVE_SYNC();
-    if (stepmax < TOL[T_XTOL] || stall >= kStallIterations || creeping || final_step) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
+    if ((double)stepmax < TOL[T_XTOL] || stall >= kStallIterations || creeping || final_step) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
   }
 
   if (a.solution)
