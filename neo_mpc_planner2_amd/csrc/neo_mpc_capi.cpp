@@ -131,6 +131,7 @@ void derive(neo_mpc_handle* h) {
   d.compat = p.compat_flags;
   d.disc_in_box = (p.min_vel_x <= -p.max_vel_trans && p.max_vel_x >= p.max_vel_trans &&
                    p.min_vel_y <= -p.max_vel_trans && p.max_vel_y >= p.max_vel_trans) ? 1 : 0;
+  d.tame = (d.disc_in_box && fmax(fabs(p.min_vel_theta), fabs(p.max_vel_theta)) * p.prediction_horizon <= 0.78) ? 1 : 0;
   d.newton = ((p.method == NEO_MPC_METHOD_NEWTON || p.method == NEO_MPC_METHOD_AUTO) && n == 3) ? 1 : 0;
   d.early_tol = getenv("NEO_MPC_NO_EARLY") ? 0.0 : d.xtol;
   d.final_tol = getenv("NEO_MPC_NO_EARLY") ? 0.0 : (p.step_tolerance > 0.0 ? p.step_tolerance : p.opt_tolerance);

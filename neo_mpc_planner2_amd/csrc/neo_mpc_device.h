@@ -35,6 +35,7 @@ struct DevParams {
   int32_t mem;               // L-BFGS pairs
   int32_t compat;
   int32_t disc_in_box;       // the max_vel_trans disc lies inside the vx/vy box (README params)
+  int32_t tame;              // disc_in_box and max|omega| * horizon <= 0.78 rad: the kTame kernels apply
   int32_t newton;            // lanes 32-63 walk the projected Newton direction (control_steps == 3)
 };
 

@@ -186,6 +186,30 @@ __device__ __forceinline__ void sincos_fast(double x, double* sn, double* cs) {
   *cs = ((q + 1) & 2) ? -c0 : c0;
 }
 
+// The same two kernels without the reduction, for |x| <= pi/4: 17 operations.  The rollout's heading
+// never leaves that range when max|omega| * prediction_horizon <= 0.78 (DevParams.tame; 0.56 with
+// the README's parameters).
+__device__ __forceinline__ void sincos_small(double r, double* sn, double* cs) {
+  const double z = r * r;
+  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = fma(z, ps, 2.75573137070700676789e-06);
+  ps = fma(z, ps, -1.98412698298579493134e-04);
+  ps = fma(z, ps, 8.33333333332248946124e-03);
+  ps = fma(z, ps, -1.66666666666666324348e-01);
+  *sn = fma(z * r, ps, r);
+  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = fma(z, pc, -2.75573143513906633035e-07);
+  pc = fma(z, pc, 2.48015872894767294178e-05);
+  pc = fma(z, pc, -1.38888888888741095749e-03);
+  pc = fma(z, pc, 4.16666666666666019037e-02);
+  *cs = fma(z * z, pc, fma(z, -0.5, 1.0));
+}
+template <bool kTame>
+__device__ __forceinline__ void sincos_heading(double th, double* sn, double* cs) {
+  if (kTame) sincos_small(th, sn, cs);
+  else sincos_fast(th, sn, cs);
+}
+
 // py:176-178
 __device__ __forceinline__ double yaw_of(const double* q) {
   double t3 = 2.0 * (q[3] * q[2] + q[0] * q[1]);
@@ -267,12 +291,12 @@ __device__ double footprint_cost(const SolveArgs& a, const double* L, uint32_t b
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // Euclidean projection of (vx, vy) onto box ∩ disc; omega clamped (py:125-134, 157-158)
-// kDisc: the caller knows at compile time that the disc lies inside the vx/vy box
-template <bool kDisc = false>
+// kTame: the caller knows at compile time that the disc lies inside the vx/vy box (DevParams.tame)
+template <bool kTame = false>
 __device__ __forceinline__ void project_block(const DevParams& p, double& b0, double& b1, double& b2) {
   b2 = clampd(b2, p.lo[2], p.hi[2]);
   const double zx = b0, zy = b1, r = p.r;
-  if (kDisc || p.disc_in_box) {  // README parameters: the box never binds, the projection is radial
+  if (kTame || p.disc_in_box) {  // README parameters: the box never binds, the projection is radial
     const double n2 = zx * zx + zy * zy;
     if (n2 > r * r) { const double sc = r * rsq_fast(n2); b0 = zx * sc; b1 = zy * sc; }
     return;
@@ -313,7 +337,7 @@ __device__ __forceinline__ double lane_scale(int lane) {
 // control block i of this lane's candidate
 // (`step`: this lane's step along its own family; `pstep`: its proximal-gradient step length, used
 // by the L-BFGS lanes for blocks sitting next to the control-norm kink)
-template <bool kDisc = false>
+template <bool kTame = false>
 __device__ __forceinline__ void candidate_block(const SolveArgs& a, const Ctx& c, const double* L, int lane,
                                                 double step, double pstep, int i, double& b0, double& b1,
                                                 double& b2) {
@@ -331,7 +355,7 @@ __device__ __forceinline__ void candidate_block(const SolveArgs& a, const Ctx& c
     const double* d = L + a.lds.d + 3 * i;
     b0 = u[0] + step * d[0]; b1 = u[1] + step * d[1]; b2 = u[2] + step * d[2];
   }
-  project_block<kDisc>(a.p, b0, b1, b2);
+  project_block<kTame>(a.p, b0, b1, b2);
 }
 
 // rollout + cost of one control sequence (py:224-268); Block(i, b0, b1, b2) yields the controls
@@ -340,7 +364,7 @@ struct NoRecord {
 };
 // kSteps > 0: control_steps known at compile time (loops unroll); Record(i, sin, cos) lets the caller
 // keep the rollout's trigonometry (the winner's is reused by the next adjoint sweep)
-template <int kSteps = 0, class Block, class Record = NoRecord>
+template <int kSteps = 0, bool kTame = false, class Block, class Record = NoRecord>
 __device__ __forceinline__ double rollout_cost(const SolveArgs& a, const Ctx& c, const double* L, Block block,
                                                Record record = Record()) {
   const DevParams& p = a.p;
@@ -352,7 +376,7 @@ __device__ __forceinline__ double rollout_cost(const SolveArgs& a, const Ctx& c,
     block(i, vx, vy, w);
     th += w * p.dt;                                     // py:230
     double sn, cs;
-    sincos_fast(th, &sn, &cs);
+    sincos_heading<kTame>(th, &sn, &cs);
     record(i, sn, cs);
     x += (vx * cs - vy * sn) * p.dt;                    // py:231
     y += (vx * sn + vy * cs) * p.dt;                    // py:232
@@ -562,9 +586,11 @@ __device__ void load_records(const SolveArgs& a, double* L, uint32_t b, int lane
 // kSteps > 0: specialisation for control_steps == kSteps -- every lane keeps its candidate's controls
 // and sin/cos in registers, so the winner is stored without being recomputed and the next adjoint
 // sweep needs no trigonometry.  kSteps == 0: any control_steps (LDS-only path).
-// kDisc: instantiation for parameter sets whose max_vel_trans disc lies inside the vx/vy box (the
-// README's): the box/disc corner cases of the projection and of the tangent cone drop out.
-template <int kMinWavesPerSimd, int kSteps, bool kNewton = false, bool kDisc = false>
+// kTame: instantiation for parameter sets (the README's among them) whose max_vel_trans disc lies
+// inside the vx/vy box -- the box/disc corner cases of the projection and of the tangent cone drop
+// out -- and whose heading cannot leave [-pi/4, pi/4] within the horizon -- no range reduction in
+// the rollout's sin/cos.
+template <int kMinWavesPerSimd, int kSteps, bool kNewton = false, bool kTame = false>
 __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveArgs args) {
   static_assert(!kNewton || kSteps > 0, "the Newton path needs a compile-time control_steps");
   extern __shared__ __align__(16) double L[];
@@ -632,7 +658,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   int* AMODE = reinterpret_cast<int*>(L + a.lds.mode);  // [4n]: mode, wfroz, near, near_prev
 
   // x0 clipped to the feasible set (SciPy clips x0 to the bounds, _slsqp_py.py:268)
-  for (int i = lane; i < n; i += kLanes) project_block<kDisc>(p, u[3 * i], u[3 * i + 1], u[3 * i + 2]);
+  for (int i = lane; i < n; i += kLanes) project_block<kTame>(p, u[3 * i], u[3 * i + 1], u[3 * i + 2]);
   WAVE_SYNC();
   // f(x0) comes out of the first candidate pass: lane 0 evaluates x0 itself there
   double f = INFINITY;
@@ -671,7 +697,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         const double vy = u[3 * i + 1] + (lane == 3 * i + 1 ? hstep : 0.0);
         const double w = u[3 * i + 2] + (lane == 3 * i + 2 ? hstep : 0.0);
         th += w * p.dt;
-        sincos_fast(th, &psn[i], &pcs[i]);
+        sincos_heading<kTame>(th, &psn[i], &pcs[i]);
         x += (vx * pcs[i] - vy * psn[i]) * p.dt;
         y += (vx * psn[i] + vy * pcs[i]) * p.dt;
       }
@@ -706,7 +732,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       const double vx = on ? u[3 * lane] : 0.0, vy = on ? u[3 * lane + 1] : 0.0, w = on ? u[3 * lane + 2] : 0.0;
       const double th = wave_scan(w * p.dt);
       double sn, cs;
-      sincos_fast(th, &sn, &cs);
+      sincos_heading<kTame>(th, &sn, &cs);
       const double ddx = (vx * cs - vy * sn) * p.dt, ddy = (vx * sn + vy * cs) * p.dt;
       const double x = wave_scan(ddx), y = wave_scan(ddy);
       double rt = on ? -2.0 * p.wo_n * (c.tyaw - th) : 0.0;
@@ -733,7 +759,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         th += w * p.dt;
         double sn, cs;
         if (kSteps && have_trig) { sn = ASN[i]; cs = ACS[i]; }
-        else sincos_fast(th, &sn, &cs);
+        else sincos_heading<kTame>(th, &sn, &cs);
         const double ddx = (vx * cs - vy * sn) * p.dt, ddy = (vx * sn + vy * cs) * p.dt;
         x += ddx; y += ddy;
         double rt = -2.0 * p.wo_n * (c.tyaw - th);
@@ -787,7 +813,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       // (fixed slots + validity flags: no dynamically indexed private arrays, i.e. no scratch)
       double nx0 = 0.0, ny0 = 0.0, nx1 = 0.0, ny1 = 0.0, nx2 = 0.0, ny2 = 0.0;
       bool v0 = false, v1 = false, v2 = false;
-      if (!kDisc && !p.disc_in_box) {  // (inside the box a bound can only touch where the disc touches too)
+      if (!kTame && !p.disc_in_box) {  // (inside the box a bound can only touch where the disc touches too)
         if (u0 <= p.lo[0]) { nx0 = -1.0; v0 = true; }
         else if (u0 >= p.hi[0]) { nx0 = 1.0; v0 = true; }
         if (u1 <= p.lo[1]) { ny1 = -1.0; v1 = true; }
@@ -1037,10 +1063,10 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     // ---- 64 candidates, one rollout per lane; lowest objective wins
     const double pstep = alpha * lane_scale(lane);
     const double step = lane < 32 ? pstep : lane_scale(lane);
-    double fc = rollout_cost<kSteps>(
+    double fc = rollout_cost<kSteps, kTame>(
         a, c, L,
         [&](int i, double& b0, double& b1, double& b2) {
-          candidate_block<kDisc>(a, c, L, lane, step, pstep, i, b0, b1, b2);
+          candidate_block<kTame>(a, c, L, lane, step, pstep, i, b0, b1, b2);
           if (it == 0 && lane == 0) { b0 = u[3 * i]; b1 = u[3 * i + 1]; b2 = u[3 * i + 2]; }
           if (kSteps) { cand[3 * i] = b0; cand[3 * i + 1] = b1; cand[3 * i + 2] = b2; }
         },
@@ -1067,7 +1093,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       const double bstep = lane_value(step, best), bpstep = lane_value(pstep, best);
       for (int i = lane; i < n; i += kLanes) {
         double b0, b1, b2;
-        candidate_block<kDisc>(a, c, L, best, bstep, bpstep, i, b0, b1, b2);
+        candidate_block<kTame>(a, c, L, best, bstep, bpstep, i, b0, b1, b2);
         u_new[3 * i] = b0; u_new[3 * i + 1] = b1; u_new[3 * i + 2] = b2;
       }
     }
@@ -1283,7 +1309,7 @@ void launch_solve(const SolveArgs& a, void* stream) {
   const dim3 grid(a.count), block(kLanes);
   hipStream_t st = (hipStream_t)stream;
   const bool generic = getenv("NEO_MPC_GENERIC_STEPS") != nullptr || a.p.mem != 4;  // A/B: LDS-only path
-  const bool disc = a.p.disc_in_box != 0 && getenv("NEO_MPC_NO_DISC_SPECIALISATION") == nullptr;
+  const bool disc = a.p.tame != 0 && getenv("NEO_MPC_NO_TAME_SPECIALISATION") == nullptr;
   const size_t lds = a.lds.total_bytes;
 #define NEO_LAUNCH(...) hipLaunchKernelGGL((k_solve<__VA_ARGS__>), grid, block, lds, st, a)
   if (a.p.n == 3 && a.p.newton) {  // projected Newton (its layout does not depend on lbfgs_memory)

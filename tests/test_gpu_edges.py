@@ -261,9 +261,9 @@ def test_window_tolerance_trims_the_creeping_tail_only():
 
 @pytest.mark.parametrize("n_steps", [3, 8])
 def test_disc_in_box_specialisation_equals_the_general_kernel(n_steps, monkeypatch):
-    """README-like parameters (the max_vel_trans disc inside the vx/vy box) run kernels compiled
-    without the box/disc corner cases; NEO_MPC_NO_DISC_SPECIALISATION selects the general ones:
-    same iterates, bit for bit."""
+    """README-like parameters (the max_vel_trans disc inside the vx/vy box, heading within pi/4 over
+    the horizon) run kernels compiled without the box/disc corner cases and without the sin/cos range
+    reduction; NEO_MPC_NO_TAME_SPECIALISATION selects the general ones: same results up to rounding."""
     from neo_mpc_planner2_amd.solver import BatchSolver
     params = util.orc.make_params(control_steps=n_steps)
     cmap = synthetic.make_costmap(500, seed=51)
@@ -271,11 +271,32 @@ def test_disc_in_box_specialisation_equals_the_general_kernel(n_steps, monkeypat
     res = []
     for general in (False, True):
         if general:
-            monkeypatch.setenv("NEO_MPC_NO_DISC_SPECIALISATION", "1")
+            monkeypatch.setenv("NEO_MPC_NO_TAME_SPECIALISATION", "1")
         st, warm = synthetic.make_states(probs, n_steps)
         with BatchSolver(params) as s:
             s.set_costmap(*cmap)
             res.append(s.solve(probs, st, warm))
     (c0, x0), (c1, x1) = res
-    assert (c0["iterations"] == c1["iterations"]).mean() >= 0.99
-    assert np.abs(x0 - x1).max() <= 1e-9
+    assert (c0["iterations"] == c1["iterations"]).mean() >= 0.97
+    assert (np.abs(x0 - x1).max(axis=1) <= 1e-6).mean() >= 0.97   # (sin/cos differ in the last place)
+    assert (np.abs(c0["vel"] - c1["vel"]).max(axis=1) <= 1e-6).mean() >= 0.99
+
+
+def test_fast_turning_robot_uses_the_range_reduced_trigonometry():
+    """max_vel_theta * prediction_horizon > pi/4: the heading can leave the range of the reduction-free
+    sin/cos kernels, so the general kernels (Cody-Waite reduction) must be chosen -- results agree
+    with the mirror (libm sin/cos) as for any other parameter set."""
+    from neo_mpc_planner2_amd.solver import BatchSolver
+    params = util.orc.make_params(max_vel_theta=3.0, min_vel_theta=-3.0, w_orient=2.0)
+    cmap = synthetic.make_costmap(500, seed=61)
+    probs = synthetic.make_problems(512, 500, seed=62)
+    probs["carrot_q"] = synthetic.yaw_quat(np.random.default_rng(63).uniform(-3.0, 3.0, len(probs)))
+    st, warm = synthetic.make_states(probs, 3)
+    st_c, warm_c = st.copy(), warm.copy()
+    with BatchSolver(params) as s:
+        s.set_costmap(*cmap)
+        cg, xg = s.solve(probs, st, warm)
+    cc, xc, _ = _mirror(params, cmap, probs, st_c, warm_c)
+    assert np.abs(xg[:, 2::3]).max() > 0.9          # the solutions do turn hard
+    _close(cg, cc, frac=0.97)
+    assert (cg["cost"] <= cc["cost"] + 1e-6).mean() >= 0.97
