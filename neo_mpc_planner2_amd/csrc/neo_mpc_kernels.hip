@@ -656,6 +656,11 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   double* ANX = L + a.lds.nx;
   double* ANY = L + a.lds.ny;
   int* AMODE = reinterpret_cast<int*>(L + a.lds.mode);  // [4n]: mode, wfroz, near, near_prev
+  // Newton: one float32 record per control block (projector + block curvature), written by the
+  // tangent-cone pass; it lives in the cs..rt step arrays, which the Newton kernel does not use
+  constexpr int kNewtonRecord = 13;
+  static_assert(!kNewton || 2 * 7 * kRegSteps >= kNewtonRecord * kRegSteps, "Newton records do not fit the step arrays");
+  float* NB = reinterpret_cast<float*>(L + a.lds.cs);
 
   // x0 clipped to the feasible set (SciPy clips x0 to the bounds, _slsqp_py.py:268)
   for (int i = lane; i < n; i += kLanes) project_block<kTame>(p, u[3 * i], u[3 * i + 1], u[3 * i + 2]);
@@ -804,6 +809,10 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         gt[3 * i] = 0.0; gt[3 * i + 1] = 0.0; gt[3 * i + 2] = 0.0;
         gr[3 * i] = 0.0; gr[3 * i + 1] = 0.0; gr[3 * i + 2] = 0.0;
         ANX[i] = 0.0; ANY[i] = 0.0; AMODE[4 * i] = 0; AMODE[4 * i + 1] = 0; AMODE[4 * i + 2] = 1;
+        if (kNewton) {
+#pragma unroll
+          for (int k = 0; k < kNewtonRecord; ++k) NB[kNewtonRecord * i + k] = 0.0f;  // P = 0: row/column of I
+        }
         continue;
       }
       gt[3 * i] = t0; gt[3 * i + 1] = t1; gt[3 * i + 2] = t2;
@@ -847,12 +856,27 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       }
       gr[3 * i] = r0; gr[3 * i + 1] = r1; gr[3 * i + 2] = wfroz ? 0.0 : t2;
       ANX[i] = mnx; ANY[i] = mny; AMODE[4 * i] = mode; AMODE[4 * i + 1] = wfroz; AMODE[4 * i + 2] = 0;
-      if (kNewton) {  // projector onto the tangent cone's face + curvature of a binding disc
-        ADX[i] = mode == 0 ? 1.0 : mode == 1 ? 1.0 - mnx * mnx : 0.0;   // P00
-        ADY[i] = mode == 1 ? -mnx * mny : 0.0;                          // P01
-        ARX[i] = mode == 0 ? 1.0 : mode == 1 ? 1.0 - mny * mny : 0.0;   // P11
-        ARY[i] = wfroz ? 0.0 : 1.0;                                     // PW
-        ART[i] = (mode == 1 && mslot == 2) ? mlam * rcp_fast(p.r) : 0.0;  // lambda / r
+      if (kNewton) {
+        // Block record of the Newton system, float32: the projector onto the tangent cone's face
+        // (P00 P01 P11 PW) and the block's own curvature C (3x3): the control norm's Hessian
+        // (w/|e|)(I - e e^T/|e|^2) plus lambda/r t t^T of a binding disc, t = (-ny, nx)
+        float* nb = NB + kNewtonRecord * i;
+        nb[0] = mode == 0 ? 1.0f : mode == 1 ? (float)(1.0 - mnx * mnx) : 0.0f;
+        nb[1] = mode == 1 ? (float)(-mnx * mny) : 0.0f;
+        nb[2] = mode == 0 ? 1.0f : mode == 1 ? (float)(1.0 - mny * mny) : 0.0f;
+        nb[3] = wfroz ? 0.0f : 1.0f;
+        const float f0 = (float)e0, f1 = (float)e1, f2 = (float)e2;
+        const float fn2 = f0 * f0 + f1 * f1 + f2 * f2;
+        const float ine = fn2 > 0.0f ? __builtin_amdgcn_rsqf(fn2) : 0.0f;
+        const float sN = (float)p.wc_n * ine, h0 = f0 * ine, h1 = f1 * ine, h2 = f2 * ine;
+        const float k2 = (mode == 1 && mslot == 2) ? (float)(mlam * rcp_fast(p.r)) : 0.0f;
+        const float tx = -(float)mny, ty = (float)mnx;
+        const float c00 = sN * (1.0f - h0 * h0) + k2 * tx * tx, c01 = -sN * h0 * h1 + k2 * tx * ty,
+                    c02 = -sN * h0 * h2, c11 = sN * (1.0f - h1 * h1) + k2 * ty * ty, c12 = -sN * h1 * h2,
+                    c22 = sN * (1.0f - h2 * h2);
+        nb[4] = c00; nb[5] = c01; nb[6] = c02;
+        nb[7] = c01; nb[8] = c11; nb[9] = c12;
+        nb[10] = c02; nb[11] = c12; nb[12] = c22;
       }
     }
     WAVE_SYNC();
@@ -866,36 +890,22 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       // search and the float64 objective decide), and single precision halves registers, readlanes
       // and VALU time of this section.
       float* Hm = reinterpret_cast<float*>(L + a.lds.hess);
-      // ---- lane k < 3N holds Hessian column k: add the control norm's Hessian and the disc
-      //      curvature on its diagonal block, apply P on the row index, store the column
+      // this lane's own block (lane = variable index 3 * kb + kq) and that block's record
+      const int kv = lane < kVars ? lane : 0, kb = (kv * 11) >> 5, kq = kv - 3 * kb;   // kv / 3 for kv < 32
+      const float* own = NB + kNewtonRecord * kb;
+      // ---- lane k < 3N holds Hessian column k: add column kq of its block's curvature, apply P on
+      //      the row index, store the column
+      {
+        const float cn0 = own[4 + kq], cn1 = own[7 + kq], cn2 = own[10 + kq];  // (C is symmetric)
 #pragma unroll
-      for (int bk = 0; bk < kRegSteps; ++bk) {
-        const bool near_b = AMODE[4 * bk + 2] != 0;
-        const float e0 = (float)(u[3 * bk] - c.v0), e1 = (float)(u[3 * bk + 1] - c.v1), e2 = (float)(u[3 * bk + 2] - c.v2);
-        const float ne2 = e0 * e0 + e1 * e1 + e2 * e2;
-        const int q = lane - 3 * bk;  // column inside block bk
-        if (q >= 0 && q < 3 && !near_b) {
-          if (ne2 > 0.0f) {  // (w/|e|)(I - e e^T / |e|^2)
-            const float ine = __builtin_amdgcn_rsqf(ne2);
-            const float sN = (float)p.wc_n * ine, h0 = e0 * ine, h1 = e1 * ine, h2 = e2 * ine;
-            const float hq = q == 0 ? h0 : q == 1 ? h1 : h2;
-            hc[3 * bk] += sN * ((q == 0 ? 1.0f : 0.0f) - h0 * hq);
-            hc[3 * bk + 1] += sN * ((q == 1 ? 1.0f : 0.0f) - h1 * hq);
-            hc[3 * bk + 2] += sN * ((q == 2 ? 1.0f : 0.0f) - h2 * hq);
-          }
-          const float k2 = (float)ART[bk];
-          if (k2 != 0.0f && q < 2) {  // tangent (-ny, nx)
-            const float tx = -(float)ANY[bk], ty = (float)ANX[bk], tq = q == 0 ? tx : ty;
-            hc[3 * bk] += k2 * tx * tq;
-            hc[3 * bk + 1] += k2 * ty * tq;
-          }
+        for (int bk = 0; bk < kRegSteps; ++bk) {
+          const float* nb = NB + kNewtonRecord * bk;
+          const bool mine = lane < kVars && kb == bk;
+          const float hx = hc[3 * bk] + (mine ? cn0 : 0.0f), hy = hc[3 * bk + 1] + (mine ? cn1 : 0.0f);
+          hc[3 * bk] = nb[0] * hx + nb[1] * hy;
+          hc[3 * bk + 1] = nb[1] * hx + nb[2] * hy;
+          hc[3 * bk + 2] = (hc[3 * bk + 2] + (mine ? cn2 : 0.0f)) * nb[3];
         }
-        const float P00 = near_b ? 0.0f : (float)ADX[bk], P01 = near_b ? 0.0f : (float)ADY[bk],
-                    P11 = near_b ? 0.0f : (float)ARX[bk], PW = near_b ? 0.0f : (float)ARY[bk];
-        const float hx = hc[3 * bk], hy = hc[3 * bk + 1];
-        hc[3 * bk] = P00 * hx + P01 * hy;
-        hc[3 * bk + 1] = P01 * hx + P11 * hy;
-        hc[3 * bk + 2] *= PW;
       }
       if (lane < kVars) {
 #pragma unroll
@@ -912,19 +922,22 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
 #pragma unroll
         for (int q = 0; q < kVars; ++q) hc[q] = 0.0f;
       }
+      {
+        // row kq of I - P of this lane's block
+        const float p00 = own[0], p01 = own[1], p11 = own[2], pw = own[3];
+        const float a0 = kq == 0 ? 1.0f - p00 : kq == 1 ? -p01 : 0.0f;
+        const float a1 = kq == 0 ? -p01 : kq == 1 ? 1.0f - p11 : 0.0f;
+        const float a2 = kq == 2 ? 1.0f - pw : 0.0f;
 #pragma unroll
-      for (int bk = 0; bk < kRegSteps; ++bk) {
-        const bool near_b = AMODE[4 * bk + 2] != 0;
-        const float P00 = near_b ? 0.0f : (float)ADX[bk], P01 = near_b ? 0.0f : (float)ADY[bk],
-                    P11 = near_b ? 0.0f : (float)ARX[bk], PW = near_b ? 0.0f : (float)ARY[bk];
-        const float hx = hc[3 * bk], hy = hc[3 * bk + 1];
-        hc[3 * bk] = hx * P00 + hy * P01;
-        hc[3 * bk + 1] = hx * P01 + hy * P11;
-        hc[3 * bk + 2] *= PW;
-        const int r = lane - 3 * bk;  // + (I - P) on the diagonal block
-        if (r == 0) { hc[3 * bk] += 1.0f - P00; hc[3 * bk + 1] -= P01; diag = hc[3 * bk]; }
-        if (r == 1) { hc[3 * bk] -= P01; hc[3 * bk + 1] += 1.0f - P11; diag = hc[3 * bk + 1]; }
-        if (r == 2) { hc[3 * bk + 2] += 1.0f - PW; diag = hc[3 * bk + 2]; }
+        for (int bk = 0; bk < kRegSteps; ++bk) {
+          const float* nb = NB + kNewtonRecord * bk;
+          const bool mine = lane < kVars && kb == bk;
+          const float hx = hc[3 * bk], hy = hc[3 * bk + 1];
+          hc[3 * bk] = hx * nb[0] + hy * nb[1] + (mine ? a0 : 0.0f);
+          hc[3 * bk + 1] = hx * nb[1] + hy * nb[2] + (mine ? a1 : 0.0f);
+          hc[3 * bk + 2] = hc[3 * bk + 2] * nb[3] + (mine ? a2 : 0.0f);
+          if (mine) diag = kq == 0 ? hc[3 * bk] : kq == 1 ? hc[3 * bk + 1] : hc[3 * bk + 2];
+        }
       }
       const float deltaf = fmaxf(1e-6f * wave_max_f(fabsf(diag)), 1e-30f);
       float pinvf[kVars];
