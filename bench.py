@@ -28,6 +28,7 @@ if ROOT not in sys.path:
 
 # BASELINE.md "Algorithmic bytes per solve": inputs (17+3N)*4 + outputs (3+3N+1)*4 + reach tile 729
 ALGO_BYTES = {3: 885, 8: 1005, 32: 1581}
+SIMD_CLOCK_GHZ = 2.4   # MI355X peak engine clock (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -191,13 +192,16 @@ def main():
         value = total_instances * args.steps / elapsed
         k_ms = float(np.mean(kernel_ms))
         achieved = ALGO_BYTES[n] * cfg["batch"] / (k_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = valu = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.workload)
+                prof = json.load(open(tpath))
+                if cfg["batch"] == synthetic.CONFIGS[args.workload]["batch"]:   # the PMC passes ran at the config's batch
+                    traffic = prof.get(args.workload)
+                    valu = prof.get(args.workload + "_valu_insts")
             except Exception:
-                traffic = None
+                traffic = valu = None
         out = {
             "metric": "MPC solves/sec (control_steps=%d, %dx%d costmap)" % (n, cfg["map_size"], cfg["map_size"]),
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -212,6 +216,11 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_solve", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_solve": ALGO_BYTES[n]},
+            # what actually bounds K1: VALU issue.  SQ_INSTS_VALU of the committed PMC
+            # pass x 4 cycles (a wave64 instruction on a 16-lane SIMD) over 1024 SIMDs x this run's kernel time
+            "valu_issue": None if not valu else {
+                "insts_per_launch": valu, "cycles_per_inst": 4, "simds": 1024, "clock_ghz": SIMD_CLOCK_GHZ,
+                "frac": valu * 4 / (1024 * k_ms * 1e-3 * SIMD_CLOCK_GHZ * 1e9)},
             "solver": {"mean_iterations": float(cmds["iterations"].mean()),
                        "converged_frac": float((cmds["status"] == 0).mean())},
         }
