@@ -1,0 +1,90 @@
+// costmap.h -- costmap lookups: world -> cell, bordered device map, LDS reach tile, footprint raster
+// Part of libneo_mpc.so's device code (included by neo_mpc_kernels.hip only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "neo_mpc_device.h"
+#include "wave_ops.h"
+#include "solver_context.h"
+
+namespace neo_mpc {
+namespace {
+
+// ---------------------------------------------------------------- costmap
+// floor((w - origin) / resolution): multiply by the reciprocal, redo with the exact division
+// only when the quotient sits on a cell edge, so the result always equals the division's.
+__device__ __forceinline__ int cell_of(double w, double origin, double res, double inv) {
+  double t = w - origin;
+  double q = t * inv;
+  double fl = floor(q);
+  if (fabs(q - rint(q)) < 1e-6) fl = floor(t / res);
+  // v_cvt_i32_f64 saturates (and maps NaN to 0) in hardware; spelled as an instruction because the
+  // C conversion of an out-of-range value is undefined -- saturated indices fall outside every map
+  // and read as lethal, like the +-1e9 clamp this replaces (three instructions cheaper per lookup)
+  int cell;
+  asm("v_cvt_i32_f64 %0, %1" : "=v"(cell) : "v"(fl));
+  return cell;
+}
+
+__device__ __forceinline__ int map_raw(const DevMap& m, int mx, int my) {
+  if (mx < -kMapBorder || my < -kMapBorder || mx >= m.size_x + kMapBorder || my >= m.size_y + kMapBorder)
+    return 254;  // contract: out of bounds is lethal
+  return m.cells[(long)my * m.pitch + mx];
+}
+
+// normalised cost of a raw cell: nav2 occupancy translation / 100 (build's costmap contract)
+__device__ __forceinline__ int raw_occupancy(int raw) {
+  return raw == 0 ? 0 : raw == 253 ? 99 : raw == 254 ? 100 : raw == 255 ? -1 : 1 + (97 * (raw - 1)) / 251;
+}
+__device__ __forceinline__ double raw_cost(int raw) { return (double)raw_occupancy(raw) / 100.0; }
+
+__device__ __forceinline__ double step_term(const SolveArgs& a, const Ctx& c, const double* L, double x, double y) {
+  const double X = c.X0 + (c.c0 * x - c.s0 * y), Y = c.Y0 + (c.s0 * x + c.c0 * y);
+  const int mx = cell_of(X, a.map.origin_x, a.map.resolution, a.map.inv_resolution);
+  const int my = cell_of(Y, a.map.origin_y, a.map.resolution, a.map.inv_resolution);
+  const unsigned tx = (unsigned)(mx - c.tile_x0), ty = (unsigned)(my - c.tile_y0);
+  int raw;
+  if (tx < (unsigned)a.lds.tile_w && ty < (unsigned)a.lds.tile_h)
+    raw = reinterpret_cast<const uint8_t*>(L + a.lds.tile)[ty * a.lds.tile_w + tx];
+  else
+    raw = map_raw(a.map, mx, my);
+  return L[a.lds.term + raw];
+}
+
+// Bresenham outline cost of one polygon edge (end points inclusive)
+__device__ double edge_cost(const DevMap& m, double ax, double ay, double bx, double by) {
+  int x0 = cell_of(ax, m.origin_x, m.resolution, m.inv_resolution);
+  int y0 = cell_of(ay, m.origin_y, m.resolution, m.inv_resolution);
+  const int x1 = cell_of(bx, m.origin_x, m.resolution, m.inv_resolution);
+  const int y1 = cell_of(by, m.origin_y, m.resolution, m.inv_resolution);
+  const long dx = labs((long)x1 - x0), dy = labs((long)y1 - y0);
+  const int sx = x1 >= x0 ? 1 : -1, sy = y1 >= y0 ? 1 : -1;
+  long err = dx - dy;
+  double worst = -1.0;
+  for (long guard = 0; guard <= dx + dy + 1; ++guard) {
+    worst = fmax(worst, raw_cost(map_raw(m, x0, y0)));
+    if (x0 == x1 && y0 == y1) break;
+    long e2 = 2 * err;
+    if (e2 > -dy) { err -= dy; x0 += sx; }
+    if (e2 < dx) { err += dx; y0 += sy; }
+  }
+  return worst;
+}
+
+// getFootprintCost of the published footprint (py:343): lanes take edges, wave max
+__device__ double footprint_cost(const SolveArgs& a, const double* L, uint32_t b, int lane) {
+  if (!a.footprints || a.footprint_points == 0) return L[a.lds.prob + P_FOOTPRINT];
+  const int np = (int)a.footprint_points;
+  const double* pts = a.footprints + (size_t)b * 2 * np;
+  double worst = -1.0;
+  for (int e = lane; e < np; e += kLanes) {
+    int j = (e + 1) % np;
+    worst = fmax(worst, edge_cost(a.map, pts[2 * e], pts[2 * e + 1], pts[2 * j], pts[2 * j + 1]));
+  }
+  return wave_max(worst);
+}
+
+}  // namespace
+}  // namespace neo_mpc

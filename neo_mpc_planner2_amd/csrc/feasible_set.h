@@ -1,0 +1,87 @@
+// feasible_set.h -- projection onto box x disc and the 64 candidates of one iteration
+// Part of libneo_mpc.so's device code (included by neo_mpc_kernels.hip only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "neo_mpc_device.h"
+#include "fast_math.h"
+#include "solver_context.h"
+
+namespace neo_mpc {
+namespace {
+
+// ---------------------------------------------------------------- feasible set
+__device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Euclidean projection of (vx, vy) onto box ∩ disc; omega clamped (py:125-134, 157-158)
+// kTame: the caller knows at compile time that the disc lies inside the vx/vy box (DevParams.tame)
+template <bool kTame = false>
+__device__ __forceinline__ void project_block(const DevParams& p, double& b0, double& b1, double& b2) {
+  b2 = clampd(b2, p.lo[2], p.hi[2]);
+  const double zx = b0, zy = b1, r = p.r;
+  if (kTame || p.disc_in_box) {  // README parameters: the box never binds, the projection is radial
+    const double n2 = zx * zx + zy * zy;
+    if (n2 > r * r) { const double sc = r * rsq_fast(n2); b0 = zx * sc; b1 = zy * sc; }
+    return;
+  }
+  const double px = clampd(zx, p.lo[0], p.hi[0]), py = clampd(zy, p.lo[1], p.hi[1]);
+  if (px * px + py * py <= r * r) { b0 = px; b1 = py; return; }
+  const double nz = sqrt(zx * zx + zy * zy);
+  const double qx = zx * (r / nz), qy = zy * (r / nz);
+  if (qx >= p.lo[0] && qx <= p.hi[0] && qy >= p.lo[1] && qy <= p.hi[1]) { b0 = qx; b1 = qy; return; }
+  double best = INFINITY, bx = px, by = py;  // both bind: closest circle / box-edge intersection
+  for (int e = 0; e < 4; ++e) {
+    const double fixed = (e == 0) ? p.lo[0] : (e == 1) ? p.hi[0] : (e == 2) ? p.lo[1] : p.hi[1];
+    if (fabs(fixed) > r) continue;
+    const double o = sqrt(r * r - fixed * fixed);
+    for (int s = -1; s <= 1; s += 2) {
+      const double ex = (e < 2) ? fixed : s * o, ey = (e < 2) ? s * o : fixed;
+      if (ex < p.lo[0] || ex > p.hi[0] || ey < p.lo[1] || ey > p.hi[1]) continue;
+      const double dd = (ex - zx) * (ex - zx) + (ey - zy) * (ey - zy);
+      if (dd < best) { best = dd; bx = ex; by = ey; }
+    }
+  }
+  b0 = bx; b1 = by;
+}
+
+// candidate step multipliers: lanes 0..31 scale the proximal-gradient step by 2^(-12 + l/2),
+// lanes 32..63 are step lengths along the L-BFGS direction
+__constant__ double kQnSteps[32] = {
+    1.0, 0.84, 1.19, 0.71, 1.41, 0.59, 1.68, 0.5, 2.0, 0.42, 2.38, 0.35, 2.83, 0.25, 4.0, 0.177,
+    0.125, 0.088, 0.0625, 0.044, 0.03125, 0.0156, 0.0078, 0.0039, 0.00195, 0.00098, 4.9e-4, 2.4e-4,
+    1.2e-4, 6e-5, 3e-5, 1.5e-5};
+
+__device__ __forceinline__ double lane_scale(int lane) {
+  if (lane >= 32) return kQnSteps[lane - 32];
+  double s = ldexp(1.0, -12 + (lane >> 1));
+  return (lane & 1) ? s * 1.4142135623730951 : s;
+}
+
+// control block i of this lane's candidate
+// (`step`: this lane's step along its own family; `pstep`: its proximal-gradient step length, used
+// by the L-BFGS lanes for blocks sitting next to the control-norm kink)
+template <bool kTame = false>
+__device__ __forceinline__ void candidate_block(const SolveArgs& a, const Ctx& c, const double* L, int lane,
+                                                double step, double pstep, int i, double& b0, double& b1,
+                                                double& b2) {
+  const double* u = L + a.lds.u + 3 * i;
+  const bool near = reinterpret_cast<const int*>(L + a.lds.mode)[4 * i + 2] != 0;
+  if (lane < 32 || near) {  // proximal gradient: forward step on the smooth part, prox of the control norm
+    if (lane >= 32) step = pstep;
+    const double* gs = L + a.lds.gs + 3 * i;
+    const double e0 = (u[0] - step * gs[0]) - c.v0, e1 = (u[1] - step * gs[1]) - c.v1,
+                 e2 = (u[2] - step * gs[2]) - c.v2;
+    const double ne2 = e0 * e0 + e1 * e1 + e2 * e2;
+    const double sh = (ne2 > 0.0) ? fmax(0.0, 1.0 - step * a.p.wc_n * rsq_fast(ne2)) : 0.0;
+    b0 = c.v0 + sh * e0; b1 = c.v1 + sh * e1; b2 = c.v2 + sh * e2;
+  } else {          // quasi-Newton direction
+    const double* d = L + a.lds.d + 3 * i;
+    b0 = u[0] + step * d[0]; b1 = u[1] + step * d[1]; b2 = u[2] + step * d[2];
+  }
+  project_block<kTame>(a.p, b0, b1, b2);
+}
+
+}  // namespace
+}  // namespace neo_mpc

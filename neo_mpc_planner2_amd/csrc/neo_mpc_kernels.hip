@@ -33,558 +33,19 @@
 #include <stdlib.h>
 
 #include "neo_mpc_device.h"
+#include "wave_ops.h"
+#include "fast_math.h"
+#include "solver_context.h"
+#include "costmap.h"
+#include "feasible_set.h"
+#include "rollout.h"
 
 namespace neo_mpc {
 namespace {
 
-#define WAVE_SYNC() __syncthreads()
-
 // consecutive iterations gaining less than ftol*max(1,|f|) or moving less than stall_step that end
 // the search (creeping along a costmap cell edge gains ~1e-9 per iteration for ever)
 constexpr int kStallIterations = 5;
-
-// ---------------------------------------------------------------- wave primitives
-// Cross-lane reductions on the DPP network (row_shr within the 16-lane rows, row_bcast across
-// rows), not through LDS (`__shfl` lowers to ds_bpermute, ~100 cycles per hop): the L-BFGS
-// recursion is a chain of dependent dot products, so the reduction latency is on the critical path.
-template <int kCtrl, int kRowMask, bool kZeroFill>
-__device__ __forceinline__ double dpp_move(double v, double fill) {
-  const int lo = __double2loint(v), hi = __double2hiint(v);
-  const int flo = __double2loint(fill), fhi = __double2hiint(fill);
-  const int rlo = __builtin_amdgcn_update_dpp(flo, lo, kCtrl, kRowMask, 0xf, kZeroFill);
-  const int rhi = __builtin_amdgcn_update_dpp(fhi, hi, kCtrl, kRowMask, 0xf, kZeroFill);
-  return __hiloint2double(rhi, rlo);
-}
-__device__ __forceinline__ double lane_value(double v, int lane) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
-                          __builtin_amdgcn_readlane(__double2loint(v), lane));
-}
-// every lane returns the sum over the 64 lanes (bitwise identical in all lanes)
-__device__ __forceinline__ double wave_sum(double v) {
-  v += dpp_move<0x111, 0xf, true>(v, 0.0);  // row_shr:1
-  v += dpp_move<0x112, 0xf, true>(v, 0.0);  // row_shr:2
-  v += dpp_move<0x114, 0xf, true>(v, 0.0);  // row_shr:4
-  v += dpp_move<0x118, 0xf, true>(v, 0.0);  // row_shr:8   -> lane 15 of each row: row sum
-  v += dpp_move<0x142, 0xa, false>(v, 0.0); // row_bcast:15 into rows 1 and 3
-  v += dpp_move<0x143, 0xc, false>(v, 0.0); // row_bcast:31 into rows 2 and 3 -> lane 63: total
-  return lane_value(v, 63);
-}
-// inclusive prefix sum over the lanes (lane i: sum of lanes 0..i) -- the same DPP ladder as wave_sum
-__device__ __forceinline__ double wave_scan(double v) {
-  v += dpp_move<0x111, 0xf, true>(v, 0.0);
-  v += dpp_move<0x112, 0xf, true>(v, 0.0);
-  v += dpp_move<0x114, 0xf, true>(v, 0.0);
-  v += dpp_move<0x118, 0xf, true>(v, 0.0);
-  v += dpp_move<0x142, 0xa, false>(v, 0.0);
-  v += dpp_move<0x143, 0xc, false>(v, 0.0);
-  return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-  v = fmax(v, dpp_move<0x111, 0xf, false>(v, v));
-  v = fmax(v, dpp_move<0x112, 0xf, false>(v, v));
-  v = fmax(v, dpp_move<0x114, 0xf, false>(v, v));
-  v = fmax(v, dpp_move<0x118, 0xf, false>(v, v));
-  v = fmax(v, dpp_move<0x142, 0xa, false>(v, v));
-  v = fmax(v, dpp_move<0x143, 0xc, false>(v, v));
-  return lane_value(v, 63);
-}
-__device__ __forceinline__ double wave_min(double v) { return -wave_max(-v); }
-// maximum of non-negative float32 values (step lengths, pivots: compared against tolerances, single
-// precision is plenty): one DPP-fused v_max_f32 per hop instead of two moves and a 64-bit max
-template <int kCtrl, int kRowMask>
-__device__ __forceinline__ float dpp_move_f(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v),
-                                                              kCtrl, kRowMask, 0xf, false));
-}
-__device__ __forceinline__ float wave_max_f(float v) {
-  v = fmaxf(v, dpp_move_f<0x111, 0xf>(v));
-  v = fmaxf(v, dpp_move_f<0x112, 0xf>(v));
-  v = fmaxf(v, dpp_move_f<0x114, 0xf>(v));
-  v = fmaxf(v, dpp_move_f<0x118, 0xf>(v));
-  v = fmaxf(v, dpp_move_f<0x142, 0xa>(v));
-  v = fmaxf(v, dpp_move_f<0x143, 0xc>(v));
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
-// lowest value, ties to the lowest lane; every lane returns the same pair
-__device__ __forceinline__ void wave_argmin(double& v, int& idx) {
-  const double m = wave_min(v);
-  const unsigned long long hit = __ballot(v == m);
-  idx = (int)__ffsll((long long)hit) - 1;
-  v = m;
-}
-__device__ __forceinline__ int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-// ---------------------------------------------------------------- problem record indices (doubles)
-enum : int {
-  P_CUR_X = 0, P_CUR_Y = 1, P_CUR_Q = 2, P_CARROT_X = 6, P_CARROT_Y = 7, P_CARROT_Q = 8,
-  P_GOAL = 12, P_GOAL_Q = 15, P_VEL = 19, P_INTERVAL = 22, P_DELTA_T = 23, P_FOOTPRINT = 24,
-  S_LAST = 0, S_OLD_GOAL = 3, S_WAIT = 10, SI_HAS_GOAL = 22, SI_COLLISION = 23, SI_COLL_FP = 24
-};
-
-struct Ctx {
-  double cx, cy, tyaw, fyaw, c0, s0, X0, Y0, v0, v1, v2, konst, true_yaw;
-  int tile_x0, tile_y0;
-};
-
-// sin and cos of a moderate argument: three-term Cody-Waite reduction by pi/2 (exact products for
-// |x| < 1e6) and the degree-13/14 minimax kernels on [-pi/4, pi/4]; ~40 f64 operations, no
-// table, no branch, no call -- the library sincos carries a Payne-Hanek path the rollout never needs.
-// 1/x by v_rcp_f64 and two Newton steps (error ~1 ulp, no scaling/fix-up for denormals or
-// infinities): used where only a search direction or a unit vector depends on it
-__device__ __forceinline__ double rcp_fast(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = fma(fma(-x, r, 1.0), r, r);
-  r = fma(fma(-x, r, 1.0), r, r);
-  return r;
-}
-
-// 1/sqrt(x), x > 0: v_rsq_f64 and two Newton steps
-__device__ __forceinline__ double rsq_fast(double x) {
-  double r = __builtin_amdgcn_rsq(x);
-  r = r * fma(fma(-x * r, r, 1.0), 0.5, 1.0);
-  r = r * fma(fma(-x * r, r, 1.0), 0.5, 1.0);
-  return r;
-}
-
-// sqrt(x), x >= 0 and not huge: v_rsq_f64, one coupled Goldschmidt step and one residual correction.
-// Measured on gfx950 against the correctly rounded root (tools/sqrt_check.hip, 4 M arguments over
-// 2^-300..2^300): identical except 1 ulp on a denormal; 11 operations where the library's
-// sequence (input scaling, a second correction, class test) takes 18.
-__device__ __forceinline__ double sqrt_fast(double x) {
-  const double y = __builtin_amdgcn_rsq(x);
-  double g = x * y, h = 0.5 * y;
-  const double r = fma(-h, g, 0.5);
-  g = fma(g, r, g);
-  h = fma(h, r, h);
-  g = fma(fma(-g, g, x), h, g);
-  return x > 0.0 ? g : 0.0;
-}
-
-__device__ __forceinline__ void sincos_fast(double x, double* sn, double* cs) {
-  // (|x| beyond ~1e6 -- never produced by a feasible rollout, |theta| <= max_vel_theta * horizon
-  // plus a yaw -- only loses accuracy; a non-finite x gives NaN, which the arc search discards)
-  const double k = rint(x * 6.36619772367581382433e-01);
-  double r = fma(-k, 1.57079632673412561417e+00, x);
-  r = fma(-k, 6.07710050630396597660e-11, r);
-  r = fma(-k, 2.02226624879595063154e-21, r);
-  const double z = r * r;
-  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-  ps = fma(z, ps, 2.75573137070700676789e-06);
-  ps = fma(z, ps, -1.98412698298579493134e-04);
-  ps = fma(z, ps, 8.33333333332248946124e-03);
-  ps = fma(z, ps, -1.66666666666666324348e-01);
-  const double sr = fma(z * r, ps, r);
-  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-  pc = fma(z, pc, -2.75573143513906633035e-07);
-  pc = fma(z, pc, 2.48015872894767294178e-05);
-  pc = fma(z, pc, -1.38888888888741095749e-03);
-  pc = fma(z, pc, 4.16666666666666019037e-02);
-  const double cr = fma(z * z, pc, fma(z, -0.5, 1.0));
-  const int q = (int)fmin(fmax(k, -2.0e9), 2.0e9) & 3;
-  const double s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
-  *sn = (q & 2) ? -s0 : s0;
-  *cs = ((q + 1) & 2) ? -c0 : c0;
-}
-
-// The same two kernels without the reduction, for |x| <= pi/4: 17 operations.  The rollout's heading
-// never leaves that range when max|omega| * prediction_horizon <= 0.78 (DevParams.tame; 0.56 with
-// the README's parameters).
-__device__ __forceinline__ void sincos_small(double r, double* sn, double* cs) {
-  const double z = r * r;
-  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-  ps = fma(z, ps, 2.75573137070700676789e-06);
-  ps = fma(z, ps, -1.98412698298579493134e-04);
-  ps = fma(z, ps, 8.33333333332248946124e-03);
-  ps = fma(z, ps, -1.66666666666666324348e-01);
-  *sn = fma(z * r, ps, r);
-  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-  pc = fma(z, pc, -2.75573143513906633035e-07);
-  pc = fma(z, pc, 2.48015872894767294178e-05);
-  pc = fma(z, pc, -1.38888888888741095749e-03);
-  pc = fma(z, pc, 4.16666666666666019037e-02);
-  *cs = fma(z * z, pc, fma(z, -0.5, 1.0));
-}
-template <bool kTame>
-__device__ __forceinline__ void sincos_heading(double th, double* sn, double* cs) {
-  if (kTame) sincos_small(th, sn, cs);
-  else sincos_fast(th, sn, cs);
-}
-
-// py:176-178
-__device__ __forceinline__ double yaw_of(const double* q) {
-  double t3 = 2.0 * (q[3] * q[2] + q[0] * q[1]);
-  double t4 = 1.0 - 2.0 * (q[1] * q[1] + q[2] * q[2]);
-  return atan2(t3, t4);
-}
-
-// ---------------------------------------------------------------- costmap
-// floor((w - origin) / resolution): multiply by the reciprocal, redo with the exact division
-// only when the quotient sits on a cell edge, so the result always equals the division's.
-__device__ __forceinline__ int cell_of(double w, double origin, double res, double inv) {
-  double t = w - origin;
-  double q = t * inv;
-  double fl = floor(q);
-  if (fabs(q - rint(q)) < 1e-6) fl = floor(t / res);
-  // v_cvt_i32_f64 saturates (and maps NaN to 0) in hardware; spelled as an instruction because the
-  // C conversion of an out-of-range value is undefined -- saturated indices fall outside every map
-  // and read as lethal, like the +-1e9 clamp this replaces (three instructions cheaper per lookup)
-  int cell;
-  asm("v_cvt_i32_f64 %0, %1" : "=v"(cell) : "v"(fl));
-  return cell;
-}
-
-__device__ __forceinline__ int map_raw(const DevMap& m, int mx, int my) {
-  if (mx < -kMapBorder || my < -kMapBorder || mx >= m.size_x + kMapBorder || my >= m.size_y + kMapBorder)
-    return 254;  // contract: out of bounds is lethal
-  return m.cells[(long)my * m.pitch + mx];
-}
-
-// normalised cost of a raw cell: nav2 occupancy translation / 100 (build's costmap contract)
-__device__ __forceinline__ int raw_occupancy(int raw) {
-  return raw == 0 ? 0 : raw == 253 ? 99 : raw == 254 ? 100 : raw == 255 ? -1 : 1 + (97 * (raw - 1)) / 251;
-}
-__device__ __forceinline__ double raw_cost(int raw) { return (double)raw_occupancy(raw) / 100.0; }
-
-__device__ __forceinline__ double step_term(const SolveArgs& a, const Ctx& c, const double* L, double x, double y) {
-  const double X = c.X0 + (c.c0 * x - c.s0 * y), Y = c.Y0 + (c.s0 * x + c.c0 * y);
-  const int mx = cell_of(X, a.map.origin_x, a.map.resolution, a.map.inv_resolution);
-  const int my = cell_of(Y, a.map.origin_y, a.map.resolution, a.map.inv_resolution);
-  const unsigned tx = (unsigned)(mx - c.tile_x0), ty = (unsigned)(my - c.tile_y0);
-  int raw;
-  if (tx < (unsigned)a.lds.tile_w && ty < (unsigned)a.lds.tile_h)
-    raw = reinterpret_cast<const uint8_t*>(L + a.lds.tile)[ty * a.lds.tile_w + tx];
-  else
-    raw = map_raw(a.map, mx, my);
-  return L[a.lds.term + raw];
-}
-
-// Bresenham outline cost of one polygon edge (end points inclusive)
-__device__ double edge_cost(const DevMap& m, double ax, double ay, double bx, double by) {
-  int x0 = cell_of(ax, m.origin_x, m.resolution, m.inv_resolution);
-  int y0 = cell_of(ay, m.origin_y, m.resolution, m.inv_resolution);
-  const int x1 = cell_of(bx, m.origin_x, m.resolution, m.inv_resolution);
-  const int y1 = cell_of(by, m.origin_y, m.resolution, m.inv_resolution);
-  const long dx = labs((long)x1 - x0), dy = labs((long)y1 - y0);
-  const int sx = x1 >= x0 ? 1 : -1, sy = y1 >= y0 ? 1 : -1;
-  long err = dx - dy;
-  double worst = -1.0;
-  for (long guard = 0; guard <= dx + dy + 1; ++guard) {
-    worst = fmax(worst, raw_cost(map_raw(m, x0, y0)));
-    if (x0 == x1 && y0 == y1) break;
-    long e2 = 2 * err;
-    if (e2 > -dy) { err -= dy; x0 += sx; }
-    if (e2 < dx) { err += dx; y0 += sy; }
-  }
-  return worst;
-}
-
-// getFootprintCost of the published footprint (py:343): lanes take edges, wave max
-__device__ double footprint_cost(const SolveArgs& a, const double* L, uint32_t b, int lane) {
-  if (!a.footprints || a.footprint_points == 0) return L[a.lds.prob + P_FOOTPRINT];
-  const int np = (int)a.footprint_points;
-  const double* pts = a.footprints + (size_t)b * 2 * np;
-  double worst = -1.0;
-  for (int e = lane; e < np; e += kLanes) {
-    int j = (e + 1) % np;
-    worst = fmax(worst, edge_cost(a.map, pts[2 * e], pts[2 * e + 1], pts[2 * j], pts[2 * j + 1]));
-  }
-  return wave_max(worst);
-}
-
-// ---------------------------------------------------------------- feasible set
-__device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
-
-// Euclidean projection of (vx, vy) onto box ∩ disc; omega clamped (py:125-134, 157-158)
-// kTame: the caller knows at compile time that the disc lies inside the vx/vy box (DevParams.tame)
-template <bool kTame = false>
-__device__ __forceinline__ void project_block(const DevParams& p, double& b0, double& b1, double& b2) {
-  b2 = clampd(b2, p.lo[2], p.hi[2]);
-  const double zx = b0, zy = b1, r = p.r;
-  if (kTame || p.disc_in_box) {  // README parameters: the box never binds, the projection is radial
-    const double n2 = zx * zx + zy * zy;
-    if (n2 > r * r) { const double sc = r * rsq_fast(n2); b0 = zx * sc; b1 = zy * sc; }
-    return;
-  }
-  const double px = clampd(zx, p.lo[0], p.hi[0]), py = clampd(zy, p.lo[1], p.hi[1]);
-  if (px * px + py * py <= r * r) { b0 = px; b1 = py; return; }
-  const double nz = sqrt(zx * zx + zy * zy);
-  const double qx = zx * (r / nz), qy = zy * (r / nz);
-  if (qx >= p.lo[0] && qx <= p.hi[0] && qy >= p.lo[1] && qy <= p.hi[1]) { b0 = qx; b1 = qy; return; }
-  double best = INFINITY, bx = px, by = py;  // both bind: closest circle / box-edge intersection
-  for (int e = 0; e < 4; ++e) {
-    const double fixed = (e == 0) ? p.lo[0] : (e == 1) ? p.hi[0] : (e == 2) ? p.lo[1] : p.hi[1];
-    if (fabs(fixed) > r) continue;
-    const double o = sqrt(r * r - fixed * fixed);
-    for (int s = -1; s <= 1; s += 2) {
-      const double ex = (e < 2) ? fixed : s * o, ey = (e < 2) ? s * o : fixed;
-      if (ex < p.lo[0] || ex > p.hi[0] || ey < p.lo[1] || ey > p.hi[1]) continue;
-      const double dd = (ex - zx) * (ex - zx) + (ey - zy) * (ey - zy);
-      if (dd < best) { best = dd; bx = ex; by = ey; }
-    }
-  }
-  b0 = bx; b1 = by;
-}
-
-// candidate step multipliers: lanes 0..31 scale the proximal-gradient step by 2^(-12 + l/2),
-// lanes 32..63 are step lengths along the L-BFGS direction
-__constant__ double kQnSteps[32] = {
-    1.0, 0.84, 1.19, 0.71, 1.41, 0.59, 1.68, 0.5, 2.0, 0.42, 2.38, 0.35, 2.83, 0.25, 4.0, 0.177,
-    0.125, 0.088, 0.0625, 0.044, 0.03125, 0.0156, 0.0078, 0.0039, 0.00195, 0.00098, 4.9e-4, 2.4e-4,
-    1.2e-4, 6e-5, 3e-5, 1.5e-5};
-
-__device__ __forceinline__ double lane_scale(int lane) {
-  if (lane >= 32) return kQnSteps[lane - 32];
-  double s = ldexp(1.0, -12 + (lane >> 1));
-  return (lane & 1) ? s * 1.4142135623730951 : s;
-}
-
-// control block i of this lane's candidate
-// (`step`: this lane's step along its own family; `pstep`: its proximal-gradient step length, used
-// by the L-BFGS lanes for blocks sitting next to the control-norm kink)
-template <bool kTame = false>
-__device__ __forceinline__ void candidate_block(const SolveArgs& a, const Ctx& c, const double* L, int lane,
-                                                double step, double pstep, int i, double& b0, double& b1,
-                                                double& b2) {
-  const double* u = L + a.lds.u + 3 * i;
-  const bool near = reinterpret_cast<const int*>(L + a.lds.mode)[4 * i + 2] != 0;
-  if (lane < 32 || near) {  // proximal gradient: forward step on the smooth part, prox of the control norm
-    if (lane >= 32) step = pstep;
-    const double* gs = L + a.lds.gs + 3 * i;
-    const double e0 = (u[0] - step * gs[0]) - c.v0, e1 = (u[1] - step * gs[1]) - c.v1,
-                 e2 = (u[2] - step * gs[2]) - c.v2;
-    const double ne2 = e0 * e0 + e1 * e1 + e2 * e2;
-    const double sh = (ne2 > 0.0) ? fmax(0.0, 1.0 - step * a.p.wc_n * rsq_fast(ne2)) : 0.0;
-    b0 = c.v0 + sh * e0; b1 = c.v1 + sh * e1; b2 = c.v2 + sh * e2;
-  } else {          // quasi-Newton direction
-    const double* d = L + a.lds.d + 3 * i;
-    b0 = u[0] + step * d[0]; b1 = u[1] + step * d[1]; b2 = u[2] + step * d[2];
-  }
-  project_block<kTame>(a.p, b0, b1, b2);
-}
-
-// rollout + cost of one control sequence (py:224-268); Block(i, b0, b1, b2) yields the controls
-struct NoRecord {
-  __device__ __forceinline__ void operator()(int, double, double) const {}
-};
-// kSteps > 0: control_steps known at compile time (loops unroll); Record(i, sin, cos) lets the caller
-// keep the rollout's trigonometry (the winner's is reused by the next adjoint sweep)
-template <int kSteps = 0, bool kTame = false, class Block, class Record = NoRecord>
-__device__ __forceinline__ double rollout_cost(const SolveArgs& a, const Ctx& c, const double* L, Block block,
-                                               Record record = Record()) {
-  const DevParams& p = a.p;
-  const int n = kSteps ? kSteps : p.n;
-  double f = 0.0, x = 0.0, y = 0.0, th = 0.0;
-#pragma unroll
-  for (int i = 0; i < n; ++i) {
-    double vx, vy, w;
-    block(i, vx, vy, w);
-    th += w * p.dt;                                     // py:230
-    double sn, cs;
-    sincos_heading<kTame>(th, &sn, &cs);
-    record(i, sn, cs);
-    x += (vx * cs - vy * sn) * p.dt;                    // py:231
-    y += (vx * sn + vy * cs) * p.dt;                    // py:232
-    const double dx = c.cx - x, dy = c.cy - y, et = c.tyaw - th;
-    const double e0 = c.v0 - vx, e1 = c.v1 - vy, e2 = c.v2 - w;
-    f += p.wt_n * (dx * dx + dy * dy) + p.wo_n * (et * et);   // py:252
-    f += p.wc_n * sqrt_fast(e0 * e0 + e1 * e1 + e2 * e2);      // py:253-254
-    f += step_term(a, c, L, x, y);                             // py:246-247, 257-260
-  }
-  const double et = c.fyaw - th;
-  return f + p.wterm_o * (et * et) + c.konst;                  // py:266-268
-}
-
-// ---------------------------------------------------------------- set-up shared by the kernels
-__device__ void load_term_table(const double* table, double* L, int term, int lane) {
-  for (int k = lane; k < 256; k += kLanes) L[term + k] = table[k];
-}
-
-__device__ void make_ctx(const DevParams& p, const DevMap& m, const double* P, double fcost, Ctx& c) {
-  c.cx = P[P_CARROT_X]; c.cy = P[P_CARROT_Y];
-  c.tyaw = yaw_of(P + P_CARROT_Q);                       // py:211
-  c.fyaw = yaw_of(P + P_GOAL_Q);                         // py:212
-  double q[4] = {P[P_CUR_Q], P[P_CUR_Q + 1], P[P_CUR_Q + 2],
-                 (p.compat & NEO_MPC_COMPAT_ODOM_YAW_GOAL_W) ? P[P_GOAL_Q + 3] : P[P_CUR_Q + 3]};
-  const double psi0 = yaw_of(q);                          // py:213 (goal's w: reference quirk)
-  sincos_fast(psi0, &c.s0, &c.c0);
-  c.true_yaw = yaw_of(P + P_CUR_Q);                      // py:317
-  c.X0 = P[P_CUR_X]; c.Y0 = P[P_CUR_Y];
-  c.v0 = P[P_VEL]; c.v1 = P[P_VEL + 1]; c.v2 = P[P_VEL + 2];
-  const double gdx = c.cx - P[P_GOAL], gdy = c.cy - P[P_GOAL + 1];
-  c.konst = p.wterm_t * (gdx * gdx + gdy * gdy);          // py:266, 268: constant in u
-  if (fcost == 1.0) c.konst += p.w_footprint;             // py:262-263: N steps * w_footprint/N
-  c.tile_x0 = 0; c.tile_y0 = 0;
-}
-
-// make_ctx for the wave-per-instance kernels: the four yaw extractions run side by side in lanes
-// 0-3 (one atan2 instead of four); every lane leaves with the same wave-uniform values
-__device__ void make_ctx_wave(const DevParams& p, const DevMap& m, const double* P, double fcost, Ctx& c, int lane) {
-  // lane 0: carrot (py:211), 1: goal (py:212), 2: current pose with the goal's w (py:213), 3: current pose (py:317)
-  const int base = lane == 0 ? P_CARROT_Q : lane == 1 ? P_GOAL_Q : P_CUR_Q;
-  const bool goal_w = lane == 2 && (p.compat & NEO_MPC_COMPAT_ODOM_YAW_GOAL_W);
-  const double q[4] = {P[base], P[base + 1], P[base + 2], goal_w ? P[P_GOAL_Q + 3] : P[base + 3]};
-  const double yaw = yaw_of(q);
-  c.tyaw = lane_value(yaw, 0);
-  c.fyaw = lane_value(yaw, 1);
-  const double psi0 = lane_value(yaw, 2);
-  c.true_yaw = lane_value(yaw, 3);
-  sincos_fast(psi0, &c.s0, &c.c0);
-  c.cx = P[P_CARROT_X]; c.cy = P[P_CARROT_Y];
-  c.X0 = P[P_CUR_X]; c.Y0 = P[P_CUR_Y];
-  c.v0 = P[P_VEL]; c.v1 = P[P_VEL + 1]; c.v2 = P[P_VEL + 2];
-  const double gdx = c.cx - P[P_GOAL], gdy = c.cy - P[P_GOAL + 1];
-  c.konst = p.wterm_t * (gdx * gdx + gdy * gdy);          // py:266, 268: constant in u
-  if (fcost == 1.0) c.konst += p.w_footprint;             // py:262-263: N steps * w_footprint/N
-  c.tile_x0 = 0; c.tile_y0 = 0;
-}
-
-// stage the reach tile: rows [my0-R, my0+R], columns from floor4(mx0-R), dword loads
-__device__ void load_tile(const SolveArgs& a, Ctx& c, double* L, int lane) {
-  if (a.lds.tile_w == 0) { c.tile_x0 = 0; c.tile_y0 = 0; return; }
-  const int mx0 = cell_of(c.X0, a.map.origin_x, a.map.resolution, a.map.inv_resolution);
-  const int my0 = cell_of(c.Y0, a.map.origin_y, a.map.resolution, a.map.inv_resolution);
-  c.tile_x0 = (mx0 - a.lds.reach) & ~3;
-  c.tile_y0 = my0 - a.lds.reach;
-  uint32_t* tile = reinterpret_cast<uint32_t*>(L + a.lds.tile);
-  const int wq = a.lds.tile_w >> 2;  // dwords per row (power of two)
-  const int total = wq * a.lds.tile_h;
-  const int shift = __ffs(wq) - 1;
-  for (int idx = lane; idx < total; idx += kLanes) {
-    const int row = idx >> shift, col = idx & (wq - 1);
-    const long gy = (long)c.tile_y0 + row, gx = (long)c.tile_x0 + 4 * col;
-    uint32_t v = 0xFEFEFEFEu;  // lethal outside the padded map
-    if (gy >= -kMapBorder && gy < (long)a.map.size_y + kMapBorder && gx >= -kMapBorder &&
-        gx + 4 <= (long)a.map.pitch - kMapBorder)
-      v = *reinterpret_cast<const uint32_t*>(a.map.cells + gy * a.map.pitch + gx);
-    tile[idx] = v;
-  }
-}
-
-// Global-frame rollout of the controls x from the request's pose and TRUE yaw (py:293-306, 320-327):
-// lane i < n leaves with pose i.  The three running sums are accumulated in the reference's order
-// (sequentially, every lane alike); only the trigonometry and the products run side by side, one
-// step per lane -- one sincos per wave instead of n in a row.
-__device__ __forceinline__ void rollout_global(const double* x, int n, double dt, const Ctx& c, int lane,
-                                               double& px_i, double& py_i, double& yaw_i) {
-  double yaw = c.true_yaw;
-  yaw_i = yaw;
-  for (int i = 0; i < n; ++i) {
-    yaw += x[3 * i + 2] * dt;
-    if (lane == i) yaw_i = yaw;
-  }
-  double sn, cs;
-  sincos_fast(yaw_i, &sn, &cs);
-  const int k = lane < n ? lane : 0;
-  const double inc_x = x[3 * k] * cs * dt - x[3 * k + 1] * sn * dt;   // py:326
-  const double inc_y = x[3 * k] * sn * dt + x[3 * k + 1] * cs * dt;   // py:327
-  double px = c.X0, py = c.Y0;
-  px_i = px; py_i = py;
-  for (int i = 0; i < n; ++i) {
-    px += lane_value(inc_x, i);
-    py += lane_value(inc_y, i);
-    if (lane == i) { px_i = px; py_i = py; }
-  }
-}
-
-// ---------------------------------------------------------------- K2: py:365-403
-// `x` (LDS, 3N doubles) is the raw solver output; modified in place like `x.x`.
-__device__ void postprocess(const SolveArgs& a, const Ctx& c, double* L, uint32_t b, int lane, double* x,
-                            bool success, double fcost, int flags, double cost, int status, int nit, int nfev) {
-  const DevParams& p = a.p;
-  const int n = p.n, nv = 3 * n;
-  double* S = L + a.lds.state;
-  int* Si = reinterpret_cast<int*>(S);
-  const double* P = L + a.lds.prob;
-  // the `local_plan` rollout of the UNFILTERED solution (publishLocalPlan, py:293-306, runs
-  // before the low-pass at py:366) from the request's current pose
-  if (a.path) {
-    double px, py, yaw;
-    rollout_global(x, n, p.dt, c, lane, px, py, yaw);
-    if (lane < n) {
-      double* o = a.path + ((size_t)b * n + lane) * 3;
-      o[0] = px; o[1] = py; o[2] = yaw;
-    }
-  }
-  // low-pass on the first control, in place (py:366-367)
-  const double g = p.low_pass_gain;
-  double x0 = x[0] * g + S[S_LAST + 0] * (1 - g);
-  double x1 = x[1] * g + S[S_LAST + 1] * (1 - g);
-  double x2 = x[2] * g + S[S_LAST + 2] * (1 - g);
-  WAVE_SYNC();
-  if (lane == 0) { x[0] = x0; x[1] = x1; x[2] = x2; }
-  WAVE_SYNC();
-  // collision_check (py:312-341): global-frame rollout from the TRUE yaw
-  int collision = Si[SI_COLLISION];
-  {
-    double px, py, yaw;
-    rollout_global(x, n, p.dt, c, lane, px, py, yaw);
-    const int mx = cell_of(px, a.map.origin_x, a.map.resolution, a.map.inv_resolution);
-    const int my = cell_of(py, a.map.origin_y, a.map.resolution, a.map.inv_resolution);
-    // cost >= 0.99 (py:338-341) <=> occupancy >= 99: 99 / 100.0 is the double the literal 0.99 denotes
-    const bool hit = lane < n && raw_occupancy(map_raw(a.map, mx, my)) >= 99;
-    if (__ballot(hit) != 0ull) collision = 1;
-  }
-  const int coll_fp = (fcost == 1.0) ? 1 : 0;                       // py:343-347
-  double out0, out1, out2, waiting = S[S_WAIT];
-  if (collision || coll_fp) {                                       // py:374-382
-    out0 = out1 = out2 = 0.0;
-    flags |= NEO_MPC_FLAG_STOPPED;
-    waiting += P[P_DELTA_T];
-    if (waiting >= 3.0) { collision = 0; waiting = 0.0; }
-  } else {                                                          // py:385-391
-    const double ci = P[P_INTERVAL];
-    out0 = fmax(fmin(x0, S[S_LAST + 0] + p.acc[0] * ci), S[S_LAST + 0] - p.acc[0] * ci);
-    out1 = fmax(fmin(x1, S[S_LAST + 1] + p.acc[1] * ci), S[S_LAST + 1] - p.acc[1] * ci);
-    out2 = fmax(fmin(x2, S[S_LAST + 2] + p.acc[2] * ci), S[S_LAST + 2] - p.acc[2] * ci);
-  }
-  // warm start (py:397-400, 198-202)
-  double* warm = a.warm + (size_t)b * nv;
-  for (int k = lane; k < nv; k += kLanes) {
-    double v;
-    if (success) v = (k < nv - 3) ? x[k + 3] : x[k - (nv - 3)];
-    else v = x[k];
-    warm[k] = v;
-  }
-  WAVE_SYNC();
-  if (lane == 0) {
-    S[S_LAST + 0] = out0; S[S_LAST + 1] = out1; S[S_LAST + 2] = out2;   // py:393-395
-    for (int k = 0; k < 3; ++k) S[S_OLD_GOAL + k] = P[P_GOAL + k];       // py:402
-    for (int k = 0; k < 4; ++k) S[S_OLD_GOAL + 3 + k] = P[P_GOAL_Q + k];
-    S[S_WAIT] = waiting;
-    Si[SI_HAS_GOAL] = 1; Si[SI_COLLISION] = collision; Si[SI_COLL_FP] = coll_fp;
-    neo_mpc_command cmd;
-    cmd.vel[0] = out0; cmd.vel[1] = out1; cmd.vel[2] = out2;
-    cmd.cost = cost; cmd.status = status; cmd.iterations = nit; cmd.evaluations = nfev; cmd.flags = flags;
-    a.commands[b] = cmd;
-    if (a.velocities) { double* v = a.velocities + 3 * (size_t)b; v[0] = out0; v[1] = out1; v[2] = out2; }
-  }
-  WAVE_SYNC();
-  if (lane < 16) reinterpret_cast<double*>(a.states + b)[lane] = S[lane];
-}
-
-// py:358-361; returns true when the reset is taken.  x0 -> L[u]
-__device__ bool reset_and_warm(const SolveArgs& a, double* L, uint32_t b, int lane) {
-  double* S = L + a.lds.state;
-  int* Si = reinterpret_cast<int*>(S);
-  const double* P = L + a.lds.prob;
-  bool same = Si[SI_HAS_GOAL] != 0;
-  for (int k = 0; k < 3; ++k) same = same && (S[S_OLD_GOAL + k] == P[P_GOAL + k]);
-  for (int k = 0; k < 4; ++k) same = same && (S[S_OLD_GOAL + 3 + k] == P[P_GOAL_Q + k]);
-  same = uniform_int(same ? 1 : 0) != 0;
-  const int nv = 3 * a.p.n;
-  WAVE_SYNC();
-  for (int k = lane; k < nv; k += kLanes) L[a.lds.u + k] = same ? a.warm[(size_t)b * nv + k] : 0.0;
-  if (!same && lane == 0) { S[S_LAST] = 0.0; S[S_LAST + 1] = 0.0; S[S_LAST + 2] = 0.0; S[S_WAIT] = 0.0; }
-  WAVE_SYNC();
-  return !same;
-}
-
-__device__ void load_records(const SolveArgs& a, double* L, uint32_t b, int lane) {
-  if (lane < 32) L[a.lds.prob + lane] = reinterpret_cast<const double*>(a.problems + b)[lane];
-  else if (lane < 48) L[a.lds.state + lane - 32] = reinterpret_cast<const double*>(a.states + b)[lane - 32];
-  load_term_table(a.term_table, L, a.lds.term, lane);
-  WAVE_SYNC();
-}
 
 // ---------------------------------------------------------------- K1
 // kSteps > 0: specialisation for control_steps == kSteps -- every lane keeps its candidate's controls

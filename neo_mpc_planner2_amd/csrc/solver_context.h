@@ -1,0 +1,26 @@
+// solver_context.h -- per-instance constants (Ctx) and the record indices of the request / state blocks
+// Part of libneo_mpc.so's device code (included by neo_mpc_kernels.hip only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "neo_mpc_device.h"
+
+namespace neo_mpc {
+namespace {
+
+// ---------------------------------------------------------------- problem record indices (doubles)
+enum : int {
+  P_CUR_X = 0, P_CUR_Y = 1, P_CUR_Q = 2, P_CARROT_X = 6, P_CARROT_Y = 7, P_CARROT_Q = 8,
+  P_GOAL = 12, P_GOAL_Q = 15, P_VEL = 19, P_INTERVAL = 22, P_DELTA_T = 23, P_FOOTPRINT = 24,
+  S_LAST = 0, S_OLD_GOAL = 3, S_WAIT = 10, SI_HAS_GOAL = 22, SI_COLLISION = 23, SI_COLL_FP = 24
+};
+
+struct Ctx {
+  double cx, cy, tyaw, fyaw, c0, s0, X0, Y0, v0, v1, v2, konst, true_yaw;
+  int tile_x0, tile_y0;
+};
+
+}  // namespace
+}  // namespace neo_mpc

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Study: per-wave start/end times of one C2 launch (needs the timing build of the library:
+NEO_MPC_LIB=.../libneo_mpc_timing.so, which writes wall_clock64 stamps and HW_ID into `solution`)."""
+import sys, os, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from neo_mpc_planner2_amd import synthetic
+from neo_mpc_planner2_amd.solver import BatchSolver
+from neo_mpc_planner2_amd.mpc_optimization_server import README_PARAMS
+cfg, cmap, probs, st, warm = synthetic.make_workload("C2", seed=0)
+params = dict(README_PARAMS); params.update(control_steps=3)
+with BatchSolver(params) as s:
+    s.set_costmap(*cmap)
+    for rep in range(3):
+        st, warm = synthetic.make_states(probs, 3)
+        cmds, x = s.solve(probs, st, warm)
+t0, t1, hw = x[:, 0], x[:, 1], x[:, 2].astype(np.int64)
+base = t0.min()
+us = lambda t: (t - base) / 100.0     # wall_clock64: 100 MHz
+it = cmds["iterations"]
+dur = us(t1) - us(t0)
+print("launch span %.1f us; wave start spread: p50 %.1f p99 %.1f max %.1f us" % (us(t1).max(), np.median(us(t0)), np.quantile(us(t0), .99), us(t0).max()))
+print("wave duration: mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f us" % (dur.mean(), np.median(dur), np.quantile(dur, .9), np.quantile(dur, .99), dur.max()))
+for k in sorted(set(it)):
+    m = it == k
+    print("  iterations %2d: n %4d  duration mean %.1f  max %.1f  end max %.1f us" % (k, m.sum(), dur[m].mean(), dur[m].max(), us(t1)[m].max()))
+end = np.sort(us(t1))
+print("waves still running at t = 40/60/80/90/100 us:", [(end > t).sum() for t in (40, 60, 80, 90, 100)])
+# HW_ID: wave_id[3:0] simd[5:4] pipe[7:6] cu[11:8] sh[12] se[15:13] ... (gfx9 layout)
+simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
+key = ((se * 2 + sh) * 16 + cu) * 4 + simd
+u, cnt = np.unique(key, return_counts=True)
+print("distinct (se,sh,cu,simd) keys %d (XCD id is not in HW_ID, so keys alias across XCDs); waves per key: min %d max %d" % (len(u), cnt.min(), cnt.max()))
