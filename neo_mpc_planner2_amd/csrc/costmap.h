@@ -46,8 +46,9 @@ __device__ __forceinline__ double step_term(const SolveArgs& a, const Ctx& c, co
   const int my = cell_of(Y, a.map.origin_y, a.map.resolution, a.map.inv_resolution);
   const unsigned tx = (unsigned)(mx - c.tile_x0), ty = (unsigned)(my - c.tile_y0);
   int raw;
-  if (tx < (unsigned)a.lds.tile_w && ty < (unsigned)a.lds.tile_h)
-    raw = reinterpret_cast<const uint8_t*>(L + a.lds.tile)[ty * a.lds.tile_w + tx];
+  const int lg = c.tile_geom & 31;  // (one scalar register for the tile geometry; unpacking is scalar ALU work)
+  if ((tx >> lg) == 0u && ty < (unsigned)(c.tile_geom >> 8))
+    raw = reinterpret_cast<const uint8_t*>(L + a.lds.tile)[(ty << lg) + tx];
   else
     raw = map_raw(a.map, mx, my);
   return L[a.lds.term + raw];

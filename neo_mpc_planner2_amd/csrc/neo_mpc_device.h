@@ -69,7 +69,7 @@ constexpr LdsLayout make_lds_layout(int n, int mem) {
   int off = 0;
   l.prob = off; off += 32;
   l.state = off; off += 16;
-  l.tol = off; off += 8;    // stop tolerances (read once per iteration; kept out of the scalar registers)
+  l.tol = off; off += 10;   // stop tolerances + two cold per-instance constants (read once per iteration; kept out of the scalar registers)
   l.term = off; off += 256;
   l.u = off; off += nv;
   l.gs = off; off += nv;

@@ -87,18 +87,21 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   c.cx = lane_value(c.cx, 0); c.cy = lane_value(c.cy, 0); c.tyaw = lane_value(c.tyaw, 0);
   c.fyaw = lane_value(c.fyaw, 0); c.c0 = lane_value(c.c0, 0); c.s0 = lane_value(c.s0, 0);
   c.X0 = lane_value(c.X0, 0); c.Y0 = lane_value(c.Y0, 0); c.v0 = lane_value(c.v0, 0);
-  c.v1 = lane_value(c.v1, 0); c.v2 = lane_value(c.v2, 0); c.konst = lane_value(c.konst, 0);
-  c.true_yaw = lane_value(c.true_yaw, 0);
-  c.tile_x0 = uniform_int(c.tile_x0); c.tile_y0 = uniform_int(c.tile_y0);
+  c.v1 = lane_value(c.v1, 0); c.v2 = lane_value(c.v2, 0);
+  c.tile_x0 = uniform_int(c.tile_x0); c.tile_y0 = uniform_int(c.tile_y0); c.tile_geom = uniform_int(c.tile_geom);
 
   // The stop tolerances are read once per iteration: from LDS, so that they do not sit in (and get
   // spilled from) scalar registers all through the loop.
-  enum { T_XTOL, T_EARLY, T_FINAL, T_FTOL, T_STALL, T_WTOL, T_KINK };
+  // So do two per-instance constants the loop has no use for: the request's true yaw (K2 only) and
+  // the part of the objective that does not depend on u -- inside the loop f excludes it.
+  enum { T_XTOL, T_EARLY, T_FINAL, T_FTOL, T_STALL, T_WTOL, T_KINK, T_KONST, T_TRUE_YAW };
   if (lane == 0) {
     double* t = L + a.lds.tol;
     t[T_XTOL] = p.xtol; t[T_EARLY] = p.early_tol; t[T_FINAL] = p.final_tol; t[T_FTOL] = p.ftol;
     t[T_STALL] = p.stall_step; t[T_WTOL] = p.wtol; t[T_KINK] = p.kink_radius;
+    t[T_KONST] = c.konst; t[T_TRUE_YAW] = c.true_yaw;
   }
+  c.konst = 0.0; c.true_yaw = 0.0;
   const volatile double* TOL = L + a.lds.tol;
   double* u = L + a.lds.u;
   double* gs = L + a.lds.gs;
@@ -405,34 +408,31 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         }
       }
       const float deltaf = fmaxf(1e-6f * wave_max_f(fabsf(diag)), 1e-30f);
-      float pinvf[kVars];
       auto lane_f = [](float v, int src) {
         return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
       };
+      float own_pinv = 0.0f;  // lane pv keeps the reciprocal of its own pivot
 #pragma unroll
       for (int pv = 0; pv < kVars; ++pv) {  // Gaussian elimination, rows in registers, pivot row by readlane
         float piv = lane_f(hc[pv], pv);
         if (!(piv > deltaf)) piv = fmaxf(fabsf(piv), deltaf);
-        pinvf[pv] = __builtin_amdgcn_rcpf(piv);
-        const float fac = (lane > pv && lane < kVars) ? hc[pv] * pinvf[pv] : 0.0f;
+        const float pinv = __builtin_amdgcn_rcpf(piv);
+        if (lane == pv) own_pinv = pinv;
+        const float fac = (lane > pv && lane < kVars) ? hc[pv] * pinv : 0.0f;
 #pragma unroll
         for (int q = pv + 1; q < kVars; ++q) hc[q] -= fac * lane_f(hc[q], pv);
         rhsf -= fac * lane_f(rhsf, pv);
       }
-      double dsol[kVars];
-      float dsf[kVars];
+      // back substitution, column by column: x_pv leaves lane pv and every row above takes its
+      // share off its right-hand side (one readlane + one fma per unknown)
+      float sol = 0.0f;
 #pragma unroll
-      for (int pv = kVars - 1; pv >= 0; --pv) {  // back substitution; every lane ends with the whole d
-        float acc = rhsf;
-#pragma unroll
-        for (int q = pv + 1; q < kVars; ++q) acc -= hc[q] * dsf[q];
-        dsf[pv] = lane_f(acc * pinvf[pv], pv);
-        dsol[pv] = (double)dsf[pv];
+      for (int pv = kVars - 1; pv >= 0; --pv) {
+        const float x = lane_f(rhsf * own_pinv, pv);
+        if (lane == pv) sol = x;
+        rhsf -= hc[pv] * x;
       }
-      if (lane == 0) {
-#pragma unroll
-        for (int q = 0; q < kVars; ++q) d[q] = dsol[q];
-      }
+      if (lane < kVars) d[lane] = (double)sol;
       WAVE_SYNC();
     }
     // ---- new curvature pair
@@ -585,10 +585,11 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     }
     stepmax = wave_max_f(stepmax);
     const double gain = f - fb;
-    stall = (gain <= TOL[T_FTOL] * fmax(1.0, fabs(fb)) || (double)stepmax <= TOL[T_STALL]) ? stall + 1 : 0;
+    const double fscale = fmax(1.0, fabs(fb + TOL[T_KONST]));
+    stall = (gain <= TOL[T_FTOL] * fscale || (double)stepmax <= TOL[T_STALL]) ? stall + 1 : 0;
     // three iterations that together gained less than wtol: creeping along a costmap cell edge
     const double wtol = TOL[T_WTOL];
-    const bool creeping = wtol > 0.0 && gain + gain1 + gain2 <= wtol * fmax(1.0, fabs(fb));
+    const bool creeping = wtol > 0.0 && gain + gain1 + gain2 <= wtol * fscale;
     gain2 = gain1; gain1 = gain;
     f = fb;
     if (best < 32) {
@@ -602,6 +603,8 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   if (a.solution)
     for (int k = lane; k < nv; k += kLanes) a.solution[(size_t)b * nv + k] = u[k];
   WAVE_SYNC();
+  f += TOL[T_KONST];
+  c.true_yaw = TOL[T_TRUE_YAW];
   postprocess(a, c, L, b, lane, u, status == NEO_MPC_STATUS_CONVERGED, fcost, flags, f, status, it, nfev);
 }
 

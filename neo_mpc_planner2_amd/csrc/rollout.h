@@ -66,7 +66,7 @@ __device__ void make_ctx(const DevParams& p, const DevMap& m, const double* P, d
   const double gdx = c.cx - P[P_GOAL], gdy = c.cy - P[P_GOAL + 1];
   c.konst = p.wterm_t * (gdx * gdx + gdy * gdy);          // py:266, 268: constant in u
   if (fcost == 1.0) c.konst += p.w_footprint;             // py:262-263: N steps * w_footprint/N
-  c.tile_x0 = 0; c.tile_y0 = 0;
+  c.tile_x0 = 0; c.tile_y0 = 0; c.tile_geom = 0;
 }
 
 // make_ctx for the wave-per-instance kernels: the four yaw extractions run side by side in lanes
@@ -88,12 +88,14 @@ __device__ void make_ctx_wave(const DevParams& p, const DevMap& m, const double*
   const double gdx = c.cx - P[P_GOAL], gdy = c.cy - P[P_GOAL + 1];
   c.konst = p.wterm_t * (gdx * gdx + gdy * gdy);          // py:266, 268: constant in u
   if (fcost == 1.0) c.konst += p.w_footprint;             // py:262-263: N steps * w_footprint/N
-  c.tile_x0 = 0; c.tile_y0 = 0;
+  c.tile_x0 = 0; c.tile_y0 = 0; c.tile_geom = 0;
 }
 
 // stage the reach tile: rows [my0-R, my0+R], columns from floor4(mx0-R), dword loads
 __device__ void load_tile(const SolveArgs& a, Ctx& c, double* L, int lane) {
+  c.tile_geom = 0;
   if (a.lds.tile_w == 0) { c.tile_x0 = 0; c.tile_y0 = 0; return; }
+  c.tile_geom = (a.lds.tile_h << 8) | (__ffs(a.lds.tile_w) - 1);
   const int mx0 = cell_of(c.X0, a.map.origin_x, a.map.resolution, a.map.inv_resolution);
   const int my0 = cell_of(c.Y0, a.map.origin_y, a.map.resolution, a.map.inv_resolution);
   c.tile_x0 = (mx0 - a.lds.reach) & ~3;

@@ -20,6 +20,7 @@ enum : int {
 struct Ctx {
   double cx, cy, tyaw, fyaw, c0, s0, X0, Y0, v0, v1, v2, konst, true_yaw;
   int tile_x0, tile_y0;
+  int tile_geom;  // reach tile in LDS: rows << 8 | log2(row stride in bytes); 0: no tile
 };
 
 }  // namespace
