@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="instances per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-iterations", type=int, default=None, help="study knob: cap the solver iterations")
+    ap.add_argument("--control-steps", type=int, default=None, help="study knob: override the config's control_steps")
+    ap.add_argument("--method", type=int, default=None, help="study knob: 1 = L-BFGS, 2 = Newton (control_steps <= 8)")
     args = ap.parse_args()
 
     import torch
@@ -118,10 +120,14 @@ def main():
     cfg = dict(synthetic.CONFIGS[args.workload])
     if args.batch:
         cfg["batch"] = args.batch
+    if args.control_steps:
+        cfg["control_steps"] = args.control_steps
     n = cfg["control_steps"]
     params = readme_params(n)
     if args.max_iterations:
         params["max_iterations"] = args.max_iterations
+    if args.method is not None:
+        params["method"] = args.method
     cmap = synthetic.make_costmap(cfg["map_size"], seed=0)                 # shared map, replicated
     probs = synthetic.make_problems(cfg["batch"], cfg["map_size"], seed=1000 + rank)
     st, warm = synthetic.make_states(probs, n)
@@ -191,7 +197,8 @@ def main():
         total_instances = cfg["batch"] * world
         value = total_instances * args.steps / elapsed
         k_ms = float(np.mean(kernel_ms))
-        achieved = ALGO_BYTES[n] * cfg["batch"] / (k_ms * 1e-3) / 1e9
+        algo_bytes = ALGO_BYTES.get(n, (17 + 3 * n) * 4 + (3 + 3 * n + 1) * 4 + 729)   # BASELINE.md's per-solve figure
+        achieved = algo_bytes * cfg["batch"] / (k_ms * 1e-3) / 1e9
         traffic = valu = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
@@ -215,7 +222,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_solve", "kernel_ms": k_ms,
-                         "algorithmic_bytes_per_solve": ALGO_BYTES[n]},
+                         "algorithmic_bytes_per_solve": algo_bytes},
             # what actually bounds K1: VALU issue.  SQ_INSTS_VALU of the committed PMC
             # pass x 4 cycles (a wave64 instruction on a 16-lane SIMD) over 1024 SIMDs x this run's kernel time
             "valu_issue": None if not valu else {

@@ -49,10 +49,11 @@ extern "C" {
 #define NEO_MPC_COMPAT_ODOM_YAW_GOAL_W 1 /* py:213: odom_yaw takes quaternion w from the goal pose */
 
 /* neo_mpc_params.method */
-#define NEO_MPC_METHOD_AUTO 0   /* Newton where the kernel has it (control_steps == 3), else L-BFGS */
+#define NEO_MPC_METHOD_AUTO 0   /* Newton where the kernel has it (control_steps <= 8), else L-BFGS */
 #define NEO_MPC_METHOD_LBFGS 1  /* projected L-BFGS, any control_steps */
 #define NEO_MPC_METHOD_NEWTON 2 /* projected Newton (finite-difference Hessian of the analytic
-                                   gradient, one column per lane); control_steps == 3 only */
+                                   gradient, one column per lane); control_steps <= 8 */
+#define NEO_MPC_NEWTON_MAX_CONTROL_STEPS 8
 
 #define NEO_MPC_MAX_CONTROL_STEPS 64
 #define NEO_MPC_MAX_FOOTPRINT_POINTS 16

@@ -89,8 +89,8 @@ int validate(const neo_mpc_params& p) {
   if (nx * nx + ny * ny > p.max_vel_trans * p.max_vel_trans)
     return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "velocity box does not intersect the max_vel_trans disc");
   if (p.method < 0 || p.method > NEO_MPC_METHOD_NEWTON) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "unknown method %d", p.method);
-  if (p.method == NEO_MPC_METHOD_NEWTON && p.control_steps != 3)
-    return fail(NEO_MPC_ERR_UNSUPPORTED, "NEO_MPC_METHOD_NEWTON is built for control_steps == 3 only (got %d)",
+  if (p.method == NEO_MPC_METHOD_NEWTON && p.control_steps > NEO_MPC_NEWTON_MAX_CONTROL_STEPS)
+    return fail(NEO_MPC_ERR_UNSUPPORTED, "NEO_MPC_METHOD_NEWTON is built for control_steps <= 8 only (got %d)",
                 p.control_steps);
   if (p.lbfgs_memory > NEO_MPC_MAX_LBFGS_MEMORY)
     return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "lbfgs_memory > %d", NEO_MPC_MAX_LBFGS_MEMORY);
@@ -132,7 +132,7 @@ void derive(neo_mpc_handle* h) {
   d.disc_in_box = (p.min_vel_x <= -p.max_vel_trans && p.max_vel_x >= p.max_vel_trans &&
                    p.min_vel_y <= -p.max_vel_trans && p.max_vel_y >= p.max_vel_trans) ? 1 : 0;
   d.tame = (d.disc_in_box && fmax(fabs(p.min_vel_theta), fabs(p.max_vel_theta)) * p.prediction_horizon <= 0.78) ? 1 : 0;
-  d.newton = ((p.method == NEO_MPC_METHOD_NEWTON || p.method == NEO_MPC_METHOD_AUTO) && n == 3) ? 1 : 0;
+  d.newton = (p.method != NEO_MPC_METHOD_LBFGS && n <= NEO_MPC_NEWTON_MAX_CONTROL_STEPS) ? 1 : 0;
   d.early_tol = getenv("NEO_MPC_NO_EARLY") ? 0.0 : d.xtol;
   d.final_tol = getenv("NEO_MPC_NO_EARLY") ? 0.0 : (p.step_tolerance > 0.0 ? p.step_tolerance : p.opt_tolerance);
   d.ftol = p.cost_tolerance > 0.0 ? p.cost_tolerance : (d.newton ? 3e-4 : 3e-6) * p.opt_tolerance;

@@ -11,7 +11,7 @@
 //                     evaluates 64 candidate control sequences at once (one rollout per
 //                     lane): lanes 0-31 walk the projected proximal-gradient arc at 32
 //                     step sizes, lanes 32-63 a projected second-order direction at 32 step
-//                     lengths -- Newton at control_steps 3 (finite-difference Hessian of the
+//                     lengths -- Newton at control_steps <= 8 (finite-difference Hessian of the
 //                     analytic gradient, one column per lane, solved in registers), L-BFGS
 //                     otherwise (rollout/adjoint as DPP prefix scans, lane = step); the lowest
 //                     objective wins (wave arg-min).  Iterates, gradients and the quasi-Newton
@@ -46,18 +46,25 @@ namespace {
 // consecutive iterations gaining less than ftol*max(1,|f|) or moving less than stall_step that end
 // the search (creeping along a costmap cell edge gains ~1e-9 per iteration for ever)
 constexpr int kStallIterations = 5;
+// largest control_steps the run-time-sized Newton kernel takes (a 24 x 24 system: rows in registers)
+constexpr int kNewtonMaxSteps = 8;
 
 // ---------------------------------------------------------------- K1
 // kSteps > 0: specialisation for control_steps == kSteps -- every lane keeps its candidate's controls
 // and sin/cos in registers, so the winner is stored without being recomputed and the next adjoint
 // sweep needs no trigonometry.  kSteps == 0: any control_steps (LDS-only path).
+// kNewton: lanes 32-63 walk the projected Newton direction -- control_steps == kSteps, or with
+// kSteps == 0 any control_steps <= kNewtonMaxSteps (measured against L-BFGS on the 1000^2 map,
+// 65 536 instances: +28 % at control_steps 1, +54 % at 2, +50 % at 4, +38 % at 5-7, +42 % at 8).
 // kTame: instantiation for parameter sets (the README's among them) whose max_vel_trans disc lies
 // inside the vx/vy box -- the box/disc corner cases of the projection and of the tangent cone drop
 // out -- and whose heading cannot leave [-pi/4, pi/4] within the horizon -- no range reduction in
 // the rollout's sin/cos.
 template <int kMinWavesPerSimd, int kSteps, bool kNewton = false, bool kTame = false>
 __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveArgs args) {
-  static_assert(!kNewton || kSteps > 0, "the Newton path needs a compile-time control_steps");
+  // Newton: control_steps == kSteps, or (kSteps == 0) any control_steps <= kNewtonMaxSteps -- the
+  // system's arrays are sized for the bound and every loop over them is guarded by the run-time size
+  constexpr int kNwSteps = !kNewton ? 1 : kSteps ? kSteps : kNewtonMaxSteps;
   extern __shared__ __align__(16) double L[];
   SolveArgs a = args;
   if (kSteps) {  // compile-time LDS offsets (lbfgs_memory is 4 in the specialisations' layout)
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   // Newton: one float32 record per control block (projector + block curvature), written by the
   // tangent-cone pass; it lives in the cs..rt step arrays, which the Newton kernel does not use
   constexpr int kNewtonRecord = 13;
-  static_assert(!kNewton || 2 * 7 * kRegSteps >= kNewtonRecord * kRegSteps, "Newton records do not fit the step arrays");
+  static_assert(2 * 7 >= kNewtonRecord, "Newton records do not fit the step arrays");
   float* NB = reinterpret_cast<float*>(L + a.lds.cs);
 
   // x0 clipped to the feasible set (SciPy clips x0 to the bounds, _slsqp_py.py:268)
@@ -151,51 +158,69 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     int lane = lane_id;
     asm volatile("" : "+v"(lane));
     // ---- adjoint gradient of the tracking + terminal cost
-    constexpr int kVars = 3 * kRegSteps;
-    double hcol[kVars];  // Newton: gradient of this lane's perturbed copy
+    constexpr int kVars = 3 * kNwSteps;  // compile-time bound of the Newton system (= its size when kSteps > 0)
+    const int nvr = kSteps ? kVars : nv;  // its size
     float hc[kVars];     // Newton: column `lane` of the Hessian, then row `lane` (float32, see below)
+    double hcol[kSteps ? kVars : 1];  // control_steps specialisation: gradient of this lane's perturbed copy
     if (kNewton) {
       // Every lane runs the rollout + adjoint sweep on its own copy of u: lane k < 3N perturbs
       // coordinate k by h, the other lanes leave u alone.  One pass therefore yields the gradient
       // (any unperturbed lane) and all 3N Hessian columns by forward differences -- the sweep
       // costs the same whether the lanes agree or not.
-      const double hstep = 1e-6;
+      const double hstep = 1e-6, inv_h = 1.0 / hstep;
       // forward: keep only sin/cos per step; the reverse pass rebuilds increments and residuals
       // while it unwinds x, y, theta (fewer live registers -> one more wave per SIMD)
-      double pcs[kRegSteps], psn[kRegSteps];
+      double pcs[kNwSteps], psn[kNwSteps];
       double x = 0.0, y = 0.0, th = 0.0;
 #pragma unroll
-      for (int i = 0; i < kRegSteps; ++i) {
-        const double vx = u[3 * i] + (lane == 3 * i ? hstep : 0.0);
-        const double vy = u[3 * i + 1] + (lane == 3 * i + 1 ? hstep : 0.0);
-        const double w = u[3 * i + 2] + (lane == 3 * i + 2 ? hstep : 0.0);
-        th += w * p.dt;
-        sincos_heading<kTame>(th, &psn[i], &pcs[i]);
-        x += (vx * pcs[i] - vy * psn[i]) * p.dt;
-        y += (vx * psn[i] + vy * pcs[i]) * p.dt;
+      for (int i = 0; i < kNwSteps; ++i) {
+        if (kSteps || i < n) {
+          const double vx = u[3 * i] + (lane == 3 * i ? hstep : 0.0);
+          const double vy = u[3 * i + 1] + (lane == 3 * i + 1 ? hstep : 0.0);
+          const double w = u[3 * i + 2] + (lane == 3 * i + 2 ? hstep : 0.0);
+          th += w * p.dt;
+          sincos_heading<kTame>(th, &psn[i], &pcs[i]);
+          x += (vx * pcs[i] - vy * psn[i]) * p.dt;
+          y += (vx * psn[i] + vy * pcs[i]) * p.dt;
+        }
       }
       double SX = 0.0, SY = 0.0, ST = 0.0;
 #pragma unroll
-      for (int k = kRegSteps - 1; k >= 0; --k) {
-        const double vx = u[3 * k] + (lane == 3 * k ? hstep : 0.0);
-        const double vy = u[3 * k + 1] + (lane == 3 * k + 1 ? hstep : 0.0);
-        const double w = u[3 * k + 2] + (lane == 3 * k + 2 ? hstep : 0.0);
-        const double pdx = (vx * pcs[k] - vy * psn[k]) * p.dt, pdy = (vx * psn[k] + vy * pcs[k]) * p.dt;
-        double prt = -2.0 * p.wo_n * (c.tyaw - th);
-        if (k == kRegSteps - 1) prt += -2.0 * p.wterm_o * (c.fyaw - th);
-        SX += -2.0 * p.wt_n * (c.cx - x); SY += -2.0 * p.wt_n * (c.cy - y);
-        ST += prt - pdy * SX + pdx * SY;
-        hcol[3 * k] = p.dt * (pcs[k] * SX + psn[k] * SY);
-        hcol[3 * k + 1] = p.dt * (-psn[k] * SX + pcs[k] * SY);
-        hcol[3 * k + 2] = p.dt * ST;
-        x -= pdx; y -= pdy; th -= w * p.dt;
+      for (int k = kNwSteps - 1; k >= 0; --k) {
+        if (kSteps || k < n) {
+          const double vx = u[3 * k] + (lane == 3 * k ? hstep : 0.0);
+          const double vy = u[3 * k + 1] + (lane == 3 * k + 1 ? hstep : 0.0);
+          const double w = u[3 * k + 2] + (lane == 3 * k + 2 ? hstep : 0.0);
+          const double pdx = (vx * pcs[k] - vy * psn[k]) * p.dt, pdy = (vx * psn[k] + vy * pcs[k]) * p.dt;
+          double prt = -2.0 * p.wo_n * (c.tyaw - th);
+          if (k == n - 1) prt += -2.0 * p.wterm_o * (c.fyaw - th);
+          SX += -2.0 * p.wt_n * (c.cx - x); SY += -2.0 * p.wt_n * (c.cy - y);
+          ST += prt - pdy * SX + pdx * SY;
+          // gradient entries of this lane's copy; the unperturbed lane 63 supplies the gradient itself
+          // and the base of the forward difference
+          const double g0 = p.dt * (pcs[k] * SX + psn[k] * SY), g1 = p.dt * (-psn[k] * SX + pcs[k] * SY),
+                       g2 = p.dt * ST;
+          if (kSteps) {  // (few variables: differencing after the sweep schedules better)
+            hcol[3 * k] = g0; hcol[3 * k + 1] = g1; hcol[3 * k + 2] = g2;
+          } else {       // (up to 24: difference at once, no second register array)
+            const double b0 = lane_value(g0, 63), b1 = lane_value(g1, 63), b2 = lane_value(g2, 63);
+            if (lane == 63) { gs[3 * k] = b0; gs[3 * k + 1] = b1; gs[3 * k + 2] = b2; }
+            hc[3 * k] = (float)((g0 - b0) * inv_h);
+            hc[3 * k + 1] = (float)((g1 - b1) * inv_h);
+            hc[3 * k + 2] = (float)((g2 - b2) * inv_h);
+          }
+          x -= pdx; y -= pdy; th -= w * p.dt;
+        } else {
+          hc[3 * k] = 0.0f; hc[3 * k + 1] = 0.0f; hc[3 * k + 2] = 0.0f;
+        }
       }
-      const double inv_h = 1.0 / hstep;
+      if (kSteps) {
 #pragma unroll
-      for (int j = 0; j < kVars; ++j) {
-        const double base = lane_value(hcol[j], 63);
-        if (lane == 63) gs[j] = base;
-        hc[j] = (float)((hcol[j] - base) * inv_h);
+        for (int j = 0; j < kVars; ++j) {
+          const double base = lane_value(hcol[j], 63);
+          if (lane == 63) gs[j] = base;
+          hc[j] = (float)((hcol[j] - base) * inv_h);
+        }
       }
       WAVE_SYNC();
     } else if (!kSteps) {
@@ -351,7 +376,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     if (kNewton && it == 0 && cold) {
       // a cold start (x0 = 0, the reference's reset state py:359) is far from the minimiser and the
       // Newton step almost never wins there: steepest descent on the face for this one iteration
-      if (lane < kVars) d[lane] = -gr[lane];
+      if (lane < nvr) d[lane] = -gr[lane];
       WAVE_SYNC();
     } else if (kNewton) {
       // From here on the Newton system lives in float32: it only yields a search direction (the arc
@@ -359,37 +384,36 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       // and VALU time of this section.
       float* Hm = reinterpret_cast<float*>(L + a.lds.hess);
       // this lane's own block (lane = variable index 3 * kb + kq) and that block's record
-      const int kv = lane < kVars ? lane : 0, kb = (kv * 11) >> 5, kq = kv - 3 * kb;   // kv / 3 for kv < 32
+      const int kv = lane < nvr ? lane : 0, kb = (kv * 11) >> 5, kq = kv - 3 * kb;   // kv / 3 for kv < 32
+      const int hs = nvr;  // row stride of the system in LDS
       const float* own = NB + kNewtonRecord * kb;
       // ---- lane k < 3N holds Hessian column k: add column kq of its block's curvature, apply P on
       //      the row index, store the column
       {
         const float cn0 = own[4 + kq], cn1 = own[7 + kq], cn2 = own[10 + kq];  // (C is symmetric)
 #pragma unroll
-        for (int bk = 0; bk < kRegSteps; ++bk) {
-          const float* nb = NB + kNewtonRecord * bk;
-          const bool mine = lane < kVars && kb == bk;
-          const float hx = hc[3 * bk] + (mine ? cn0 : 0.0f), hy = hc[3 * bk + 1] + (mine ? cn1 : 0.0f);
-          hc[3 * bk] = nb[0] * hx + nb[1] * hy;
-          hc[3 * bk + 1] = nb[1] * hx + nb[2] * hy;
-          hc[3 * bk + 2] = (hc[3 * bk + 2] + (mine ? cn2 : 0.0f)) * nb[3];
+        for (int bk = 0; bk < kNwSteps; ++bk) {
+          if (kSteps || bk < n) {
+            const float* nb = NB + kNewtonRecord * bk;
+            const bool mine = lane < nvr && kb == bk;
+            const float hx = hc[3 * bk] + (mine ? cn0 : 0.0f), hy = hc[3 * bk + 1] + (mine ? cn1 : 0.0f);
+            hc[3 * bk] = nb[0] * hx + nb[1] * hy;
+            hc[3 * bk + 1] = nb[1] * hx + nb[2] * hy;
+            hc[3 * bk + 2] = (hc[3 * bk + 2] + (mine ? cn2 : 0.0f)) * nb[3];
+          }
         }
       }
-      if (lane < kVars) {
+      if (lane < nvr) {
 #pragma unroll
-        for (int j = 0; j < kVars; ++j) Hm[j * kVars + lane] = hc[j];
+        for (int j = 0; j < kVars; ++j)
+          if (kSteps || j < nvr) Hm[j * hs + lane] = hc[j];
       }
       WAVE_SYNC();
       // ---- lane j < 3N holds row j: apply P on the column index, add I - P, eliminate
       float rhsf = 0.0f, diag = 0.0f;
-      if (lane < kVars) {
 #pragma unroll
-        for (int q = 0; q < kVars; ++q) hc[q] = Hm[lane * kVars + q];
-        rhsf = -(float)gr[lane];
-      } else {
-#pragma unroll
-        for (int q = 0; q < kVars; ++q) hc[q] = 0.0f;
-      }
+      for (int q = 0; q < kVars; ++q) hc[q] = (lane < nvr && (kSteps || q < nvr)) ? Hm[lane * hs + q] : 0.0f;
+      if (lane < nvr) rhsf = -(float)gr[lane];
       {
         // row kq of I - P of this lane's block
         const float p00 = own[0], p01 = own[1], p11 = own[2], pw = own[3];
@@ -397,14 +421,16 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         const float a1 = kq == 0 ? -p01 : kq == 1 ? 1.0f - p11 : 0.0f;
         const float a2 = kq == 2 ? 1.0f - pw : 0.0f;
 #pragma unroll
-        for (int bk = 0; bk < kRegSteps; ++bk) {
-          const float* nb = NB + kNewtonRecord * bk;
-          const bool mine = lane < kVars && kb == bk;
-          const float hx = hc[3 * bk], hy = hc[3 * bk + 1];
-          hc[3 * bk] = hx * nb[0] + hy * nb[1] + (mine ? a0 : 0.0f);
-          hc[3 * bk + 1] = hx * nb[1] + hy * nb[2] + (mine ? a1 : 0.0f);
-          hc[3 * bk + 2] = hc[3 * bk + 2] * nb[3] + (mine ? a2 : 0.0f);
-          if (mine) diag = kq == 0 ? hc[3 * bk] : kq == 1 ? hc[3 * bk + 1] : hc[3 * bk + 2];
+        for (int bk = 0; bk < kNwSteps; ++bk) {
+          if (kSteps || bk < n) {
+            const float* nb = NB + kNewtonRecord * bk;
+            const bool mine = lane < nvr && kb == bk;
+            const float hx = hc[3 * bk], hy = hc[3 * bk + 1];
+            hc[3 * bk] = hx * nb[0] + hy * nb[1] + (mine ? a0 : 0.0f);
+            hc[3 * bk + 1] = hx * nb[1] + hy * nb[2] + (mine ? a1 : 0.0f);
+            hc[3 * bk + 2] = hc[3 * bk + 2] * nb[3] + (mine ? a2 : 0.0f);
+            if (mine) diag = kq == 0 ? hc[3 * bk] : kq == 1 ? hc[3 * bk + 1] : hc[3 * bk + 2];
+          }
         }
       }
       const float deltaf = fmaxf(1e-6f * wave_max_f(fabsf(diag)), 1e-30f);
@@ -414,25 +440,40 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       float own_pinv = 0.0f;  // lane pv keeps the reciprocal of its own pivot
 #pragma unroll
       for (int pv = 0; pv < kVars; ++pv) {  // Gaussian elimination, rows in registers, pivot row by readlane
-        float piv = lane_f(hc[pv], pv);
-        if (!(piv > deltaf)) piv = fmaxf(fabsf(piv), deltaf);
-        const float pinv = __builtin_amdgcn_rcpf(piv);
-        if (lane == pv) own_pinv = pinv;
-        const float fac = (lane > pv && lane < kVars) ? hc[pv] * pinv : 0.0f;
+        if (kSteps || pv < nvr) {
+          float piv = lane_f(hc[pv], pv);
+          if (!(piv > deltaf)) piv = fmaxf(fabsf(piv), deltaf);
+          const float pinv = __builtin_amdgcn_rcpf(piv);
+          if (lane == pv) own_pinv = pinv;
+          const float fac = (lane > pv && lane < nvr) ? hc[pv] * pinv : 0.0f;
+          if (kSteps) {
 #pragma unroll
-        for (int q = pv + 1; q < kVars; ++q) hc[q] -= fac * lane_f(hc[q], pv);
-        rhsf -= fac * lane_f(rhsf, pv);
+            for (int q = pv + 1; q < kVars; ++q) hc[q] -= fac * lane_f(hc[q], pv);
+          } else {
+#pragma unroll
+            for (int qb = pv / 3; qb < kNwSteps; ++qb) {   // (whole blocks of three columns at a time)
+              if (qb < n) {
+#pragma unroll
+                for (int q = 3 * qb; q < 3 * qb + 3; ++q)
+                  if (q > pv) hc[q] -= fac * lane_f(hc[q], pv);
+              }
+            }
+          }
+          rhsf -= fac * lane_f(rhsf, pv);
+        }
       }
       // back substitution, column by column: x_pv leaves lane pv and every row above takes its
       // share off its right-hand side (one readlane + one fma per unknown)
       float sol = 0.0f;
 #pragma unroll
       for (int pv = kVars - 1; pv >= 0; --pv) {
-        const float x = lane_f(rhsf * own_pinv, pv);
-        if (lane == pv) sol = x;
-        rhsf -= hc[pv] * x;
+        if (kSteps || pv < nvr) {
+          const float x = lane_f(rhsf * own_pinv, pv);
+          if (lane == pv) sol = x;
+          rhsf -= hc[pv] * x;
+        }
       }
-      if (lane < kVars) d[lane] = (double)sol;
+      if (lane < nvr) d[lane] = (double)sol;
       WAVE_SYNC();
     }
     // ---- new curvature pair
@@ -530,7 +571,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       // the kink are moved by the prox step, which d does not describe -- keep iterating then)
       float dm = 0.0f;
       int anynear = 0;
-      if (lane < kVars) { dm = (float)fabs(d[lane]); anynear = AMODE[4 * (lane / 3) + 2]; }
+      if (lane < nvr) { dm = (float)fabs(d[lane]); anynear = AMODE[4 * (lane / 3) + 2]; }
       dm = wave_max_f(dm);
       const bool near_any = __ballot(anynear != 0) != 0ull;
       if ((double)dm < TOL[T_EARLY] && !near_any) { status = NEO_MPC_STATUS_CONVERGED; break; }
@@ -802,8 +843,13 @@ void launch_solve(const SolveArgs& a, void* stream) {
     if (w == 4) NEO_LAUNCH(4, 3); else if (w == 3) NEO_LAUNCH(3, 3); else NEO_LAUNCH(2, 3);
   } else {  // any other control_steps (measured: at N = 8 the scan-based generic path beats a register
             // specialisation, 8.5 vs 10.1 ms per 65 536 instances)
-    const int w = solve_variant(3);
-    if (disc) { if (w == 4) NEO_LAUNCH(4, 0, false, true); else if (w == 3) NEO_LAUNCH(3, 0, false, true); else NEO_LAUNCH(2, 0, false, true); }
+    // (the run-time-sized Newton kernel keeps a 24-entry row per lane: 158 VGPRs, 187 without the
+    // tame specialisation -- spill-free at 3 and 2 waves/SIMD)
+    const int w = solve_variant(a.p.newton && !disc ? 2 : 3);
+    if (a.p.newton) {  // control_steps <= kNewtonMaxSteps
+      if (disc) { if (w == 4) NEO_LAUNCH(4, 0, true, true); else if (w == 3) NEO_LAUNCH(3, 0, true, true); else NEO_LAUNCH(2, 0, true, true); }
+      else { if (w == 4) NEO_LAUNCH(4, 0, true); else if (w == 3) NEO_LAUNCH(3, 0, true); else NEO_LAUNCH(2, 0, true); }
+    } else if (disc) { if (w == 4) NEO_LAUNCH(4, 0, false, true); else if (w == 3) NEO_LAUNCH(3, 0, false, true); else NEO_LAUNCH(2, 0, false, true); }
     else { if (w == 4) NEO_LAUNCH(4, 0); else if (w == 3) NEO_LAUNCH(3, 0); else NEO_LAUNCH(2, 0); }
   }
 #undef NEO_LAUNCH

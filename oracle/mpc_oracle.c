@@ -575,8 +575,7 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
   if (mem > NEO_MPC_MAX_LBFGS_MEMORY) mem = NEO_MPC_MAX_LBFGS_MEMORY;
   const double xtol = p->step_tolerance > 0.0 ? p->step_tolerance : 1e-3 * p->opt_tolerance;
   const double stall_step = p->stall_step > 0.0 ? p->stall_step : 0.3 * p->opt_tolerance;
-  const int newton = (p->method == NEO_MPC_METHOD_NEWTON || (p->method == NEO_MPC_METHOD_AUTO && p->control_steps == 3)) &&
-                     3 * p->control_steps <= ORC_NEWTON_MAXV;
+  const int newton = p->method != NEO_MPC_METHOD_LBFGS && 3 * p->control_steps <= ORC_NEWTON_MAXV;
   /* Newton converges quadratically, so a run of tiny gains means creeping along a costmap cell
    * edge much earlier than with L-BFGS: looser default */
   const double ftol = p->cost_tolerance > 0.0 ? p->cost_tolerance : (newton ? 3e-4 : 3e-6) * p->opt_tolerance;

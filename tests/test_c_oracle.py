@@ -150,8 +150,8 @@ def test_window_tolerance_only_shortens_creeping_searches():
     z_on = _cold_solve(orc.make_params(window_tolerance=0.0), zero, probs[:256])[1]
     assert np.abs(z_on[:, :3] - z_off[:, :3]).max() <= 2e-4    # the command (first control)
     assert np.abs(z_on - z_off).max() <= 1e-3
-    # L-BFGS (any other control_steps): off by default
-    p8 = orc.make_params(control_steps=8)
-    a = _cold_solve(p8, cmap, probs[:128])[0]
-    b = _cold_solve(orc.make_params(control_steps=8, window_tolerance=-1.0), cmap, probs[:128])[0]
+    # L-BFGS (control_steps > 8, or method = 1): off by default
+    p12 = orc.make_params(control_steps=12)
+    a = _cold_solve(p12, cmap, probs[:128])[0]
+    b = _cold_solve(orc.make_params(control_steps=12, window_tolerance=-1.0), cmap, probs[:128])[0]
     assert (a["iterations"] == b["iterations"]).all()

@@ -227,8 +227,8 @@ def test_newton_is_refused_for_other_control_steps():
     from neo_mpc_planner2_amd import _lib
     from neo_mpc_planner2_amd.solver import BatchSolver
     with pytest.raises(_lib.NeoMpcError) as e:
-        BatchSolver(util.orc.make_params(control_steps=5, method=2))
-    assert e.value.code == -1 or "control_steps == 3" in str(e.value)
+        BatchSolver(util.orc.make_params(control_steps=9, method=2))
+    assert e.value.code == -1 or "control_steps <= 8" in str(e.value)
 
 
 def test_window_tolerance_trims_the_creeping_tail_only():

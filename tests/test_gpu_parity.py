@@ -88,14 +88,16 @@ def test_footprint_raster_on_device_matches_oracle(solver_mod):
 
 # ------------------------------------------------------------------ solver vs CPU mirror
 @pytest.mark.parametrize("n_steps,count,map_size,method", [(3, 1024, 500, 0), (3, 1024, 500, 1), (8, 256, 200, 0),
-                                                           (32, 64, 200, 0)])
+                                                           (32, 64, 200, 0), (8, 256, 200, 1),
+                                                           # run-time-sized Newton kernel (control_steps <= 8)
+                                                           (8, 512, 300, 2), (5, 512, 300, 2), (1, 256, 300, 2)])
 def test_solver_kernel_matches_cpu_mirror(solver_mod, n_steps, count, map_size, method):
     """Same algorithm, same inputs, f64 on both sides: GPU vs oracle/mpc_oracle.c.
     Differences come only from sincos/atan2 implementations, FMA contraction and the
     summation order of the wave reductions."""
     from oracle import c_oracle
     # control_steps=32 needs more than SLSQP's 100 iterations (96 variables, L-BFGS memory 4)
-    # method 0 = auto: projected Newton at control_steps 3, projected L-BFGS otherwise; 1 = L-BFGS
+    # method 0 = auto: projected Newton at control_steps <= 8, projected L-BFGS otherwise; 1 = L-BFGS; 2 = Newton
     params = util.orc.make_params(control_steps=n_steps, max_iterations=100 if n_steps < 32 else 600, method=method)
     cmap = synthetic.make_costmap(map_size, seed=11)
     probs = synthetic.make_problems(count, map_size, seed=12 + n_steps)
