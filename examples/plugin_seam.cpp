@@ -132,8 +132,71 @@ struct NeoMpcPlannerSeam {
   }
 };
 
-int main() {  // link check only; needs a GPU to actually run
+// `plugin_seam` alone is the link check (no GPU needed).  `plugin_seam --run` drives the seam the way
+// nav2's controller server would: 300 control ticks at 30 Hz of one robot chasing a look-ahead point
+// that slides along a straight plan, costmap handed over every tick, README parameters
+// (README.md:53-84) -- and prints the per-tick latency of `solve()` (set_costmap + solve_batch,
+// host buffers, count = 1).  tests/test_gpu_parity.py runs it on the GPU box.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+int main(int argc, char** argv) {
+  if (argc < 2 || std::strcmp(argv[1], "--run") != 0) {
+    NeoMpcPlannerSeam seam;
+    (void)seam;
+    return neo_mpc_abi_version() == NEO_MPC_ABI_VERSION ? 0 : 1;
+  }
   NeoMpcPlannerSeam seam;
-  (void)seam;
-  return neo_mpc_abi_version() == NEO_MPC_ABI_VERSION ? 0 : 1;
+  seam.configureSolver([](const char* name, double dflt) {   // the README's YAML block
+    const struct { const char* n; double v; } readme[] = {
+        {"acc_x_limit", 2.5}, {"acc_y_limit", 2.5}, {"acc_theta_limit", 3.0}, {"min_vel_x", -0.7}, {"min_vel_y", -0.7},
+        {"min_vel_theta", -0.7}, {"max_vel_x", 0.7}, {"max_vel_y", 0.7}, {"max_vel_trans", 0.7}, {"max_vel_theta", 0.7},
+        {"w_trans", 0.82}, {"w_orient", 0.50}, {"w_control", 0.05}, {"w_terminal", 0.05}, {"w_footprint", 0.0},
+        {"w_costmap", 0.05}, {"low_pass_gain", 0.5}, {"opt_tolerance", 1e-3}, {"prediction_horizon", 0.8},
+        {"control_steps", 3.0}};
+    for (const auto& kv : readme) if (std::strcmp(kv.n, name) == 0) return kv.v;
+    return dflt;
+  });
+  const unsigned S = 200;                                      // 10 m x 10 m rolling window, 5 cm cells
+  std::vector<unsigned char> cells(S * S, 0);
+  for (unsigned y = 120; y < 130; ++y) for (unsigned x = 40; x < 160; ++x) cells[y * S + x] = 254;   // a wall north of the path
+  nav2_costmap_2d::Costmap2D costmap;
+  costmap.cells = cells.data(); costmap.sx = S; costmap.sy = S; costmap.res = 0.05; costmap.ox = -5.0; costmap.oy = -5.0;
+  double x = -3.0, y = 0.0, yaw = 0.3;
+  geometry_msgs::msg::Twist speed;
+  geometry_msgs::msg::Pose goal;
+  goal.position.x = 4.0; goal.orientation.w = 1.0;
+  std::vector<double> us;
+  double worst = 0.0;
+  for (int tick = 0; tick < 300; ++tick) {
+    geometry_msgs::msg::PoseStamped position, carrot;
+    position.pose.position.x = x; position.pose.position.y = y;
+    position.pose.orientation.z = std::sin(0.5 * yaw); position.pose.orientation.w = std::cos(0.5 * yaw);
+    // look-ahead point 0.4 m further along the plan y = 0, heading 0, expressed in the base frame
+    const double cxw = std::min(x + 0.4, 4.0), cyw = 0.0;
+    const double dx = cxw - x, dy = cyw - y;
+    carrot.pose.position.x = std::cos(yaw) * dx + std::sin(yaw) * dy;
+    carrot.pose.position.y = -std::sin(yaw) * dx + std::cos(yaw) * dy;
+    carrot.pose.orientation.z = std::sin(-0.5 * yaw); carrot.pose.orientation.w = std::cos(-0.5 * yaw);
+    const auto t0 = std::chrono::steady_clock::now();
+    const auto cmd = seam.solve(position, speed, carrot, goal, costmap, /*footprint_cost_raw=*/0.0);
+    const double dt_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    if (tick >= 20) us.push_back(dt_us);
+    const double vx = cmd.twist.linear.x, vy = cmd.twist.linear.y, w = cmd.twist.angular.z;
+    if (!std::isfinite(vx) || !std::isfinite(vy) || !std::isfinite(w)) { std::printf("non-finite command at tick %d\n", tick); return 2; }
+    worst = std::max(worst, std::hypot(vx, vy));
+    yaw += w / 30.0;
+    x += (vx * std::cos(yaw) - vy * std::sin(yaw)) / 30.0;
+    y += (vx * std::sin(yaw) + vy * std::cos(yaw)) / 30.0;
+    speed.linear.x = vx; speed.linear.y = vy; speed.angular.z = w;
+  }
+  seam.cleanupSolver();
+  std::sort(us.begin(), us.end());
+  std::printf("{\"what\": \"plugin seam (C++ -> C-ABI, host buffers, count = 1), 280 warm ticks\", \"tick_us_median\": %.1f, "
+              "\"tick_us_p99\": %.1f, \"final_x\": %.3f, \"final_y\": %.3f, \"final_yaw\": %.3f, \"max_speed\": %.3f}\n",
+              us[us.size() / 2], us[us.size() * 99 / 100], x, y, yaw, worst);
+  return (x > 3.0 && std::fabs(y) < 0.2 && worst <= 0.7 + 1e-9) ? 0 : 3;
 }

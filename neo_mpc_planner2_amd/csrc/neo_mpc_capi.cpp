@@ -71,7 +71,15 @@ struct neo_mpc_handle {
   DeviceBuffer map_buf, raw_buf, term_buf;
   DeviceBuffer problems, states, warm, commands, solution, path, footprints, success, u, cost;
   DeviceBuffer plan_poses, plan_offsets, robot_poses, fp_costs, slow_down, carrots, vel;
+  // latency path of neo_mpc_solve_batch (small host batches, the plugin's count = 1): one pinned
+  // staging block and one device arena, so a tick is one H2D, K1, one D2H and one synchronisation
+  void* pin = nullptr;
+  DeviceBuffer arena;
 };
+constexpr size_t kLatencyPathMaxCount = 64;
+constexpr size_t kLatencyPathBytes = kLatencyPathMaxCount * (sizeof(neo_mpc_problem) + sizeof(neo_mpc_state) +
+                                                            sizeof(neo_mpc_command) + 24 +
+                                                            3 * 3 * NEO_MPC_MAX_CONTROL_STEPS * 8);
 
 namespace {
 
@@ -337,8 +345,10 @@ void neo_mpc_destroy(neo_mpc_handle* h) {
   (void)hipSetDevice(h->device);
   DeviceBuffer* all[] = {&h->map_buf, &h->raw_buf, &h->term_buf, &h->problems, &h->states, &h->warm, &h->commands,
                          &h->solution, &h->path, &h->footprints, &h->success, &h->u, &h->cost, &h->plan_poses,
-                         &h->plan_offsets, &h->robot_poses, &h->fp_costs, &h->slow_down, &h->carrots, &h->vel};
+                         &h->plan_offsets, &h->robot_poses, &h->fp_costs, &h->slow_down, &h->carrots, &h->vel,
+                         &h->arena};
   for (DeviceBuffer* b : all) b->release();
+  if (h->pin) (void)hipHostFree(h->pin);
   delete h;
 }
 
@@ -363,7 +373,8 @@ int neo_mpc_set_costmap(neo_mpc_handle* h, const uint8_t* cells, uint32_t sx, ui
   HIP_TRY(hipMemcpy(h->raw_buf.ptr, cells, (size_t)sx * sy, hipMemcpyHostToDevice));
   rc = ingest(h, (const uint8_t*)h->raw_buf.ptr, sx, sy, res, ox, oy, nullptr);
   if (rc) return rc;
-  HIP_TRY(hipDeviceSynchronize());
+  // no synchronisation: `cells` has been consumed by the (blocking) copy above, and K3 runs on the
+  // null stream in front of whatever reads the map next
   return NEO_MPC_OK;
 }
 
@@ -384,12 +395,55 @@ int neo_mpc_solve_batch_device(neo_mpc_handle* h, const neo_mpc_batch* batch, vo
   return NEO_MPC_OK;
 }
 
+// neo_mpc_solve_batch for count <= kLatencyPathMaxCount without a footprint raster:
+// [problems | states | warm | commands | velocities | solution | path] laid out once in a pinned block and
+// mirrored in a device arena -- the whole input goes up in one copy, the whole output comes back in
+// one, and the only synchronisation is the one that makes the results visible.
+static int solve_batch_latency_path(neo_mpc_handle* h, const neo_mpc_batch* b) {
+  const size_t n = b->count, nv = 3 * (size_t)h->params.control_steps;
+  if (!h->pin) HIP_TRY(hipHostMalloc(&h->pin, kLatencyPathBytes, hipHostMallocDefault));
+  int rc = h->arena.reserve(kLatencyPathBytes);
+  if (rc) return rc;
+  const size_t o_prob = 0, o_state = o_prob + n * sizeof(neo_mpc_problem), o_warm = o_state + n * sizeof(neo_mpc_state),
+               o_cmd = o_warm + n * nv * 8, o_vel = o_cmd + n * sizeof(neo_mpc_command), o_sol = o_vel + n * 24,
+               o_path = o_sol + (b->solution ? n * nv * 8 : 0), o_end = o_path + (b->predicted_path ? n * nv * 8 : 0);
+  char* pin = (char*)h->pin;
+  char* dev = (char*)h->arena.ptr;
+  memcpy(pin + o_prob, b->problems, n * sizeof(neo_mpc_problem));
+  memcpy(pin + o_state, b->states, n * sizeof(neo_mpc_state));
+  memcpy(pin + o_warm, b->warm_start, n * nv * 8);
+  HIP_TRY(hipMemcpyAsync(dev, pin, o_cmd, hipMemcpyHostToDevice, nullptr));
+  neo_mpc_batch d = *b;
+  d.problems = (const neo_mpc_problem*)(dev + o_prob);
+  d.states = (neo_mpc_state*)(dev + o_state);
+  d.warm_start = (double*)(dev + o_warm);
+  d.commands = (neo_mpc_command*)(dev + o_cmd);
+  d.velocities = (double*)(dev + o_vel);
+  if (b->solution) d.solution = (double*)(dev + o_sol);
+  if (b->predicted_path) d.predicted_path = (double*)(dev + o_path);
+  SolveArgs a;
+  if ((rc = fill_args(h, &d, a))) return rc;
+  launch_solve(a, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(pin + o_state, dev + o_state, o_end - o_state, hipMemcpyDeviceToHost, nullptr));
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  memcpy(b->states, pin + o_state, n * sizeof(neo_mpc_state));
+  memcpy(b->warm_start, pin + o_warm, n * nv * 8);
+  memcpy(b->commands, pin + o_cmd, n * sizeof(neo_mpc_command));
+  if (b->velocities) memcpy(b->velocities, pin + o_vel, n * 24);
+  if (b->solution) memcpy(b->solution, pin + o_sol, n * nv * 8);
+  if (b->predicted_path) memcpy(b->predicted_path, pin + o_path, n * nv * 8);
+  return NEO_MPC_OK;
+}
+
 int neo_mpc_solve_batch(neo_mpc_handle* h, const neo_mpc_batch* batch) {
   SolveArgs a;
   int rc = fill_args(h, batch, a);  // validates
   if (rc) return rc;
   if (batch->count == 0) return NEO_MPC_OK;
   HIP_TRY(hipSetDevice(h->device));
+  if (batch->count <= kLatencyPathMaxCount && !batch->footprints)
+    return solve_batch_latency_path(h, batch);
   neo_mpc_batch d;
   if ((rc = stage_in(h, batch, d, false))) return rc;
   if ((rc = fill_args(h, &d, a))) return rc;

@@ -274,3 +274,26 @@ def test_server_mirror_episode_matches_oracle_wrapper():
     node2.cb_params([NS(name="max_vel_x", value=0.1, type_=3)])
     assert node2._solver.params["max_vel_x"] == 0.1
     node2.close()
+
+
+def test_plugin_seam_example_runs_a_control_loop(tmp_path):
+    """examples/plugin_seam.cpp --run: the C++ a maintainer pastes into NeoMpcPlanner.cpp (cpp:240-252
+    replacement), compiled with g++ against include/neo_mpc.h, drives one robot for 300 ticks through
+    the C-ABI alone (no Python, no torch): finite commands inside the speed disc, the robot follows
+    the plan past a wall to its end, and the per-tick latency is printed."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "seam"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "plugin_seam.cpp"),
+                           "-L", os.path.join(root, "neo_mpc_planner2_amd"), "-lneo_mpc",
+                           "-Wl,-rpath," + os.path.join(root, "neo_mpc_planner2_amd"),
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    out = subprocess.run([str(exe), "--run"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.returncode, out.stdout[-500:], out.stderr[-500:])
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["final_x"] > 3.0 and abs(rec["final_y"]) < 0.2 and rec["max_speed"] <= 0.7 + 1e-9
+    assert rec["tick_us_median"] < 5000.0   # (the reference's tick is 11.6 ms + the DDS hop)
+    print(rec)
