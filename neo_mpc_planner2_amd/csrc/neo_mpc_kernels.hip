@@ -74,6 +74,15 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     a.lds.tile_w = tile_w; a.lds.tile_h = tile_h; a.lds.reach = reach;
     a.p.n = kSteps;
   }
+  // The parameters the solver loop reads are detached from the wide scalar loads that bring the
+  // kernel arguments in: a spilled s_load_dwordx16 tuple comes back whole (16 v_readlane) for every
+  // use of one of its members; as values of their own they are reloaded pair by pair.
+  {
+    auto own = [](double& v) { asm volatile("" : "+s"(v)); };
+    own(a.p.dt); own(a.p.wt_n); own(a.p.wo_n); own(a.p.wc_n); own(a.p.wterm_o); own(a.p.r);
+    own(a.p.lo[2]); own(a.p.hi[2]);
+    own(a.map.origin_x); own(a.map.origin_y); own(a.map.resolution); own(a.map.inv_resolution);
+  }
   const int lane = threadIdx.x;
   const uint32_t b = blockIdx.x;
   if (b >= a.count) return;
@@ -109,7 +118,6 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     t[T_KONST] = c.konst; t[T_TRUE_YAW] = c.true_yaw;
   }
   c.konst = 0.0; c.true_yaw = 0.0;
-  const volatile double* TOL = L + a.lds.tol;
   double* u = L + a.lds.u;
   double* gs = L + a.lds.gs;
   double* gt = L + a.lds.gt;
@@ -157,6 +165,11 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     // at 4 waves/SIMD, parks them in scratch -- recomputing them costs a few integer operations.
     int lane = lane_id;
     asm volatile("" : "+v"(lane));
+    // (same trick for the tolerance block: an opaque LDS offset keeps its loads inside the loop and in
+    // the LDS address space -- a volatile pointer would turn them into flat loads with a full wait each)
+    int tol_off = a.lds.tol;
+    asm volatile("" : "+s"(tol_off));
+    const double* TOL = L + tol_off;
     // ---- adjoint gradient of the tracking + terminal cost
     constexpr int kVars = 3 * kNwSteps;  // compile-time bound of the Newton system (= its size when kSteps > 0)
     const int nvr = kSteps ? kVars : nv;  // its size
@@ -644,8 +657,8 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   if (a.solution)
     for (int k = lane; k < nv; k += kLanes) a.solution[(size_t)b * nv + k] = u[k];
   WAVE_SYNC();
-  f += TOL[T_KONST];
-  c.true_yaw = TOL[T_TRUE_YAW];
+  f += L[a.lds.tol + T_KONST];
+  c.true_yaw = L[a.lds.tol + T_TRUE_YAW];
   postprocess(a, c, L, b, lane, u, status == NEO_MPC_STATUS_CONVERGED, fcost, flags, f, status, it, nfev);
 }
 
