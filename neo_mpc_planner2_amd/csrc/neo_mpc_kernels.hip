@@ -46,6 +46,20 @@ namespace {
 // consecutive iterations gaining less than ftol*max(1,|f|) or moving less than stall_step that end
 // the search (creeping along a costmap cell edge gains ~1e-9 per iteration for ever)
 constexpr int kStallIterations = 5;
+
+// Study build (make timing -> libneo_mpc_timing.so, tools/phase_timing.py): shader-clock stamps at the
+// phase boundaries of solver iteration 2, written over the first six entries of `solution`.
+#ifdef NEO_MPC_PHASE_TIMING
+#define NEO_PHASE_DECL long long phase_clock[8]
+#define NEO_PHASE(k) phase_clock[k] = clock64()
+#define NEO_PHASE_DUMP()                                                                            \
+  if (it == 2 && a.solution && lane == 0)                                                          \
+    for (int k = 0; k < 6; ++k) a.solution[(size_t)b * nv + k] = (double)(phase_clock[k + 1] - phase_clock[k])
+#else
+#define NEO_PHASE_DECL
+#define NEO_PHASE(k)
+#define NEO_PHASE_DUMP()
+#endif
 // largest control_steps the run-time-sized Newton kernel takes (a 24 x 24 system: rows in registers)
 constexpr int kNewtonMaxSteps = 8;
 
@@ -170,6 +184,8 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     int tol_off = a.lds.tol;
     asm volatile("" : "+s"(tol_off));
     const double* TOL = L + tol_off;
+    NEO_PHASE_DECL;
+    NEO_PHASE(0);
     // ---- adjoint gradient of the tracking + terminal cost
     constexpr int kVars = 3 * kNwSteps;  // compile-time bound of the Newton system (= its size when kSteps > 0)
     const int nvr = kSteps ? kVars : nv;  // its size
@@ -294,6 +310,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       }
       WAVE_SYNC();
     }
+    NEO_PHASE(1);
     // ---- total gradient (control norm: minimal-norm subgradient at the kink), tangent-cone
     //      reduction at active bounds; lanes take steps
     for (int i = lane; i < n; i += kLanes) {
@@ -386,6 +403,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       }
     }
     WAVE_SYNC();
+    NEO_PHASE(2);
     if (kNewton && it == 0 && cold) {
       // a cold start (x0 = 0, the reference's reset state py:359) is far from the minimiser and the
       // Newton step almost never wins there: steepest descent on the face for this one iteration
@@ -489,6 +507,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       if (lane < nvr) d[lane] = (double)sol;
       WAVE_SYNC();
     }
+    NEO_PHASE(3);
     // ---- new curvature pair
     if (!kNewton && it > 0) {
       double* s = Sm + head * nv;
@@ -592,6 +611,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       // and taken like any other, but nothing re-checks the point it lands on
       if ((double)dm < TOL[T_FINAL] && !near_any) final_step = true;
     }
+    NEO_PHASE(4);
     // ---- 64 candidates, one rollout per lane; lowest objective wins
     const double pstep = alpha * lane_scale(lane);
     const double step = lane < 32 ? pstep : lane_scale(lane);
@@ -605,6 +625,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         [&](int i, double sn, double cs) {
           if (kSteps && !kNewton) { cand_sn[i] = sn; cand_cs[i] = cs; }
         });
+    NEO_PHASE(5);
     if (!(fc == fc)) fc = INFINITY;
     if (it == 0) f = lane_value(fc, 0);
     double fb = fc;
@@ -651,11 +672,15 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       alpha = clampd(alpha, 1e-6, 1e6);
     }
     WAVE_SYNC();
+    NEO_PHASE(6);
+    NEO_PHASE_DUMP();
     if ((double)stepmax < TOL[T_XTOL] || stall >= kStallIterations || creeping || final_step) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
   }
 
+#ifndef NEO_MPC_PHASE_TIMING
   if (a.solution)
     for (int k = lane; k < nv; k += kLanes) a.solution[(size_t)b * nv + k] = u[k];
+#endif
   WAVE_SYNC();
   f += L[a.lds.tol + T_KONST];
   c.true_yaw = L[a.lds.tol + T_TRUE_YAW];
