@@ -190,6 +190,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     constexpr int kVars = 3 * kNwSteps;  // compile-time bound of the Newton system (= its size when kSteps > 0)
     const int nvr = kSteps ? kVars : nv;  // its size
     float hc[kVars];     // Newton: column `lane` of the Hessian, then row `lane` (float32, see below)
+    float newton_sol = 0.0f;  // Newton: entry `lane` of the direction
     double hcol[kSteps ? kVars : 1];  // control_steps specialisation: gradient of this lane's perturbed copy
     if (kNewton) {
       // Every lane runs the rollout + adjoint sweep on its own copy of u: lane k < 3N perturbs
@@ -505,6 +506,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         }
       }
       if (lane < nvr) d[lane] = (double)sol;
+      newton_sol = sol;
       WAVE_SYNC();
     }
     NEO_PHASE(3);
@@ -584,7 +586,10 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       if (lane + 128 < nv) d[lane + 128] = -q2;
       WAVE_SYNC();
     }
-    {
+    if (!kNewton) {
+      // (the Newton system is built on the face: H_r = P H P + (I - P) with a right-hand side inside
+      // it, so its solution needs no restriction -- what rounding leaves outside is removed by the
+      // projection of every candidate)
       for (int i = lane; i < n; i += kLanes) {  // restrict the direction to the tangent cone's face
         if (AMODE[4 * i + 2]) { d[3 * i] = 0.0; d[3 * i + 1] = 0.0; d[3 * i + 2] = 0.0; continue; }
         if (AMODE[4 * i + 1]) d[3 * i + 2] = 0.0;
@@ -603,7 +608,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       // the kink are moved by the prox step, which d does not describe -- keep iterating then)
       float dm = 0.0f;
       int anynear = 0;
-      if (lane < nvr) { dm = (float)fabs(d[lane]); anynear = AMODE[4 * (lane / 3) + 2]; }
+      if (lane < nvr) { dm = fabsf(newton_sol); anynear = AMODE[4 * (lane / 3) + 2]; }   // (d[lane], still in a register)
       dm = wave_max_f(dm);
       const bool near_any = __ballot(anynear != 0) != 0ull;
       if ((double)dm < TOL[T_EARLY] && !near_any) { status = NEO_MPC_STATUS_CONVERGED; break; }
