@@ -638,32 +638,48 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     wave_argmin(fb, best);
     ++nfev;
     if (!(fb < f)) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
-    if (kSteps) {
+    float stepmax = 0.0f;
+    if (kSteps && kNewton) {
+      // the winner holds its candidate in registers: it measures the step against u and overwrites u
+      // in place -- one LDS round trip, no staging copy, no wave-wide maximum (the Newton path keeps
+      // no previous iterate or gradient)
       if (lane == best) {
 #pragma unroll
-        for (int i = 0; i < kRegSteps; ++i) {
-          u_new[3 * i] = cand[3 * i]; u_new[3 * i + 1] = cand[3 * i + 1]; u_new[3 * i + 2] = cand[3 * i + 2];
-          if (!kNewton) { ASN[i] = cand_sn[i]; ACS[i] = cand_cs[i]; }
+        for (int k = 0; k < 3 * kRegSteps; ++k) {
+          stepmax = fmaxf(stepmax, (float)fabs(cand[k] - u[k]));
+          u[k] = cand[k];
         }
       }
+      stepmax = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, stepmax), best));
+      have_trig = true;
     } else {
-      // rebuild the winning candidate cooperatively: lane i takes control block i
-      const double bstep = lane_value(step, best), bpstep = lane_value(pstep, best);
-      for (int i = lane; i < n; i += kLanes) {
-        double b0, b1, b2;
-        candidate_block<kTame>(a, c, L, best, bstep, bpstep, i, b0, b1, b2);
-        u_new[3 * i] = b0; u_new[3 * i + 1] = b1; u_new[3 * i + 2] = b2;
+      if (kSteps) {
+        if (lane == best) {
+#pragma unroll
+          for (int i = 0; i < kRegSteps; ++i) {
+            u_new[3 * i] = cand[3 * i]; u_new[3 * i + 1] = cand[3 * i + 1]; u_new[3 * i + 2] = cand[3 * i + 2];
+            if (!kNewton) { ASN[i] = cand_sn[i]; ACS[i] = cand_cs[i]; }
+          }
+        }
+      } else {
+        // rebuild the winning candidate cooperatively: lane i takes control block i
+        const double bstep = lane_value(step, best), bpstep = lane_value(pstep, best);
+        for (int i = lane; i < n; i += kLanes) {
+          double b0, b1, b2;
+          candidate_block<kTame>(a, c, L, best, bstep, bpstep, i, b0, b1, b2);
+          u_new[3 * i] = b0; u_new[3 * i + 1] = b1; u_new[3 * i + 2] = b2;
+        }
       }
+      have_trig = true;
+      WAVE_SYNC();
+      for (int k = lane; k < nv; k += kLanes) {
+        const double nu = u_new[k], ou = u[k];
+        stepmax = fmaxf(stepmax, (float)fabs(nu - ou));
+        if (!kNewton) { u_prev[k] = ou; gt_prev[k] = gt[k]; }
+        u[k] = nu;
+      }
+      stepmax = wave_max_f(stepmax);
     }
-    have_trig = true;
-    WAVE_SYNC();
-    float stepmax = 0.0f;
-    for (int k = lane; k < nv; k += kLanes) {
-      const double nu = u_new[k], ou = u[k];
-      stepmax = fmaxf(stepmax, (float)fabs(nu - ou));
-      u_prev[k] = ou; gt_prev[k] = gt[k]; u[k] = nu;
-    }
-    stepmax = wave_max_f(stepmax);
     const double gain = f - fb;
     const double fscale = fmax(1.0, fabs(fb + TOL[T_KONST]));
     stall = (gain <= TOL[T_FTOL] * fscale || (double)stepmax <= TOL[T_STALL]) ? stall + 1 : 0;
