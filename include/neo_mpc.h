@@ -208,7 +208,9 @@ int neo_mpc_set_params(neo_mpc_handle* handle, const neo_mpc_params* params);
 int neo_mpc_get_params(const neo_mpc_handle* handle, neo_mpc_params* params);
 
 /* Replaces the node's `Costmap2d(self)` subscription (py:118): raw nav2 costs, row-major
- * cells[my*size_x + mx] (e.g. `costmap_->getCharMap()` in the plugin).  The data is copied. */
+ * cells[my*size_x + mx] (e.g. `costmap_->getCharMap()` in the plugin).  The data is copied before the
+ * call returns; the device-side ingest is left in flight, ordered in front of every later call on
+ * this handle (the *_device entry points wait for it on the caller's stream). */
 int neo_mpc_set_costmap(neo_mpc_handle* handle, const uint8_t* cells, uint32_t size_x,
                         uint32_t size_y, double resolution, double origin_x, double origin_y);
 /* Same, `d_cells` already in device memory; ingested on `stream` (hipStream_t, may be NULL). */

@@ -75,6 +75,9 @@ struct neo_mpc_handle {
   // staging block and one device arena, so a tick is one H2D, K1, one D2H and one synchronisation
   void* pin = nullptr;
   DeviceBuffer arena;
+  // neo_mpc_set_costmap (host cells) ingests on the null stream without waiting for it; work the
+  // caller enqueues on its own (possibly non-blocking) streams is ordered behind this event
+  hipEvent_t map_ready = nullptr;
 };
 constexpr size_t kLatencyPathMaxCount = 64;
 constexpr size_t kLatencyPathBytes = kLatencyPathMaxCount * (sizeof(neo_mpc_problem) + sizeof(neo_mpc_state) +
@@ -349,6 +352,7 @@ void neo_mpc_destroy(neo_mpc_handle* h) {
                          &h->arena};
   for (DeviceBuffer* b : all) b->release();
   if (h->pin) (void)hipHostFree(h->pin);
+  if (h->map_ready) (void)hipEventDestroy(h->map_ready);
   delete h;
 }
 
@@ -373,8 +377,10 @@ int neo_mpc_set_costmap(neo_mpc_handle* h, const uint8_t* cells, uint32_t sx, ui
   HIP_TRY(hipMemcpy(h->raw_buf.ptr, cells, (size_t)sx * sy, hipMemcpyHostToDevice));
   rc = ingest(h, (const uint8_t*)h->raw_buf.ptr, sx, sy, res, ox, oy, nullptr);
   if (rc) return rc;
-  // no synchronisation: `cells` has been consumed by the (blocking) copy above, and K3 runs on the
-  // null stream in front of whatever reads the map next
+  // no synchronisation: `cells` has been consumed by the (blocking) copy above; K3 runs on the null
+  // stream in front of the library's own launches, and the *_device entry points wait for map_ready
+  if (!h->map_ready) HIP_TRY(hipEventCreateWithFlags(&h->map_ready, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(h->map_ready, nullptr));
   return NEO_MPC_OK;
 }
 
@@ -390,6 +396,7 @@ int neo_mpc_solve_batch_device(neo_mpc_handle* h, const neo_mpc_batch* batch, vo
   int rc = fill_args(h, batch, a);
   if (rc) return rc;
   HIP_TRY(hipSetDevice(h->device));  // the stream and the buffers must belong to the handle's device
+  if (h->map_ready && stream) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, h->map_ready, 0));
   launch_solve(a, stream);
   HIP_TRY(hipGetLastError());
   return NEO_MPC_OK;
