@@ -47,15 +47,27 @@ namespace {
 // the search (creeping along a costmap cell edge gains ~1e-9 per iteration for ever)
 constexpr int kStallIterations = 5;
 
-// Study build (make timing -> libneo_mpc_timing.so, tools/phase_timing.py): shader-clock stamps at the
-// phase boundaries of solver iteration 2, written over the first six entries of `solution`.
+// Study build (make timing -> libneo_mpc_timing.so): shader-clock stamps at the phase boundaries of
+// solver iteration 2 in entries 0-5 of `solution` (tools/phase_timing.py); wall-clock start and end of
+// the wave and its HW_ID in entries 6-8 (tools/wave_timeline.py; control_steps >= 3).
 #ifdef NEO_MPC_PHASE_TIMING
+#define NEO_WAVE_START const unsigned long long wave_t0 = wall_clock64()
+#define NEO_WAVE_END()                                                                              \
+  if (a.solution && lane == 0 && nv >= 9) {                                                        \
+    unsigned int hw_id;                                                                            \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));                            \
+    a.solution[(size_t)b * nv + 6] = (double)wave_t0;                                              \
+    a.solution[(size_t)b * nv + 7] = (double)wall_clock64();                                       \
+    a.solution[(size_t)b * nv + 8] = (double)hw_id;                                                \
+  }
 #define NEO_PHASE_DECL long long phase_clock[8]
 #define NEO_PHASE(k) phase_clock[k] = clock64()
 #define NEO_PHASE_DUMP()                                                                            \
   if (it == 2 && a.solution && lane == 0)                                                          \
     for (int k = 0; k < 6; ++k) a.solution[(size_t)b * nv + k] = (double)(phase_clock[k + 1] - phase_clock[k])
 #else
+#define NEO_WAVE_START
+#define NEO_WAVE_END()
 #define NEO_PHASE_DECL
 #define NEO_PHASE(k)
 #define NEO_PHASE_DUMP()
@@ -100,6 +112,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   const int lane = threadIdx.x;
   const uint32_t b = blockIdx.x;
   if (b >= a.count) return;
+  NEO_WAVE_START;
   const DevParams& p = a.p;
   const int n = kSteps ? kSteps : p.n, nv = 3 * n, mem = p.mem;
   constexpr int kRegSteps = kSteps ? kSteps : 1;
@@ -706,6 +719,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   f += L[a.lds.tol + T_KONST];
   c.true_yaw = L[a.lds.tol + T_TRUE_YAW];
   postprocess(a, c, L, b, lane, u, status == NEO_MPC_STATUS_CONVERGED, fcost, flags, f, status, it, nfev);
+  NEO_WAVE_END();
 }
 
 // K2 on its own: `solution` supplies x.x, `success` supplies x.success

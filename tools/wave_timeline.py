@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Study: per-wave start/end times of one C2 launch (needs the timing build of the library:
-NEO_MPC_LIB=.../libneo_mpc_timing.so, which writes wall_clock64 stamps and HW_ID into `solution`)."""
+"""Study: per-wave start/end times of one C2 launch.  Needs the timing build of the library, which
+writes wall_clock64 stamps and HW_ID into entries 6-8 of `solution`:
+make -C neo_mpc_planner2_amd/csrc timing; NEO_MPC_LIB=neo_mpc_planner2_amd/libneo_mpc_timing.so python tools/wave_timeline.py"""
 import sys, os, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,7 +15,7 @@ with BatchSolver(params) as s:
     for rep in range(3):
         st, warm = synthetic.make_states(probs, 3)
         cmds, x = s.solve(probs, st, warm)
-t0, t1, hw = x[:, 0], x[:, 1], x[:, 2].astype(np.int64)
+t0, t1, hw = x[:, 6], x[:, 7], x[:, 8].astype(np.int64)
 base = t0.min()
 us = lambda t: (t - base) / 100.0     # wall_clock64: 100 MHz
 it = cmds["iterations"]
