@@ -297,3 +297,29 @@ def test_plugin_seam_example_runs_a_control_loop(tmp_path):
     assert rec["final_x"] > 3.0 and abs(rec["final_y"]) < 0.2 and rec["max_speed"] <= 0.7 + 1e-9
     assert rec["tick_us_median"] < 5000.0   # (the reference's tick is 11.6 ms + the DDS hop)
     print(rec)
+
+
+def test_bench_emits_the_contract_line():
+    """`python bench.py --gpus 1 --steps K --warmup W` prints ONE JSON line, last on stdout, with the
+    driver's keys, BASELINE.json's metric, the roofline object of the dominant kernel and (without
+    --no-cpu-baseline) the CPU baseline object."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-800:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in rec, key
+    assert rec["metric"].startswith("MPC solves/sec") and rec["unit"] == "solves/s" and rec["steps"] == 5
+    assert rec["n_gpus"] == 1 and rec["higher_is_better"] is True and rec["vs_baseline"] is None
+    assert rec["dtype"] == "f64" and rec["data"] == "synthetic" and rec["config"]["workload"].startswith("C2")
+    r = rec["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(rec["value"] - 4096 * 5 / (rec["ms_per_step"] * 5e-3)) / rec["value"] < 1e-9
+    assert rec["value"] > 1e6            # the north star's floor on one MI355X
+    assert rec["solver"]["converged_frac"] == 1.0
