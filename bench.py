@@ -145,14 +145,24 @@ def main():
     ring = 4
     gathered = [torch.empty((world, cfg["batch"], 3), dtype=torch.float64, device=dev) for _ in range(ring)] \
         if use_dist else None
-    stream = torch.cuda.current_stream()
+    # a stream of its own for the hot path: on the legacy default stream the next tick's K1 ends up ordered
+    # behind the previous tick's gather (measured with rocprofv3 --kernel-trace: 35 us between launches)
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
     pending = []
 
-    def exchange(i, b):
-        # no per-tick wait on the solve stream: gathers are ordered among themselves on RCCL's
-        # stream, so a ring buffer is rewritten only after its previous gather; handles are
-        # waited for once, before the timed region closes
-        _, work = gather_commands(b.vel, gathered[i % ring], async_op=True)   # packed by K1, no copy
+    def exchange(i, b, done):
+        # The collective is issued from a side stream that waits for `done` (the event recorded after
+        # this tick's K1), so the solve stream itself carries nothing but K1 and its two timing events:
+        # every extra event record between two launches costs ~4 us of barrier-packet latency.  No
+        # per-tick wait on the solve stream either: gathers are ordered among themselves on RCCL's
+        # stream, so a ring buffer is rewritten only after its previous gather; handles are waited
+        # for once, before the timed region closes.
+        comm_stream.wait_event(done)
+        with torch.cuda.stream(comm_stream):
+            _, work = gather_commands(b.vel, gathered[i % ring], async_op=True)   # packed by K1, no copy
         pending.append(work)
 
     def drain():
@@ -160,13 +170,17 @@ def main():
             pending.pop(0).wait()
 
     if use_dist:   # communicator set-up happens here, never inside the timed region
-        exchange(0, warm_sets[0] if warm_sets else sets[0])
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        exchange(0, warm_sets[0] if warm_sets else sets[0], ev)
         drain()
     for i in range(args.warmup):
         b = warm_sets[i % len(warm_sets)]
         solver.solve_device(base.problems, b.states, b.warm, b.commands, velocities=b.vel)
         if use_dist:
-            exchange(i, b)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            exchange(i, b, ev)
     drain()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     torch.cuda.synchronize()
@@ -179,7 +193,7 @@ def main():
         solver.solve_device(base.problems, b.states, b.warm, b.commands, velocities=b.vel)
         evs[i][1].record(stream)
         if use_dist:
-            exchange(i, b)
+            exchange(i, b, evs[i][1])
     drain()
     torch.cuda.synchronize()
     if use_dist:
