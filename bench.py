@@ -182,16 +182,20 @@ def main():
             ev.record(stream)
             exchange(i, b, ev)
     drain()
+    # HIP events per launch, stamped by the dispatch itself (hipExtLaunchKernel through
+    # neo_mpc_solve_batch_device_timed): separate event records would put two barrier packets between
+    # consecutive K1 launches.  (Recorded once here so that the handles exist.)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for e0, e1 in evs:
+        e0.record(stream)
+        e1.record(stream)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         b = sets[i]
-        evs[i][0].record(stream)
-        solver.solve_device(base.problems, b.states, b.warm, b.commands, velocities=b.vel)
-        evs[i][1].record(stream)
+        solver.solve_device(base.problems, b.states, b.warm, b.commands, velocities=b.vel, events=evs[i])
         if use_dist:
             exchange(i, b, evs[i][1])
     drain()

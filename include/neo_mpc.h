@@ -224,6 +224,11 @@ int neo_mpc_set_costmap_device(neo_mpc_handle* handle, const uint8_t* d_cells, u
 int neo_mpc_solve_batch(neo_mpc_handle* handle, const neo_mpc_batch* batch);
 /* Same with every pointer in device memory; enqueued on `stream`, returns without waiting. */
 int neo_mpc_solve_batch_device(neo_mpc_handle* handle, const neo_mpc_batch* batch, void* stream);
+/* Same; `start_event` / `stop_event` (hipEvent_t, either may be NULL) are stamped with the start and the
+ * end of the solve kernel by the dispatch itself (hipExtLaunchKernel): a measurement harness gets K1's
+ * duration without putting event-record packets between consecutive launches. */
+int neo_mpc_solve_batch_device_timed(neo_mpc_handle* handle, const neo_mpc_batch* batch, void* stream,
+                                     void* start_event, void* stop_event);
 
 /* Only the part of `optimizer` after the solve (py:365-403): low-pass, collision check, stop
  * latch, acceleration clamp, warm-start shift, with `batch->solution` supplying `x.x` and

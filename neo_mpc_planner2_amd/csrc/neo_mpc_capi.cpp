@@ -391,15 +391,20 @@ int neo_mpc_set_costmap_device(neo_mpc_handle* h, const uint8_t* d_cells, uint32
   return ingest(h, d_cells, sx, sy, res, ox, oy, stream);
 }
 
-int neo_mpc_solve_batch_device(neo_mpc_handle* h, const neo_mpc_batch* batch, void* stream) {
+int neo_mpc_solve_batch_device_timed(neo_mpc_handle* h, const neo_mpc_batch* batch, void* stream, void* start_event,
+                                     void* stop_event) {
   SolveArgs a;
   int rc = fill_args(h, batch, a);
   if (rc) return rc;
   HIP_TRY(hipSetDevice(h->device));  // the stream and the buffers must belong to the handle's device
   if (h->map_ready && stream) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, h->map_ready, 0));
-  launch_solve(a, stream);
+  launch_solve(a, stream, start_event, stop_event);
   HIP_TRY(hipGetLastError());
   return NEO_MPC_OK;
+}
+
+int neo_mpc_solve_batch_device(neo_mpc_handle* h, const neo_mpc_batch* batch, void* stream) {
+  return neo_mpc_solve_batch_device_timed(h, batch, stream, nullptr, nullptr);
 }
 
 // neo_mpc_solve_batch for count <= kLatencyPathMaxCount without a footprint raster:

@@ -138,7 +138,7 @@ struct CarrotArgs {
   neo_mpc_plan_batch b;  // device pointers
 };
 
-void launch_solve(const SolveArgs& a, void* stream);
+void launch_solve(const SolveArgs& a, void* stream, void* ev_start = nullptr, void* ev_stop = nullptr);
 void launch_carrots(const CarrotArgs& a, void* stream);
 void launch_postprocess(const SolveArgs& a, void* stream);
 void launch_objective(const ObjectiveArgs& a, void* stream);

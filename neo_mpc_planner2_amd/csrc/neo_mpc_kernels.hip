@@ -28,6 +28,7 @@
 //
 // No MFMA: a 3*control_steps-variable problem has no dense contraction.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -899,14 +900,21 @@ static int solve_variant(int fallback) {
   return v ? v : fallback;
 }
 
-void launch_solve(const SolveArgs& a, void* stream) {
+void launch_solve(const SolveArgs& a, void* stream, void* ev_start, void* ev_stop) {
   if (a.count == 0) return;
   const dim3 grid(a.count), block(kLanes);
   hipStream_t st = (hipStream_t)stream;
   const bool generic = getenv("NEO_MPC_GENERIC_STEPS") != nullptr || a.p.mem != 4;  // A/B: LDS-only path
   const bool disc = a.p.tame != 0 && getenv("NEO_MPC_NO_TAME_SPECIALISATION") == nullptr;
   const size_t lds = a.lds.total_bytes;
-#define NEO_LAUNCH(...) hipLaunchKernelGGL((k_solve<__VA_ARGS__>), grid, block, lds, st, a)
+  // with events: hipExtLaunchKernel stamps them from the dispatch packet itself (no barrier packets in
+  // front of and behind the kernel, which is what separate hipEventRecord calls put on the queue)
+  hipEvent_t e0 = (hipEvent_t)ev_start, e1 = (hipEvent_t)ev_stop;
+#define NEO_LAUNCH(...)                                                                             \
+  do {                                                                                              \
+    if (e0 || e1) hipExtLaunchKernelGGL((k_solve<__VA_ARGS__>), grid, block, lds, st, e0, e1, 0, a); \
+    else hipLaunchKernelGGL((k_solve<__VA_ARGS__>), grid, block, lds, st, a);                       \
+  } while (0)
   if (a.p.n == 3 && a.p.newton) {  // projected Newton (its layout does not depend on lbfgs_memory)
     const int w = solve_variant(disc ? 4 : 3);
     if (disc) { if (w == 4) NEO_LAUNCH(4, 3, true, true); else if (w == 3) NEO_LAUNCH(3, 3, true, true); else NEO_LAUNCH(2, 3, true, true); }

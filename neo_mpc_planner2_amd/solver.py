@@ -173,9 +173,11 @@ class BatchSolver:
 
     # -- device-resident batches (torch tensors as plain device memory) ----------------
     def solve_device(self, problems, states, warm, commands, solution=None, path=None, footprints=None,
-                     stream=None, velocities=None):
+                     stream=None, velocities=None, events=None):
         """All arguments are CUDA uint8/float64 torch tensors holding the C records
-        (`DeviceBatch` builds them).  Enqueues K1 on `stream` (default: torch's current)."""
+        (`DeviceBatch` builds them).  Enqueues K1 on `stream` (default: torch's current).
+        `events` = (start, stop) torch.cuda.Event pair, already created (recorded once): stamped by
+        the kernel dispatch itself (`neo_mpc_solve_batch_device_timed`)."""
         import torch
         count = problems.shape[0]
         b = abi.NeoMpcBatch()
@@ -193,7 +195,12 @@ class BatchSolver:
             b.velocities = velocities.data_ptr()
         if stream is None:
             stream = torch.cuda.current_stream(problems.device).cuda_stream
-        _lib.check(self._lib.neo_mpc_solve_batch_device(self._handle, C.byref(b), C.c_void_p(stream)))
+        if events is None:
+            _lib.check(self._lib.neo_mpc_solve_batch_device(self._handle, C.byref(b), C.c_void_p(stream)))
+        else:
+            _lib.check(self._lib.neo_mpc_solve_batch_device_timed(
+                self._handle, C.byref(b), C.c_void_p(stream), C.c_void_p(events[0].cuda_event),
+                C.c_void_p(events[1].cuda_event)))
 
 
 class DeviceBatch:
