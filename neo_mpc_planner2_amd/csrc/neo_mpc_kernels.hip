@@ -87,12 +87,18 @@ constexpr int kNewtonMaxSteps = 8;
 // inside the vx/vy box -- the box/disc corner cases of the projection and of the tangent cone drop
 // out -- and whose heading cannot leave [-pi/4, pi/4] within the horizon -- no range reduction in
 // the rollout's sin/cos.
-template <int kMinWavesPerSimd, int kSteps, bool kNewton = false, bool kTame = false>
+// kStaticTile > 0 (with kSteps > 0): LDS is a static array sized for the compile-time layout plus a reach
+// tile of at most kStaticTile bytes -- every LDS address is then an instruction immediate instead of a
+// "dynamic LDS base + offset" value that lives in (and gets spilled from) a scalar register.
+template <int kMinWavesPerSimd, int kSteps, bool kNewton = false, bool kTame = false, int kStaticTile = 0>
 __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveArgs args) {
   // Newton: control_steps == kSteps, or (kSteps == 0) any control_steps <= kNewtonMaxSteps -- the
   // system's arrays are sized for the bound and every loop over them is guarded by the run-time size
   constexpr int kNwSteps = !kNewton ? 1 : kSteps ? kSteps : kNewtonMaxSteps;
-  extern __shared__ __align__(16) double L[];
+  extern __shared__ __align__(16) double Ldyn[];
+  constexpr int kStaticDoubles = kStaticTile ? (make_lds_layout(kSteps ? kSteps : 1, 4).total_bytes + kStaticTile) / 8 : 2;
+  __shared__ __align__(16) double Lstat[kStaticDoubles];
+  double* const L = kStaticTile ? Lstat : Ldyn;
   SolveArgs a = args;
   if (kSteps) {  // compile-time LDS offsets (lbfgs_memory is 4 in the specialisations' layout)
     constexpr LdsLayout kL = make_lds_layout(kSteps ? kSteps : 1, 4);
@@ -917,7 +923,12 @@ void launch_solve(const SolveArgs& a, void* stream, void* ev_start, void* ev_sto
   } while (0)
   if (a.p.n == 3 && a.p.newton) {  // projected Newton (its layout does not depend on lbfgs_memory)
     const int w = solve_variant(disc ? 4 : 3);
-    if (disc) { if (w == 4) NEO_LAUNCH(4, 3, true, true); else if (w == 3) NEO_LAUNCH(3, 3, true, true); else NEO_LAUNCH(2, 3, true, true); }
+    if (disc && w == 4 && a.lds.tile_w * a.lds.tile_h <= 1024 && getenv("NEO_MPC_DYNAMIC_LDS") == nullptr) {
+      const size_t lds_dyn = lds;   // (the static variant takes no dynamic LDS)
+      (void)lds_dyn;
+      if (e0 || e1) hipExtLaunchKernelGGL((k_solve<4, 3, true, true, 1024>), grid, block, 0, st, e0, e1, 0, a);
+      else hipLaunchKernelGGL((k_solve<4, 3, true, true, 1024>), grid, block, 0, st, a);
+    } else if (disc) { if (w == 4) NEO_LAUNCH(4, 3, true, true); else if (w == 3) NEO_LAUNCH(3, 3, true, true); else NEO_LAUNCH(2, 3, true, true); }
     else { if (w == 4) NEO_LAUNCH(4, 3, true); else if (w == 3) NEO_LAUNCH(3, 3, true); else NEO_LAUNCH(2, 3, true); }
   } else if (a.p.n == 3 && !generic) {
     const int w = solve_variant(3);

@@ -300,3 +300,26 @@ def test_fast_turning_robot_uses_the_range_reduced_trigonometry():
     assert np.abs(xg[:, 2::3]).max() > 0.9          # the solutions do turn hard
     _close(cg, cc, frac=0.97)
     assert (cg["cost"] <= cc["cost"] + 1e-6).mean() >= 0.97
+
+
+def test_static_lds_variant_equals_the_dynamic_one(monkeypatch):
+    """The headline kernel keeps its LDS in a static array when the reach tile is small enough (every
+    LDS address an instruction immediate); NEO_MPC_DYNAMIC_LDS selects the dynamic-LDS build of the
+    same code: the same iterates up to the compiler's choice of fused multiply-adds."""
+    from neo_mpc_planner2_amd.solver import BatchSolver
+    params = util.orc.make_params()
+    cmap = synthetic.make_costmap(500, seed=71)
+    probs = synthetic.make_problems(512, 500, seed=72)
+    res = []
+    for dynamic in (False, True):
+        if dynamic:
+            monkeypatch.setenv("NEO_MPC_DYNAMIC_LDS", "1")
+        st, warm = synthetic.make_states(probs, 3)
+        with BatchSolver(params) as s:
+            s.set_costmap(*cmap)
+            res.append(s.solve(probs, st, warm))
+    (c0, x0), (c1, x1) = res
+    assert (c0["iterations"] == c1["iterations"]).mean() >= 0.99
+    assert (np.abs(x0 - x1).max(axis=1) <= 1e-6).mean() >= 0.99
+    assert (np.abs(c0["vel"] - c1["vel"]).max(axis=1) <= 1e-6).mean() >= 0.99
+    assert np.allclose(c0["cost"], c1["cost"], rtol=0, atol=1e-6)
