@@ -96,16 +96,17 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   // system's arrays are sized for the bound and every loop over them is guarded by the run-time size
   constexpr int kNwSteps = !kNewton ? 1 : kSteps ? kSteps : kNewtonMaxSteps;
   extern __shared__ __align__(16) double Ldyn[];
-  constexpr int kStaticDoubles = kStaticTile ? (make_lds_layout(kSteps ? kSteps : 1, 4).total_bytes + kStaticTile) / 8 : 2;
+  // (the run-time-sized Newton kernel carves LDS for its largest system and no L-BFGS pairs)
+  constexpr LdsLayout kStaticLayout = make_lds_layout(kSteps ? kSteps : kNewtonMaxSteps, kSteps ? 4 : 0);
+  constexpr int kStaticDoubles = kStaticTile ? (kStaticLayout.total_bytes + kStaticTile) / 8 : 2;
   __shared__ __align__(16) double Lstat[kStaticDoubles];
   double* const L = kStaticTile ? Lstat : Ldyn;
   SolveArgs a = args;
-  if (kSteps) {  // compile-time LDS offsets (lbfgs_memory is 4 in the specialisations' layout)
-    constexpr LdsLayout kL = make_lds_layout(kSteps ? kSteps : 1, 4);
+  if (kSteps || kStaticTile) {  // compile-time LDS offsets (lbfgs_memory is 4 in the specialisations' layout)
     const int tile_w = args.lds.tile_w, tile_h = args.lds.tile_h, reach = args.lds.reach;
-    a.lds = kL;
+    a.lds = kStaticLayout;
     a.lds.tile_w = tile_w; a.lds.tile_h = tile_h; a.lds.reach = reach;
-    a.p.n = kSteps;
+    if (kSteps) a.p.n = kSteps;
   }
   // The parameters the solver loop reads are detached from the wide scalar loads that bring the
   // kernel arguments in: a spilled s_load_dwordx16 tuple comes back whole (16 v_readlane) for every
@@ -939,7 +940,10 @@ void launch_solve(const SolveArgs& a, void* stream, void* ev_start, void* ev_sto
     // tame specialisation -- spill-free at 3 and 2 waves/SIMD)
     const int w = solve_variant(a.p.newton && !disc ? 2 : 3);
     if (a.p.newton) {  // control_steps <= kNewtonMaxSteps
-      if (disc) { if (w == 4) NEO_LAUNCH(4, 0, true, true); else if (w == 3) NEO_LAUNCH(3, 0, true, true); else NEO_LAUNCH(2, 0, true, true); }
+      if (disc && w == 3 && a.lds.tile_w * a.lds.tile_h <= 1024 && getenv("NEO_MPC_DYNAMIC_LDS") == nullptr) {
+        if (e0 || e1) hipExtLaunchKernelGGL((k_solve<3, 0, true, true, 1024>), grid, block, 0, st, e0, e1, 0, a);
+        else hipLaunchKernelGGL((k_solve<3, 0, true, true, 1024>), grid, block, 0, st, a);
+      } else if (disc) { if (w == 4) NEO_LAUNCH(4, 0, true, true); else if (w == 3) NEO_LAUNCH(3, 0, true, true); else NEO_LAUNCH(2, 0, true, true); }
       else { if (w == 4) NEO_LAUNCH(4, 0, true); else if (w == 3) NEO_LAUNCH(3, 0, true); else NEO_LAUNCH(2, 0, true); }
     } else if (disc) { if (w == 4) NEO_LAUNCH(4, 0, false, true); else if (w == 3) NEO_LAUNCH(3, 0, false, true); else NEO_LAUNCH(2, 0, false, true); }
     else { if (w == 4) NEO_LAUNCH(4, 0); else if (w == 3) NEO_LAUNCH(3, 0); else NEO_LAUNCH(2, 0); }
