@@ -106,7 +106,10 @@ typedef struct neo_mpc_problem {
   double delta_t;          /* wall-clock seconds since the previous call (py:369-371) */
   double footprint_cost;   /* normalised getFootprintCost(published footprint) (py:262, 343); used
                               when the batch carries no polygons */
-  double reserved[7];
+  int32_t map_index;       /* which costmap of a pool this instance lives in (neo_mpc_set_costmap_pool);
+                              ignored with a single costmap */
+  int32_t reserved_i;
+  double reserved[6];
 } neo_mpc_problem;
 
 /* State the reference node keeps between requests (py:115-152).  128 bytes.  The warm
@@ -217,6 +220,18 @@ int neo_mpc_set_costmap(neo_mpc_handle* handle, const uint8_t* cells, uint32_t s
 int neo_mpc_set_costmap_device(neo_mpc_handle* handle, const uint8_t* d_cells, uint32_t size_x,
                                uint32_t size_y, double resolution, double origin_x,
                                double origin_y, void* stream);
+
+/* Fleet variant of neo_mpc_set_costmap: `count` costmaps of one size and resolution -- nav2's rolling
+ * local costmaps, one per robot or per group of robots -- stored back to back (map k at
+ * cells + k*size_x*size_y), origins[2k], origins[2k+1] = origin of map k.  Every instance reads the map
+ * its `neo_mpc_problem.map_index` names.  Replaces whatever costmap(s) the handle held. */
+int neo_mpc_set_costmap_pool(neo_mpc_handle* handle, const uint8_t* cells, uint32_t count, uint32_t size_x,
+                             uint32_t size_y, double resolution, const double* origins);
+/* Same with `d_cells` and `d_origins` in device memory; the ingest runs on `stream`.  `d_origins` is read
+ * by every later solve: it must stay valid (and may be rewritten by the caller between ticks). */
+int neo_mpc_set_costmap_pool_device(neo_mpc_handle* handle, const uint8_t* d_cells, uint32_t count,
+                                    uint32_t size_x, uint32_t size_y, double resolution,
+                                    const double* d_origins, void* stream);
 
 /* Replaces `client->async_send_request(request); result.get()` (cpp:248-250), i.e. the whole of
  * `MpcOptimizationServer.optimizer` (py:349-403), for `count` independent instances.

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("NEO_MPC_LIB") or os.path.join(HERE, "libneo_mpc.so")
 EXPORTS = (
     "neo_mpc_abi_version", "neo_mpc_last_error", "neo_mpc_default_params", "neo_mpc_create",
     "neo_mpc_destroy", "neo_mpc_set_params", "neo_mpc_get_params", "neo_mpc_set_costmap",
-    "neo_mpc_set_costmap_device", "neo_mpc_solve_batch", "neo_mpc_solve_batch_device",
+    "neo_mpc_set_costmap_device", "neo_mpc_set_costmap_pool", "neo_mpc_set_costmap_pool_device", "neo_mpc_solve_batch", "neo_mpc_solve_batch_device",
     "neo_mpc_solve_batch_device_timed",
     "neo_mpc_postprocess_batch", "neo_mpc_objective_batch", "neo_mpc_kernel_info",
     "neo_mpc_select_carrots", "neo_mpc_select_carrots_device",
@@ -64,6 +64,10 @@ def load():
                                         C.c_double, C.c_double, C.c_double]
     lib.neo_mpc_set_costmap_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                                C.c_double, C.c_double, C.c_double, C.c_void_p]
+    lib.neo_mpc_set_costmap_pool.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                             C.c_double, C.c_void_p]
+    lib.neo_mpc_set_costmap_pool_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                    C.c_double, C.c_void_p, C.c_void_p]
     lib.neo_mpc_solve_batch.argtypes = [C.c_void_p, P(abi.NeoMpcBatch)]
     lib.neo_mpc_solve_batch_device.argtypes = [C.c_void_p, P(abi.NeoMpcBatch), C.c_void_p]
     lib.neo_mpc_solve_batch_device_timed.argtypes = [C.c_void_p, P(abi.NeoMpcBatch), C.c_void_p, C.c_void_p, C.c_void_p]

@@ -21,7 +21,9 @@ PROBLEM_DTYPE = np.dtype([
     ("delta_t", "<f8"),             # wall-clock seconds since the previous call (py:369-371)
     ("footprint_cost", "<f8"),      # getFootprintCost(published footprint), normalised; used when
                                     # no polygon is supplied (py:262, 343)
-    ("reserved", "<f8", (7,)),
+    ("map_index", "<i4"),           # which costmap of a pool (BatchSolver.set_costmap_pool); else ignored
+    ("reserved_i", "<i4"),
+    ("reserved", "<f8", (6,)),
 ], align=False)
 assert PROBLEM_DTYPE.itemsize == 256
 

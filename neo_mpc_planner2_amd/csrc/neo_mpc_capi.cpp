@@ -68,7 +68,7 @@ struct neo_mpc_handle {
   DevMap map{};
   bool has_map = false;
   LdsLayout lds{};
-  DeviceBuffer map_buf, raw_buf, term_buf;
+  DeviceBuffer map_buf, raw_buf, term_buf, origins_buf;
   DeviceBuffer problems, states, warm, commands, solution, path, footprints, success, u, cost;
   DeviceBuffer plan_poses, plan_offsets, robot_poses, fp_costs, slow_down, carrots, vel;
   // latency path of neo_mpc_solve_batch (small host batches, the plugin's count = 1): one pinned
@@ -197,24 +197,32 @@ int apply_params(neo_mpc_handle* h, const neo_mpc_params* params) {
   return upload_term_table(h);
 }
 
-int ingest(neo_mpc_handle* h, const uint8_t* d_cells, uint32_t sx, uint32_t sy, double res, double ox, double oy,
-           void* stream) {
-  if (!d_cells || sx == 0 || sy == 0 || sx > (1u << 20) || sy > (1u << 20) || !(res > 0.0))
-    return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "bad costmap geometry %ux%u res %g", sx, sy, res);
+// `maps` raw costmaps back to back in device memory -> bordered, pitched device maps (K3).
+// d_origins == nullptr: a single map with origin (ox, oy); else a pool whose origins stay where they are.
+int ingest(neo_mpc_handle* h, const uint8_t* d_cells, uint32_t maps, uint32_t sx, uint32_t sy, double res, double ox,
+           double oy, const double* d_origins, void* stream) {
+  if (!d_cells || maps == 0 || sx == 0 || sy == 0 || sx > (1u << 20) || sy > (1u << 20) || !(res > 0.0))
+    return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "bad costmap geometry %ux%u x%u res %g", sx, sy, maps, res);
   const int pitch = (int)((sx + 2 * kMapBorder + 127) & ~127u);
   const int rows = (int)sy + 2 * kMapBorder;
-  int rc = h->map_buf.reserve((size_t)pitch * rows);
+  const size_t stride = (size_t)pitch * rows;
+  int rc = h->map_buf.reserve(stride * maps);
   if (rc) return rc;
   IngestArgs a;
   a.src = d_cells;
   a.dst = (uint8_t*)h->map_buf.ptr;
   a.size_x = (int)sx; a.size_y = (int)sy; a.pitch = pitch; a.rows = rows;
+  a.maps = (int)maps; a.pad_ = 0; a.dst_stride = (int64_t)stride;
   launch_ingest(a, stream);
   HIP_TRY(hipGetLastError());
   h->map.cells = (const uint8_t*)h->map_buf.ptr + (size_t)kMapBorder * pitch + kMapBorder;
   h->map.size_x = (int)sx; h->map.size_y = (int)sy; h->map.pitch = pitch;
   h->map.resolution = res; h->map.inv_resolution = 1.0 / res;
   h->map.origin_x = ox; h->map.origin_y = oy;
+  h->map.pool_count = d_origins ? (int)maps : 0;
+  h->map.pad_ = 0;
+  h->map.pool_stride = (int64_t)stride;
+  h->map.pool_origins = d_origins;
   h->has_map = true;
   derive(h);
   return NEO_MPC_OK;
@@ -349,7 +357,7 @@ void neo_mpc_destroy(neo_mpc_handle* h) {
   DeviceBuffer* all[] = {&h->map_buf, &h->raw_buf, &h->term_buf, &h->problems, &h->states, &h->warm, &h->commands,
                          &h->solution, &h->path, &h->footprints, &h->success, &h->u, &h->cost, &h->plan_poses,
                          &h->plan_offsets, &h->robot_poses, &h->fp_costs, &h->slow_down, &h->carrots, &h->vel,
-                         &h->arena};
+                         &h->arena, &h->origins_buf};
   for (DeviceBuffer* b : all) b->release();
   if (h->pin) (void)hipHostFree(h->pin);
   if (h->map_ready) (void)hipEventDestroy(h->map_ready);
@@ -375,7 +383,7 @@ int neo_mpc_set_costmap(neo_mpc_handle* h, const uint8_t* cells, uint32_t sx, ui
   int rc = h->raw_buf.reserve((size_t)sx * sy);
   if (rc) return rc;
   HIP_TRY(hipMemcpy(h->raw_buf.ptr, cells, (size_t)sx * sy, hipMemcpyHostToDevice));
-  rc = ingest(h, (const uint8_t*)h->raw_buf.ptr, sx, sy, res, ox, oy, nullptr);
+  rc = ingest(h, (const uint8_t*)h->raw_buf.ptr, 1, sx, sy, res, ox, oy, nullptr, nullptr);
   if (rc) return rc;
   // no synchronisation: `cells` has been consumed by the (blocking) copy above; K3 runs on the null
   // stream in front of the library's own launches, and the *_device entry points wait for map_ready
@@ -388,7 +396,34 @@ int neo_mpc_set_costmap_device(neo_mpc_handle* h, const uint8_t* d_cells, uint32
                                double ox, double oy, void* stream) {
   if (!h || !d_cells) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "null argument");
   HIP_TRY(hipSetDevice(h->device));
-  return ingest(h, d_cells, sx, sy, res, ox, oy, stream);
+  return ingest(h, d_cells, 1, sx, sy, res, ox, oy, nullptr, stream);
+}
+
+int neo_mpc_set_costmap_pool_device(neo_mpc_handle* h, const uint8_t* d_cells, uint32_t count, uint32_t sx,
+                                    uint32_t sy, double res, const double* d_origins, void* stream) {
+  if (!h || !d_cells || !d_origins) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "null argument");
+  if (count == 0 || count > (1u << 24)) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "bad costmap count %u", count);
+  HIP_TRY(hipSetDevice(h->device));
+  return ingest(h, d_cells, count, sx, sy, res, 0.0, 0.0, d_origins, stream);
+}
+
+int neo_mpc_set_costmap_pool(neo_mpc_handle* h, const uint8_t* cells, uint32_t count, uint32_t sx, uint32_t sy,
+                             double res, const double* origins) {
+  if (!h || !cells || !origins) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "null argument");
+  if (count == 0 || count > (1u << 24)) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "bad costmap count %u", count);
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t bytes = (size_t)sx * sy * count;
+  int rc = h->raw_buf.reserve(bytes);
+  if (rc) return rc;
+  if ((rc = h->origins_buf.reserve((size_t)count * 16))) return rc;
+  HIP_TRY(hipMemcpy(h->raw_buf.ptr, cells, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->origins_buf.ptr, origins, (size_t)count * 16, hipMemcpyHostToDevice));
+  rc = ingest(h, (const uint8_t*)h->raw_buf.ptr, count, sx, sy, res, 0.0, 0.0, (const double*)h->origins_buf.ptr,
+              nullptr);
+  if (rc) return rc;
+  if (!h->map_ready) HIP_TRY(hipEventCreateWithFlags(&h->map_ready, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(h->map_ready, nullptr));
+  return NEO_MPC_OK;
 }
 
 int neo_mpc_solve_batch_device_timed(neo_mpc_handle* h, const neo_mpc_batch* batch, void* stream, void* start_event,

@@ -46,6 +46,12 @@ struct DevMap {
   int32_t size_x, size_y;
   int32_t pitch;
   double resolution, inv_resolution, origin_x, origin_y;
+  // costmap pool (neo_mpc_set_costmap_pool): pool_count bordered maps of this geometry back to back,
+  // pool_stride bytes apart, their origins in pool_origins[2k], [2k+1]; 0: the single map above
+  int32_t pool_count;
+  int32_t pad_;
+  int64_t pool_stride;
+  const double* pool_origins;
 };
 
 // LDS carve-up of the solve kernel, in doubles from the start of dynamic LDS.
@@ -128,9 +134,12 @@ struct ObjectiveArgs {
 };
 
 struct IngestArgs {
-  const uint8_t* src;  // raw nav2 costmap, row-major size_x * size_y
-  uint8_t* dst;        // padded map base (row 0 of the border)
+  const uint8_t* src;  // raw nav2 costmap(s), row-major size_x * size_y each, back to back
+  uint8_t* dst;        // padded map base (row 0 of the border) of the first map
   int32_t size_x, size_y, pitch, rows;  // rows = size_y + 2*border
+  int32_t maps;        // number of maps (blockIdx.y)
+  int32_t pad_;
+  int64_t dst_stride;  // bytes between padded maps
 };
 
 struct CarrotArgs {

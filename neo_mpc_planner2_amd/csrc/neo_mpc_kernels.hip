@@ -129,6 +129,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   bool have_trig = false;  // ACS/ASN already hold sin/cos of the rollout at u
 
   load_records(a, L, b, lane);
+  select_map(a.map, L + a.lds.prob);
   int flags = reset_and_warm(a, L, b, lane) ? NEO_MPC_FLAG_RESET : 0;
   const double fcost = footprint_cost(a, L, b, lane);
   Ctx c;
@@ -731,13 +732,15 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
 }
 
 // K2 on its own: `solution` supplies x.x, `success` supplies x.success
-__global__ __launch_bounds__(kLanes) void k_postprocess(const SolveArgs a) {
+__global__ __launch_bounds__(kLanes) void k_postprocess(const SolveArgs args) {
   extern __shared__ __align__(16) double L[];
+  SolveArgs a = args;
   const int lane = threadIdx.x;
   const uint32_t b = blockIdx.x;
   if (b >= a.count) return;
   const int nv = 3 * a.p.n;
   load_records(a, L, b, lane);
+  select_map(a.map, L + a.lds.prob);
   int flags = reset_and_warm(a, L, b, lane) ? NEO_MPC_FLAG_RESET : 0;
   const double fcost = footprint_cost(a, L, b, lane);
   Ctx c;
@@ -765,8 +768,9 @@ __global__ __launch_bounds__(256) void k_objective(const ObjectiveArgs a) {
   sa.p = a.p; sa.map = a.map;
   sa.lds.term = 0; sa.lds.tile = 0; sa.lds.tile_w = 0; sa.lds.tile_h = 0;
   const double* P = reinterpret_cast<const double*>(a.problems + b);
+  select_map<false>(sa.map, P);
   Ctx c;
-  make_ctx(a.p, a.map, P, P[P_FOOTPRINT], c);
+  make_ctx(a.p, sa.map, P, P[P_FOOTPRINT], c);
   const double* u = a.u + (size_t)b * 3 * a.p.n;
   a.cost[b] = rollout_cost(sa, c, term, [&](int i, double& b0, double& b1, double& b2) {
     b0 = u[3 * i]; b1 = u[3 * i + 1]; b2 = u[3 * i + 2];
@@ -774,7 +778,10 @@ __global__ __launch_bounds__(256) void k_objective(const ObjectiveArgs a) {
 }
 
 // K3: raw nav2 costmap -> bordered, pitched device map.  One 16-byte store per lane.
-__global__ __launch_bounds__(256) void k_ingest(const IngestArgs a) {
+__global__ __launch_bounds__(256) void k_ingest(const IngestArgs args) {
+  IngestArgs a = args;   // blockIdx.y: which map of a pool
+  a.src += (long)blockIdx.y * a.size_x * a.size_y;
+  a.dst += (long)blockIdx.y * a.dst_stride;
   const int chunks_per_row = a.pitch >> 4;
   const long total = (long)a.rows * chunks_per_row;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -966,7 +973,7 @@ void launch_ingest(const IngestArgs& a, void* stream) {
   const long total = (long)a.rows * (a.pitch >> 4);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(k_ingest, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(k_ingest, dim3(blocks, a.maps > 0 ? a.maps : 1), dim3(256), 0, (hipStream_t)stream, a);
 }
 
 }  // namespace neo_mpc

@@ -234,6 +234,18 @@ __device__ bool reset_and_warm(const SolveArgs& a, double* L, uint32_t b, int la
   return !same;
 }
 
+// costmap pool: point `m` at the map the request names (wave-uniform), the single map otherwise
+template <bool kUniform = true>
+__device__ __forceinline__ void select_map(DevMap& m, const double* P) {
+  if (m.pool_count <= 0) return;
+  int idx = reinterpret_cast<const int*>(P)[PI_MAP_INDEX];
+  idx = idx < 0 ? 0 : (idx >= m.pool_count ? m.pool_count - 1 : idx);
+  if (kUniform) idx = __builtin_amdgcn_readfirstlane(idx);
+  m.cells += (long)idx * m.pool_stride;
+  m.origin_x = m.pool_origins[2 * idx];
+  m.origin_y = m.pool_origins[2 * idx + 1];
+}
+
 __device__ void load_records(const SolveArgs& a, double* L, uint32_t b, int lane) {
   if (lane < 32) L[a.lds.prob + lane] = reinterpret_cast<const double*>(a.problems + b)[lane];
   else if (lane < 48) L[a.lds.state + lane - 32] = reinterpret_cast<const double*>(a.states + b)[lane - 32];

@@ -72,6 +72,30 @@ class BatchSolver:
                 self._handle, C.c_void_p(cells.data_ptr()), sx, sy, float(resolution), float(origin_x),
                 float(origin_y), C.c_void_p(stream)))
 
+    def set_costmap_pool(self, cells, resolution, origins):
+        """Fleet variant: cells uint8 [count, size_y, size_x] (NumPy or CUDA torch tensor), origins
+        float64 [count, 2]; instances pick their map with `problems["map_index"]`.  With device
+        tensors `origins` is read by every later solve and must stay alive (it may be updated in
+        place between ticks, as rolling windows move)."""
+        if isinstance(cells, np.ndarray):
+            cells = np.ascontiguousarray(cells, dtype=np.uint8)
+            origins = np.ascontiguousarray(origins, dtype=np.float64)
+            m, sy, sx = cells.shape
+            assert origins.shape == (m, 2)
+            _lib.check(self._lib.neo_mpc_set_costmap_pool(self._handle, C.c_void_p(cells.ctypes.data), m, sx, sy,
+                                                         float(resolution), C.c_void_p(origins.ctypes.data)))
+        else:
+            import torch
+            assert cells.is_cuda and cells.dtype == torch.uint8 and cells.is_contiguous()
+            assert origins.is_cuda and origins.dtype == torch.float64 and origins.is_contiguous()
+            m, sy, sx = cells.shape
+            assert tuple(origins.shape) == (m, 2)
+            self._pool_origins = origins   # keep it alive
+            stream = torch.cuda.current_stream(cells.device).cuda_stream
+            _lib.check(self._lib.neo_mpc_set_costmap_pool_device(
+                self._handle, C.c_void_p(cells.data_ptr()), m, sx, sy, float(resolution),
+                C.c_void_p(origins.data_ptr()), C.c_void_p(stream)))
+
     def kernel_info(self):
         a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
         _lib.check(self._lib.neo_mpc_kernel_info(self._handle, C.byref(a), C.byref(b), C.byref(c)))

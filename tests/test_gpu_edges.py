@@ -323,3 +323,62 @@ def test_static_lds_variant_equals_the_dynamic_one(monkeypatch):
     assert (np.abs(x0 - x1).max(axis=1) <= 1e-6).mean() >= 0.99
     assert (np.abs(c0["vel"] - c1["vel"]).max(axis=1) <= 1e-6).mean() >= 0.99
     assert np.allclose(c0["cost"], c1["cost"], rtol=0, atol=1e-6)
+
+
+def test_costmap_pool_each_instance_reads_its_own_map():
+    """Fleet variant (`neo_mpc_set_costmap_pool`): eight rolling windows of one geometry with their own
+    contents and origins, instances spread over them by `map_index` -- every instance must come out as
+    if it had been solved alone against its own map (mirror run per map), through the host and the
+    device entry points; an out-of-range index is clamped."""
+    import torch
+    from neo_mpc_planner2_amd.solver import BatchSolver, DeviceBatch
+    params = util.orc.make_params()
+    m, size, count = 8, 160, 768
+    rng = np.random.default_rng(81)
+    maps = [synthetic.make_costmap(size, seed=90 + k) for k in range(m)]
+    cells = np.stack([mp[0] for mp in maps])
+    res = maps[0][1]
+    offsets = rng.uniform(-50.0, 50.0, size=(m, 2))
+    origins = np.array([[mp[2] + offsets[k, 0], mp[3] + offsets[k, 1]] for k, mp in enumerate(maps)])
+    probs = synthetic.make_problems(count, size, seed=82)
+    idx = rng.integers(0, m, size=count).astype(np.int32)
+    probs["map_index"] = idx
+    probs["cur_xy"] += offsets[idx]
+    probs["goal_xyz"][:, :2] += offsets[idx]
+    st, warm = synthetic.make_states(probs, 3)
+    st_d, warm_d = st.copy(), warm.copy()
+    want_c = np.zeros(count, dtype=abi.COMMAND_DTYPE)
+    want_x = np.zeros((count, 9))
+    for k in range(m):
+        sel = np.where(idx == k)[0]
+        st_k, warm_k = synthetic.make_states(probs[sel], 3)
+        cc, xc, _ = _mirror(params, (cells[k], res, origins[k, 0], origins[k, 1]), probs[sel], st_k, warm_k)
+        want_c[sel], want_x[sel] = cc, xc
+    with BatchSolver(params) as s:
+        s.set_costmap_pool(cells, res, origins)
+        cg, xg = s.solve(probs, st, warm)
+        _close(cg, want_c, frac=0.97)
+        assert (cg["cost"] <= want_c["cost"] + 1e-6).mean() >= 0.97
+        # the maps differ: solving everything against map 0 must NOT reproduce the per-map answers
+        wrong = probs.copy()
+        wrong["map_index"] = 0
+        st_w, warm_w = synthetic.make_states(wrong, 3)
+        cw, _ = s.solve(wrong, st_w, warm_w)
+        other = idx != 0
+        assert (np.abs(cw["cost"][other] - want_c["cost"][other]) > 1e-6).mean() > 0.3
+        # out-of-range indices are clamped to the last map
+        far = probs[idx == m - 1].copy()
+        far["map_index"] = 1000
+        st_f, warm_f = synthetic.make_states(far, 3)
+        cf, _ = s.solve(far, st_f, warm_f)
+        assert np.allclose(cf["vel"], cg["vel"][idx == m - 1], atol=1e-12)
+        # device-resident pool, origins rewritten in place between ticks (rolling windows)
+        dev = "cuda:0"
+        d_cells = torch.from_numpy(cells).to(dev)
+        d_orig = torch.from_numpy(origins).to(dev)
+        s.set_costmap_pool(d_cells, res, d_orig)
+        b = DeviceBatch(probs, st_d, warm_d, dev)
+        s.solve_device(b.problems, b.states, b.warm, b.commands, solution=b.solution)
+        torch.cuda.synchronize()
+        cd = b.commands_host()
+        assert np.allclose(cd["vel"], cg["vel"], atol=1e-12) and (cd["iterations"] == cg["iterations"]).all()
