@@ -29,7 +29,7 @@ __device__ __forceinline__ int cell_of(double w, double origin, double res, doub
 }
 
 __device__ __forceinline__ int map_raw(const DevMap& m, int mx, int my) {
-  if (mx < -kMapBorder || my < -kMapBorder || mx >= m.size_x + kMapBorder || my >= m.size_y + kMapBorder)
+  if (mx < -m.border || my < -m.border || mx >= m.size_x + m.border || my >= m.size_y + m.border)
     return 254;  // contract: out of bounds is lethal
   return m.cells[(long)my * m.pitch + mx];
 }

@@ -203,8 +203,9 @@ int ingest(neo_mpc_handle* h, const uint8_t* d_cells, uint32_t maps, uint32_t sx
            double oy, const double* d_origins, void* stream) {
   if (!d_cells || maps == 0 || sx == 0 || sy == 0 || sx > (1u << 20) || sy > (1u << 20) || !(res > 0.0))
     return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "bad costmap geometry %ux%u x%u res %g", sx, sy, maps, res);
-  const int pitch = (int)((sx + 2 * kMapBorder + 127) & ~127u);
-  const int rows = (int)sy + 2 * kMapBorder;
+  const int border = d_origins ? kPoolBorder : kMapBorder;
+  const int pitch = (int)((sx + 2 * border + 127) & ~127u);
+  const int rows = (int)sy + 2 * border;
   const size_t stride = (size_t)pitch * rows;
   int rc = h->map_buf.reserve(stride * maps);
   if (rc) return rc;
@@ -212,15 +213,15 @@ int ingest(neo_mpc_handle* h, const uint8_t* d_cells, uint32_t maps, uint32_t sx
   a.src = d_cells;
   a.dst = (uint8_t*)h->map_buf.ptr;
   a.size_x = (int)sx; a.size_y = (int)sy; a.pitch = pitch; a.rows = rows;
-  a.maps = (int)maps; a.pad_ = 0; a.dst_stride = (int64_t)stride;
+  a.maps = (int)maps; a.border = border; a.dst_stride = (int64_t)stride;
   launch_ingest(a, stream);
   HIP_TRY(hipGetLastError());
-  h->map.cells = (const uint8_t*)h->map_buf.ptr + (size_t)kMapBorder * pitch + kMapBorder;
+  h->map.cells = (const uint8_t*)h->map_buf.ptr + (size_t)border * pitch + border;
   h->map.size_x = (int)sx; h->map.size_y = (int)sy; h->map.pitch = pitch;
   h->map.resolution = res; h->map.inv_resolution = 1.0 / res;
   h->map.origin_x = ox; h->map.origin_y = oy;
   h->map.pool_count = d_origins ? (int)maps : 0;
-  h->map.pad_ = 0;
+  h->map.border = border;
   h->map.pool_stride = (int64_t)stride;
   h->map.pool_origins = d_origins;
   h->has_map = true;

@@ -8,7 +8,8 @@
 namespace neo_mpc {
 
 constexpr int kLanes = 64;          // one CDNA4 wavefront per MPC instance
-constexpr int kMapBorder = 64;      // lethal border (cells) K3 adds around the costmap
+constexpr int kMapBorder = 64;      // lethal border (cells) K3 adds around a single costmap
+constexpr int kPoolBorder = 16;     // ... around each map of a pool (every lookup is bounds-checked anyway)
 constexpr int kMaxTileWidth = 128;  // widest reach tile staged in LDS (bytes per row)
 
 // Constants of one solver configuration, precomputed on the host in float64 exactly as
@@ -49,7 +50,7 @@ struct DevMap {
   // costmap pool (neo_mpc_set_costmap_pool): pool_count bordered maps of this geometry back to back,
   // pool_stride bytes apart, their origins in pool_origins[2k], [2k+1]; 0: the single map above
   int32_t pool_count;
-  int32_t pad_;
+  int32_t border;    // lethal cells around the map in device memory (multiple of 16)
   int64_t pool_stride;
   const double* pool_origins;
 };
@@ -138,7 +139,7 @@ struct IngestArgs {
   uint8_t* dst;        // padded map base (row 0 of the border) of the first map
   int32_t size_x, size_y, pitch, rows;  // rows = size_y + 2*border
   int32_t maps;        // number of maps (blockIdx.y)
-  int32_t pad_;
+  int32_t border;
   int64_t dst_stride;  // bytes between padded maps
 };
 

@@ -786,10 +786,14 @@ __global__ __launch_bounds__(256) void k_ingest(const IngestArgs args) {
   const long total = (long)a.rows * chunks_per_row;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int row = (int)(idx / chunks_per_row), chunk = (int)(idx - (long)row * chunks_per_row);
-    const int my = row - kMapBorder;
-    const int mx0 = chunk * 16 - kMapBorder;
+    const int my = row - a.border;
+    const int mx0 = chunk * 16 - a.border;
     uint4 v = make_uint4(0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu);
-    if (my >= 0 && my < a.size_y && mx0 + 16 > 0 && mx0 < a.size_x) {
+    if (my >= 0 && my < a.size_y && mx0 >= 0 && mx0 + 16 <= a.size_x && (a.size_x & 3) == 0) {
+      // interior chunk of a map whose rows are dword-aligned (mx0 is a multiple of 16): four dword loads
+      const uint32_t* src4 = reinterpret_cast<const uint32_t*>(a.src + (long)my * a.size_x + mx0);
+      v = make_uint4(src4[0], src4[1], src4[2], src4[3]);
+    } else if (my >= 0 && my < a.size_y && mx0 + 16 > 0 && mx0 < a.size_x) {
       uint8_t bytes[16];
       const uint8_t* src = a.src + (long)my * a.size_x;
 #pragma unroll

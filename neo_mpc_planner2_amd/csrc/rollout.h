@@ -108,8 +108,8 @@ __device__ void load_tile(const SolveArgs& a, Ctx& c, double* L, int lane) {
     const int row = idx >> shift, col = idx & (wq - 1);
     const long gy = (long)c.tile_y0 + row, gx = (long)c.tile_x0 + 4 * col;
     uint32_t v = 0xFEFEFEFEu;  // lethal outside the padded map
-    if (gy >= -kMapBorder && gy < (long)a.map.size_y + kMapBorder && gx >= -kMapBorder &&
-        gx + 4 <= (long)a.map.pitch - kMapBorder)
+    if (gy >= -a.map.border && gy < (long)a.map.size_y + a.map.border && gx >= -a.map.border &&
+        gx + 4 <= (long)a.map.pitch - a.map.border)
       v = *reinterpret_cast<const uint32_t*>(a.map.cells + gy * a.map.pitch + gx);
     tile[idx] = v;
   }

@@ -19,4 +19,5 @@ for b in 4096 32768 262144; do
     python -c "import sys,json; d=json.loads(sys.stdin.read()); print('batch $b %.4g solves/s kernel_ms %.4f' % (d['value'], d['roofline']['kernel_ms']))"
 done > $O/batch_scaling.txt
 timeout 300 python tools/bench_fleet_loop.py 2>/dev/null | tail -1 > $O/fleet_loop.json
+timeout 300 python tools/bench_fleet_loop.py --pool 2>/dev/null | tail -1 > $O/fleet_loop_pool.json
 for p in 128 512 2048; do timeout 120 python tools/bench_carrot.py --poses $p 2>/dev/null | tail -1; done > $O/carrot_hbm.jsonl

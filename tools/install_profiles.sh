@@ -13,6 +13,7 @@ cp $F/other_configs.jsonl profiles/${T}_other_configs.jsonl
 cp $F/batch_scaling.txt profiles/${T}_batch_scaling.txt
 cp $F/carrot_hbm.jsonl profiles/${T}_carrot_hbm.jsonl
 [ -f $F/fleet_loop.json ] && cp $F/fleet_loop.json profiles/${T}_fleet_loop.json
+[ -f $F/fleet_loop_pool.json ] && cp $F/fleet_loop_pool.json profiles/${T}_fleet_loop_pool.json
 python - <<PY
 import json, re
 pmc = open("profiles/${T}_pmc_c2.txt").read()
