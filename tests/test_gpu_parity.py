@@ -212,6 +212,17 @@ def test_errors_are_reported_not_thrown(solver_mod):
         solver_mod.BatchSolver(util.orc.make_params(control_steps=0))
     with pytest.raises(_lib.NeoMpcError):
         solver_mod.BatchSolver(util.orc.make_params(min_vel_x=0.9, max_vel_x=1.0, min_vel_y=0.9, max_vel_y=1.0))
+    # costmap pool: null origins, empty pool, degenerate geometry
+    import ctypes as C
+    lib = _lib.load()
+    cells = np.zeros((2, 8, 8), dtype=np.uint8)
+    orig = np.zeros((2, 2))
+    assert lib.neo_mpc_set_costmap_pool(s._handle, C.c_void_p(cells.ctypes.data), 2, 8, 8, 0.05, None) == -1
+    assert lib.neo_mpc_set_costmap_pool(s._handle, C.c_void_p(cells.ctypes.data), 0, 8, 8, 0.05,
+                                        C.c_void_p(orig.ctypes.data)) == -1
+    assert lib.neo_mpc_set_costmap_pool(s._handle, C.c_void_p(cells.ctypes.data), 2, 8, 8, 0.0,
+                                        C.c_void_p(orig.ctypes.data)) == -1
+    assert b"costmap" in lib.neo_mpc_last_error()
     s.close()
 
 
