@@ -207,6 +207,8 @@ int ingest(neo_mpc_handle* h, const uint8_t* d_cells, uint32_t maps, uint32_t sx
   const int pitch = (int)((sx + 2 * border + 127) & ~127u);
   const int rows = (int)sy + 2 * border;
   const size_t stride = (size_t)pitch * rows;
+  if (stride / 16 >= (1ull << 31))   // K3 indexes the 16-byte chunks of one map with 32 bits
+    return fail(NEO_MPC_ERR_UNSUPPORTED, "costmap %ux%u is too large (over 32 GiB padded)", sx, sy);
   int rc = h->map_buf.reserve(stride * maps);
   if (rc) return rc;
   IngestArgs a;

@@ -782,15 +782,19 @@ __global__ __launch_bounds__(256) void k_ingest(const IngestArgs args) {
   IngestArgs a = args;   // blockIdx.y: which map of a pool
   a.src += (long)blockIdx.y * a.size_x * a.size_y;
   a.dst += (long)blockIdx.y * a.dst_stride;
-  const int chunks_per_row = a.pitch >> 4;
-  const long total = (long)a.rows * chunks_per_row;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int row = (int)(idx / chunks_per_row), chunk = (int)(idx - (long)row * chunks_per_row);
+  const unsigned chunks_per_row = (unsigned)a.pitch >> 4;
+  const unsigned total = (unsigned)a.rows * chunks_per_row;   // (< 2^31: rows, pitch <= 2^20 + 256 and pitch/16 per row)
+  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int row = (int)(idx / chunks_per_row), chunk = (int)(idx - (unsigned)row * chunks_per_row);
     const int my = row - a.border;
     const int mx0 = chunk * 16 - a.border;
     uint4 v = make_uint4(0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu);
-    if (my >= 0 && my < a.size_y && mx0 >= 0 && mx0 + 16 <= a.size_x && (a.size_x & 3) == 0) {
-      // interior chunk of a map whose rows are dword-aligned (mx0 is a multiple of 16): four dword loads
+    if (my >= 0 && my < a.size_y && mx0 >= 0 && mx0 + 16 <= a.size_x && (a.size_x & 7) == 0) {
+      // interior chunk of a map whose rows are 8-byte aligned (mx0 is a multiple of 16): two 8-byte loads
+      const uint2* src8 = reinterpret_cast<const uint2*>(a.src + (long)my * a.size_x + mx0);
+      const uint2 lo = src8[0], hi = src8[1];
+      v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    } else if (my >= 0 && my < a.size_y && mx0 >= 0 && mx0 + 16 <= a.size_x && (a.size_x & 3) == 0) {
       const uint32_t* src4 = reinterpret_cast<const uint32_t*>(a.src + (long)my * a.size_x + mx0);
       v = make_uint4(src4[0], src4[1], src4[2], src4[3]);
     } else if (my >= 0 && my < a.size_y && mx0 + 16 > 0 && mx0 < a.size_x) {
@@ -975,7 +979,9 @@ void launch_objective(const ObjectiveArgs& a, void* stream) {
 }
 void launch_ingest(const IngestArgs& a, void* stream) {
   const long total = (long)a.rows * (a.pitch >> 4);
-  int blocks = (int)((total + 255) / 256);
+  // a few 16-byte chunks per thread: one-chunk threads make the launch dispatch-bound for pools of small maps
+  const int per_thread = getenv("NEO_MPC_INGEST_CHUNKS") ? atoi(getenv("NEO_MPC_INGEST_CHUNKS")) : 2;
+  int blocks = (int)((total + 256L * per_thread - 1) / (256L * per_thread));
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(k_ingest, dim3(blocks, a.maps > 0 ? a.maps : 1), dim3(256), 0, (hipStream_t)stream, a);
 }
