@@ -382,3 +382,37 @@ def test_costmap_pool_each_instance_reads_its_own_map():
         torch.cuda.synchronize()
         cd = b.commands_host()
         assert np.allclose(cd["vel"], cg["vel"], atol=1e-12) and (cd["iterations"] == cg["iterations"]).all()
+
+
+def test_device_entry_point_can_be_captured_in_a_hip_graph():
+    """`neo_mpc_solve_batch_device` only enqueues work on the caller's stream (no allocation, no
+    synchronisation), so a control tick can be captured once in a HIP graph and replayed: the replays,
+    fed through the same device buffers, equal direct launches."""
+    import torch
+    from neo_mpc_planner2_amd.solver import BatchSolver, DeviceBatch
+    params = util.orc.make_params()
+    cmap = synthetic.make_costmap(300, seed=91)
+    probs = synthetic.make_problems(256, 300, seed=92)
+    st, warm = synthetic.make_states(probs, 3)
+    dev = "cuda:0"
+    with BatchSolver(params) as s:
+        s.set_costmap(torch.from_numpy(cmap[0]).to(dev), *cmap[1:])
+        direct = DeviceBatch(probs, st, warm, dev)
+        graphed = DeviceBatch(probs, st, warm, dev)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):      # warm-up on the capture stream, as torch asks for
+            s.solve_device(graphed.problems, graphed.states, graphed.warm, graphed.commands, solution=graphed.solution)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graphed = DeviceBatch(probs, st, warm, dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            s.solve_device(graphed.problems, graphed.states, graphed.warm, graphed.commands, solution=graphed.solution)
+        for tick in range(3):              # three ticks: state and warm start carry over inside the buffers
+            g.replay()
+            s.solve_device(direct.problems, direct.states, direct.warm, direct.commands, solution=direct.solution)
+            torch.cuda.synchronize()
+            a, b = graphed.commands_host(), direct.commands_host()
+            assert (a["iterations"] == b["iterations"]).all() and (a["vel"] == b["vel"]).all(), tick
+        assert (graphed.states_host()["has_old_goal"] == 1).all()
