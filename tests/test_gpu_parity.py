@@ -334,3 +334,40 @@ def test_bench_emits_the_contract_line():
     assert abs(rec["value"] - 4096 * 5 / (rec["ms_per_step"] * 5e-3)) / rec["value"] < 1e-9
     assert rec["value"] > 1e6            # the north star's floor on one MI355X
     assert rec["solver"]["converged_frac"] == 1.0
+
+
+@pytest.mark.parametrize("name", ["C3", "C5"])
+def test_c3_c5_full_size_properties(solver_mod, name):
+    """BASELINE configs 3 (262 144 instances, control_steps 8, 1000x1000 map) and 5 (65 536 instances,
+    control_steps 32) at full size, through properties that do not need the oracle: never worse than
+    the start, inside box and disc, (near-)idempotent, sharded == unsharded bit for bit, acceleration
+    clamp honoured."""
+    cfg, cmap, probs, st, warm = synthetic.make_workload(name, seed=0)
+    n = cfg["control_steps"]
+    params = util.orc.make_params(control_steps=n)
+    with _solver(solver_mod, params, cmap) as s:
+        st0, warm0 = st.copy(), warm.copy()
+        cmds, x = s.solve(probs, st, warm)
+        assert (cmds["status"] == 0).mean() >= 0.99
+        f0 = s.objective(probs, np.zeros_like(x))
+        assert (cmds["cost"] <= f0 + 1e-12).all()
+        xs = x.reshape(len(x), -1, 3)
+        assert (np.hypot(xs[:, :, 0], xs[:, :, 1]) <= 0.7 + 1e-9).all()
+        assert (np.abs(xs) <= 0.7 + 1e-12).all()
+        f_at = s.objective(probs, x)                                    # reported cost == objective at the solution
+        assert np.allclose(f_at, cmds["cost"], rtol=1e-12, atol=1e-12)
+        cm2, x2 = s.solve(probs, st0.copy(), x.copy())                   # restart from the solution
+        assert (cm2["cost"] <= cmds["cost"] + 1e-12).all()
+        # (a restarted search has a fresh stop window and creeps on where the first one stopped at a
+        # costmap cell edge: 3 % of the C3 commands move by more than 1e-3, objective never up)
+        assert (np.abs(x2[:, :3] - x[:, :3]).max(axis=1) <= 1e-3).mean() >= (0.95 if n <= 8 else 0.9)
+        h = len(probs) // 2
+        sa, wa = st0[:h].copy(), warm0[:h].copy()
+        sb, wb = st0[h:].copy(), warm0[h:].copy()
+        ca, xa = s.solve(probs[:h], sa, wa)
+        cb, xb = s.solve(probs[h:], sb, wb)
+        assert (np.concatenate([xa, xb]) == x).all()
+        assert (np.concatenate([ca["vel"], cb["vel"]]) == cmds["vel"]).all()
+    moving = (cmds["flags"] & abi.FLAG_STOPPED) == 0
+    dv = np.abs(cmds["vel"] - probs["cur_vel"])[moving]
+    assert (dv <= np.array([2.5, 2.5, 3.0]) / 30.0 + 1e-12).all()
