@@ -807,7 +807,11 @@ __global__ __launch_bounds__(256) void k_ingest(const IngestArgs args) {
       }
       v = *reinterpret_cast<const uint4*>(bytes);
     }
-    *reinterpret_cast<uint4*>(a.dst + (long)row * a.pitch + chunk * 16) = v;
+    // streamed once, read back sparsely (reach tiles): non-temporal, so the stream does not wait for
+    // L2 lines to be allocated (measured: 3.0 -> 4.3 TB/s over a pool of 4096 windows)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 out = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(out, reinterpret_cast<u32x4*>(a.dst + (long)row * a.pitch + chunk * 16));
   }
 }
 
