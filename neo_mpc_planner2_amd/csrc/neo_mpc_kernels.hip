@@ -841,10 +841,12 @@ __global__ __launch_bounds__(kLanes) void k_carrot(const CarrotArgs a) {
   uint32_t besti = 0xffffffffu;
   uint32_t k = lane;
   for (; k + 3 * kLanes < np; k += 4 * kLanes) {  // four independent pose loads in flight per lane
-    const double x0 = poses[3 * k], y0 = poses[3 * k + 1];
-    const double x1 = poses[3 * (k + kLanes)], y1 = poses[3 * (k + kLanes) + 1];
-    const double x2 = poses[3 * (k + 2 * kLanes)], y2 = poses[3 * (k + 2 * kLanes) + 1];
-    const double x3 = poses[3 * (k + 3 * kLanes)], y3 = poses[3 * (k + 3 * kLanes) + 1];
+#define NT(p) __builtin_nontemporal_load(p)
+    const double x0 = NT(poses + 3 * k), y0 = NT(poses + 3 * k + 1);
+    const double x1 = NT(poses + 3 * (k + kLanes)), y1 = NT(poses + 3 * (k + kLanes) + 1);
+    const double x2 = NT(poses + 3 * (k + 2 * kLanes)), y2 = NT(poses + 3 * (k + 2 * kLanes) + 1);
+    const double x3 = NT(poses + 3 * (k + 3 * kLanes)), y3 = NT(poses + 3 * (k + 3 * kLanes) + 1);
+#undef NT
     const double d0 = hypot(x0 - rx, y0 - ry), d1 = hypot(x1 - rx, y1 - ry);
     const double d2 = hypot(x2 - rx, y2 - ry), d3 = hypot(x3 - rx, y3 - ry);
     if (d0 < best) { best = d0; besti = k; }
