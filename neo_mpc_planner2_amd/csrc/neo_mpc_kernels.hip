@@ -195,6 +195,10 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   double gain1 = INFINITY, gain2 = INFINITY;  // objective decrease of the previous two iterations
   bool final_step = false;
   const int lane_id = lane;
+  // this lane's step multiplier: the one lane-derived constant worth two registers for the whole loop
+  // (half of the table sits in constant memory: re-reading it would put a global load on every
+  // iteration's critical path)
+  const double my_scale = lane_scale(lane);
   for (it = 0; it < p.max_it; ++it) {
     // The lane index is re-read opaquely every iteration: otherwise the compiler hoists two dozen
     // lane-derived constants (step multipliers, compare masks, LDS addresses) out of the loop and,
@@ -640,8 +644,8 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     }
     NEO_PHASE(4);
     // ---- 64 candidates, one rollout per lane; lowest objective wins
-    const double pstep = alpha * lane_scale(lane);
-    const double step = lane < 32 ? pstep : lane_scale(lane);
+    const double pstep = alpha * my_scale;
+    const double step = lane < 32 ? pstep : my_scale;
     double fc = rollout_cost<kSteps, kTame>(
         a, c, L,
         [&](int i, double& b0, double& b1, double& b2) {
