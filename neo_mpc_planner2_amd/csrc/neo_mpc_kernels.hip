@@ -344,14 +344,17 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       const double u0 = u[3 * i], u1 = u[3 * i + 1], u2 = u[3 * i + 2];
       const double g0 = gs[3 * i], g1 = gs[3 * i + 1], g2 = gs[3 * i + 2];
       const double e0 = u0 - c.v0, e1 = u1 - c.v1, e2 = u2 - c.v2;
-      const double ne = sqrt_fast(e0 * e0 + e1 * e1 + e2 * e2);
+      // |e| and 1/|e| from one reciprocal square root (a shorter dependent chain than sqrt, then rcp)
+      const double ne2 = e0 * e0 + e1 * e1 + e2 * e2;
+      const double ine = ne2 > 0.0 ? rsq_fast(ne2) : 0.0;
+      const double ne = ne2 * ine;
       double t0, t1, t2;
-      if (ne > 0.0) {
-        const double wn = p.wc_n * rcp_fast(ne);
+      if (ne2 > 0.0) {
+        const double wn = p.wc_n * ine;
         t0 = g0 + wn * e0; t1 = g1 + wn * e1; t2 = g2 + wn * e2;
       } else {
-        const double ng = sqrt_fast(g0 * g0 + g1 * g1 + g2 * g2);
-        const double sh = (ng > p.wc_n) ? 1.0 - p.wc_n * rcp_fast(ng) : 0.0;
+        const double ng2 = g0 * g0 + g1 * g1 + g2 * g2;
+        const double sh = (ng2 > p.wc_n * p.wc_n) ? 1.0 - p.wc_n * rsq_fast(ng2) : 0.0;
         t0 = g0 * sh; t1 = g1 * sh; t2 = g2 * sh;
       }
       AMODE[4 * i + 3] = AMODE[4 * i + 2];
@@ -378,8 +381,8 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         if (u1 <= p.lo[1]) { ny1 = -1.0; v1 = true; }
         else if (u1 >= p.hi[1]) { ny1 = 1.0; v1 = true; }
       }
-      const double nvv = sqrt_fast(u0 * u0 + u1 * u1);
-      if (nvv > 0.0 && nvv >= p.r * (1.0 - 1e-12)) { const double iv = rcp_fast(nvv); nx2 = u0 * iv; ny2 = u1 * iv; v2 = true; }
+      const double nvv2 = u0 * u0 + u1 * u1, rlim = p.r * (1.0 - 1e-12);
+      if (nvv2 > 0.0 && nvv2 >= rlim * rlim) { const double iv = rsq_fast(nvv2); nx2 = u0 * iv; ny2 = u1 * iv; v2 = true; }
       const double dx = -t0, dy = -t1;
       const double dn0 = nx0 * dx + ny0 * dy, dn1 = nx1 * dx + ny1 * dy, dn2 = nx2 * dx + ny2 * dy;
       int mode = 0, mslot = -1;
