@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-iterations", type=int, default=None, help="study knob: cap the solver iterations")
     ap.add_argument("--control-steps", type=int, default=None, help="study knob: override the config's control_steps")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="study knob (NOT the headline): consecutive steps alternate over this many streams, so "
+                         "the next batch starts while the previous one's stragglers finish (independent fleets)")
     ap.add_argument("--method", type=int, default=None, help="study knob: 1 = L-BFGS, 2 = Newton (control_steps <= 8)")
     args = ap.parse_args()
 
@@ -193,9 +196,11 @@ def main():
     if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
+    extra_streams = [torch.cuda.Stream(device=dev) for _ in range(max(0, args.streams - 1))]
     for i in range(args.steps):
         b = sets[i]
-        solver.solve_device(base.problems, b.states, b.warm, b.commands, velocities=b.vel, events=evs[i])
+        st_i = None if args.streams <= 1 or i % args.streams == 0 else extra_streams[i % args.streams - 1].cuda_stream
+        solver.solve_device(base.problems, b.states, b.warm, b.commands, velocities=b.vel, events=evs[i], stream=st_i)
         if use_dist:
             exchange(i, b, evs[i][1])
     drain()
@@ -246,6 +251,7 @@ def main():
             "valu_issue": None if not valu else {
                 "insts_per_launch": valu, "cycles_per_inst": 4, "simds": 1024, "clock_ghz": SIMD_CLOCK_GHZ,
                 "frac": valu * 4 / (1024 * k_ms * 1e-3 * SIMD_CLOCK_GHZ * 1e9)},
+            **({"study_streams": args.streams} if args.streams > 1 else {}),
             "solver": {"mean_iterations": float(cmds["iterations"].mean()),
                        "converged_frac": float((cmds["status"] == 0).mean())},
         }
