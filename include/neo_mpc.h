@@ -49,10 +49,13 @@ extern "C" {
 #define NEO_MPC_COMPAT_ODOM_YAW_GOAL_W 1 /* py:213: odom_yaw takes quaternion w from the goal pose */
 
 /* neo_mpc_params.method */
-#define NEO_MPC_METHOD_AUTO 0   /* Newton where the kernel has it (control_steps <= 8), else L-BFGS */
+#define NEO_MPC_METHOD_AUTO 0   /* dense Newton at control_steps <= 8, stage-wise (Riccati) Newton beyond */
 #define NEO_MPC_METHOD_LBFGS 1  /* projected L-BFGS, any control_steps */
 #define NEO_MPC_METHOD_NEWTON 2 /* projected Newton (finite-difference Hessian of the analytic
                                    gradient, one column per lane); control_steps <= 8 */
+#define NEO_MPC_METHOD_RICCATI 3 /* projected Newton, the same system solved stage by stage (Riccati
+                                   recursion over the rollout chain, 3x3 blocks, analytic second-order
+                                   terms): any control_steps, O(control_steps) per iteration */
 #define NEO_MPC_NEWTON_MAX_CONTROL_STEPS 8
 
 #define NEO_MPC_MAX_CONTROL_STEPS 64
@@ -108,7 +111,8 @@ typedef struct neo_mpc_problem {
                               when the batch carries no polygons */
   int32_t map_index;       /* which costmap of a pool this instance lives in (neo_mpc_set_costmap_pool);
                               ignored with a single costmap */
-  int32_t reserved_i;
+  int32_t switch_opt;      /* request.switch_opt = closer_to_goal (cpp:245); the reference stores it (py:354)
+                              and never reads it -- carried so that the record is the request field for field */
   double reserved[6];
 } neo_mpc_problem;
 
@@ -213,7 +217,12 @@ int neo_mpc_get_params(const neo_mpc_handle* handle, neo_mpc_params* params);
 /* Replaces the node's `Costmap2d(self)` subscription (py:118): raw nav2 costs, row-major
  * cells[my*size_x + mx] (e.g. `costmap_->getCharMap()` in the plugin).  The data is copied before the
  * call returns; the device-side ingest is left in flight, ordered in front of every later call on
- * this handle (the *_device entry points wait for it on the caller's stream). */
+ * this handle (the *_device entry points wait for it on the caller's stream).
+ * Stream ordering, all set_costmap* variants: the ingest records an event on the stream it ran on and every
+ * solve / postprocess / objective entry point makes its own stream wait for it; every solve records an event
+ * on its stream and the next ingest waits for it before it rewrites the device map -- a solve never sees a
+ * half-written map whatever streams the caller mixes.  (The caller's own buffers -- `d_cells`, `d_origins`,
+ * the batch arrays -- stay the caller's to order.) */
 int neo_mpc_set_costmap(neo_mpc_handle* handle, const uint8_t* cells, uint32_t size_x,
                         uint32_t size_y, double resolution, double origin_x, double origin_y);
 /* Same, `d_cells` already in device memory; ingested on `stream` (hipStream_t, may be NULL). */
@@ -225,6 +234,7 @@ int neo_mpc_set_costmap_device(neo_mpc_handle* handle, const uint8_t* d_cells, u
  * local costmaps, one per robot or per group of robots -- stored back to back (map k at
  * cells + k*size_x*size_y), origins[2k], origins[2k+1] = origin of map k.  Every instance reads the map
  * its `neo_mpc_problem.map_index` names.  Replaces whatever costmap(s) the handle held. */
+#define NEO_MPC_MAX_POOL_MAPS 65535u /* one ingest launch: the map index is the grid's y coordinate */
 int neo_mpc_set_costmap_pool(neo_mpc_handle* handle, const uint8_t* cells, uint32_t count, uint32_t size_x,
                              uint32_t size_y, double resolution, const double* origins);
 /* Same with `d_cells` and `d_origins` in device memory; the ingest runs on `stream`.  `d_origins` is read
@@ -250,6 +260,13 @@ int neo_mpc_solve_batch_device_timed(neo_mpc_handle* handle, const neo_mpc_batch
  * `success[i]` supplying `x.success` (NULL: all true).  Host pointers. */
 int neo_mpc_postprocess_batch(neo_mpc_handle* handle, const neo_mpc_batch* batch,
                               const int32_t* success);
+
+/* Test hook: the total gradient the solve kernel works with at u[count][3*control_steps] (projected onto the
+ * feasible set first, like x0): analytic adjoint gradient of the tracking + terminal cost plus the gradient of
+ * the control norm, taken from inside the kernel variant the current parameters select.  What SciPy obtains
+ * by forward differences of `objective` (py:204-269; _slsqp_py.py:381).  Host pointers. */
+int neo_mpc_gradient_batch(neo_mpc_handle* handle, const neo_mpc_problem* problems, const double* u,
+                           double* grad_out, size_t count);
 
 /* `MpcOptimizationServer.objective` (py:204-269) evaluated on the device for
  * u[count][3*control_steps] (not projected); `footprint_cost` from problems[i].  Host pointers. */

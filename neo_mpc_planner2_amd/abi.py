@@ -22,7 +22,7 @@ PROBLEM_DTYPE = np.dtype([
     ("footprint_cost", "<f8"),      # getFootprintCost(published footprint), normalised; used when
                                     # no polygon is supplied (py:262, 343)
     ("map_index", "<i4"),           # which costmap of a pool (BatchSolver.set_costmap_pool); else ignored
-    ("reserved_i", "<i4"),
+    ("switch_opt", "<i4"),          # request.switch_opt (cpp:245; stored py:354, never read)
     ("reserved", "<f8", (6,)),
 ], align=False)
 assert PROBLEM_DTYPE.itemsize == 256

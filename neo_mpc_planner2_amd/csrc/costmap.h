@@ -60,6 +60,11 @@ __device__ double edge_cost(const DevMap& m, double ax, double ay, double bx, do
   int y0 = cell_of(ay, m.origin_y, m.resolution, m.inv_resolution);
   const int x1 = cell_of(bx, m.origin_x, m.resolution, m.inv_resolution);
   const int y1 = cell_of(by, m.origin_y, m.resolution, m.inv_resolution);
+  // an end point outside the map reads as lethal (contract), and lethal is the largest cost there is:
+  // the outline's maximum is decided -- and a far-away or non-finite vertex (cell_of saturates at
+  // +-2^31) cannot turn the walk below into billions of steps.  Inside, it is at most size_x + size_y long.
+  if (x0 < 0 || y0 < 0 || x0 >= m.size_x || y0 >= m.size_y || x1 < 0 || y1 < 0 || x1 >= m.size_x || y1 >= m.size_y)
+    return raw_cost(254);
   const long dx = labs((long)x1 - x0), dy = labs((long)y1 - y0);
   const int sx = x1 >= x0 ? 1 : -1, sy = y1 >= y0 ? 1 : -1;
   long err = dx - dy;

@@ -62,23 +62,37 @@ __device__ __forceinline__ double lane_scale(int lane) {
 // control block i of this lane's candidate
 // (`step`: this lane's step along its own family; `pstep`: its proximal-gradient step length, used
 // by the L-BFGS lanes for blocks sitting next to the control-norm kink)
-template <bool kTame = false>
+// kRiccati (run-time-sized kernel with the stage-wise Newton direction):
+//  * the proximal-gradient step of block i is scaled by N / (N - i): the curvature of a block's own
+//    tracking terms is proportional to the number of stages it still moves (diagonal of the
+//    Gauss-Newton Hessian, 2 w_trans/N dt^2 (N - i)) -- one step length for all blocks leaves the late
+//    blocks crawling at long horizons;
+//  * blocks the Riccati sweep sends onto the kink (AMODE slot 3) stop there: step min(t, 1), and
+//    exactly v_cur at t >= 1.
+template <bool kTame = false, bool kRiccati = false>
 __device__ __forceinline__ void candidate_block(const SolveArgs& a, const Ctx& c, const double* L, int lane,
                                                 double step, double pstep, int i, double& b0, double& b1,
                                                 double& b2) {
   const double* u = L + a.lds.u + 3 * i;
-  const bool near = reinterpret_cast<const int*>(L + a.lds.mode)[4 * i + 2] != 0;
+  const int* am = reinterpret_cast<const int*>(L + a.lds.mode) + 4 * i;
+  const bool near = am[2] != 0;
   if (lane < 32 || near) {  // proximal gradient: forward step on the smooth part, prox of the control norm
     if (lane >= 32) step = pstep;
+    if (kRiccati) step *= (double)a.p.n * rcp_fast((double)(a.p.n - i));
     const double* gs = L + a.lds.gs + 3 * i;
     const double e0 = (u[0] - step * gs[0]) - c.v0, e1 = (u[1] - step * gs[1]) - c.v1,
                  e2 = (u[2] - step * gs[2]) - c.v2;
     const double ne2 = e0 * e0 + e1 * e1 + e2 * e2;
     const double sh = (ne2 > 0.0) ? fmax(0.0, 1.0 - step * a.p.wc_n * rsq_fast(ne2)) : 0.0;
     b0 = c.v0 + sh * e0; b1 = c.v1 + sh * e1; b2 = c.v2 + sh * e2;
-  } else {          // quasi-Newton direction
+  } else {          // quasi-Newton / Newton direction
     const double* d = L + a.lds.d + 3 * i;
-    b0 = u[0] + step * d[0]; b1 = u[1] + step * d[1]; b2 = u[2] + step * d[2];
+    if (kRiccati && am[3]) {
+      if (step >= 1.0) { b0 = c.v0; b1 = c.v1; b2 = c.v2; }
+      else { b0 = u[0] + step * d[0]; b1 = u[1] + step * d[1]; b2 = u[2] + step * d[2]; }
+    } else {
+      b0 = u[0] + step * d[0]; b1 = u[1] + step * d[1]; b2 = u[2] + step * d[2];
+    }
   }
   project_block<kTame>(a.p, b0, b1, b2);
 }

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "neo_mpc_device.h"
 
@@ -75,9 +76,11 @@ struct neo_mpc_handle {
   // staging block and one device arena, so a tick is one H2D, K1, one D2H and one synchronisation
   void* pin = nullptr;
   DeviceBuffer arena;
-  // neo_mpc_set_costmap (host cells) ingests on the null stream without waiting for it; work the
-  // caller enqueues on its own (possibly non-blocking) streams is ordered behind this event
-  hipEvent_t map_ready = nullptr;
+  // Stream ordering around the device map: every ingest records map_ready on the stream it ran on and
+  // every solve / postprocess / objective launch waits for it on its own stream; every such launch
+  // records map_in_use and the next ingest waits for that before it rewrites map_buf in place.
+  hipEvent_t map_ready = nullptr, map_in_use = nullptr;
+  bool map_used = false;
 };
 constexpr size_t kLatencyPathMaxCount = 64;
 constexpr size_t kLatencyPathBytes = kLatencyPathMaxCount * (sizeof(neo_mpc_problem) + sizeof(neo_mpc_state) +
@@ -99,7 +102,7 @@ int validate(const neo_mpc_params& p) {
   double ny = std::fmin(std::fmax(0.0, p.min_vel_y), p.max_vel_y);
   if (nx * nx + ny * ny > p.max_vel_trans * p.max_vel_trans)
     return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "velocity box does not intersect the max_vel_trans disc");
-  if (p.method < 0 || p.method > NEO_MPC_METHOD_NEWTON) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "unknown method %d", p.method);
+  if (p.method < 0 || p.method > NEO_MPC_METHOD_RICCATI) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "unknown method %d", p.method);
   if (p.method == NEO_MPC_METHOD_NEWTON && p.control_steps > NEO_MPC_NEWTON_MAX_CONTROL_STEPS)
     return fail(NEO_MPC_ERR_UNSUPPORTED, "NEO_MPC_METHOD_NEWTON is built for control_steps <= 8 only (got %d)",
                 p.control_steps);
@@ -143,19 +146,27 @@ void derive(neo_mpc_handle* h) {
   d.disc_in_box = (p.min_vel_x <= -p.max_vel_trans && p.max_vel_x >= p.max_vel_trans &&
                    p.min_vel_y <= -p.max_vel_trans && p.max_vel_y >= p.max_vel_trans) ? 1 : 0;
   d.tame = (d.disc_in_box && fmax(fabs(p.min_vel_theta), fabs(p.max_vel_theta)) * p.prediction_horizon <= 0.78) ? 1 : 0;
-  d.newton = (p.method != NEO_MPC_METHOD_LBFGS && n <= NEO_MPC_NEWTON_MAX_CONTROL_STEPS) ? 1 : 0;
+  // search direction: AUTO = the register-resident dense Newton kernel at control_steps 3 (the headline
+  // specialisation), the stage-wise (Riccati) Newton sweep of the run-time-sized kernel otherwise
+  d.newton = p.method == NEO_MPC_METHOD_LBFGS ? 0
+             : p.method == NEO_MPC_METHOD_NEWTON ? 1
+             : p.method == NEO_MPC_METHOD_RICCATI ? 2
+             : (n == 3 ? 1 : 2);
   d.early_tol = getenv("NEO_MPC_NO_EARLY") ? 0.0 : d.xtol;
   d.final_tol = getenv("NEO_MPC_NO_EARLY") ? 0.0 : (p.step_tolerance > 0.0 ? p.step_tolerance : p.opt_tolerance);
   d.ftol = p.cost_tolerance > 0.0 ? p.cost_tolerance : (d.newton ? 3e-4 : 3e-6) * p.opt_tolerance;
+  // (beyond 8 control steps the objective is flatter per block -- the weights are divided by N: the
+  // window shrinks with (8/N)^2, measured on the control_steps 32 reference solves)
+  const double wscale = n > 8 ? (8.0 / n) * (8.0 / n) : 1.0;
   d.wtol = p.window_tolerance > 0.0 ? p.window_tolerance
-           : (p.window_tolerance == 0.0 && d.newton) ? 3e-3 * p.opt_tolerance : 0.0;
+           : (p.window_tolerance == 0.0 && d.newton) ? 3e-3 * p.opt_tolerance * wscale : 0.0;
 
   // LDS carve-up (shared with the kernel specialisations) + reach tile geometry
   LdsLayout& l = h->lds;
   // the control_steps == 3 specialisations carve LDS at compile time with 4 pair slots; the host
   // must reserve exactly that layout whenever launch_solve() will pick them
-  const bool specialised = n == 3 && (d.newton || d.mem == 4);
-  l = make_lds_layout(n, specialised ? 4 : d.mem);
+  const bool specialised = n == 3 && (d.newton == 1 || (d.newton == 0 && d.mem == 4));
+  l = make_lds_layout(n, specialised ? 4 : (d.newton ? 0 : d.mem), d.newton == 2);
   const int off = l.tile;
   l.tile_w = 0; l.tile_h = 0; l.reach = 0;
   if (h->has_map) {
@@ -211,6 +222,10 @@ int ingest(neo_mpc_handle* h, const uint8_t* d_cells, uint32_t maps, uint32_t sx
     return fail(NEO_MPC_ERR_UNSUPPORTED, "costmap %ux%u is too large (over 32 GiB padded)", sx, sy);
   int rc = h->map_buf.reserve(stride * maps);
   if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (!h->map_ready) HIP_TRY(hipEventCreateWithFlags(&h->map_ready, hipEventDisableTiming));
+  if (!h->map_in_use) HIP_TRY(hipEventCreateWithFlags(&h->map_in_use, hipEventDisableTiming));
+  if (h->map_used) HIP_TRY(hipStreamWaitEvent(st, h->map_in_use, 0));   // solves still reading the old map
   IngestArgs a;
   a.src = d_cells;
   a.dst = (uint8_t*)h->map_buf.ptr;
@@ -218,6 +233,7 @@ int ingest(neo_mpc_handle* h, const uint8_t* d_cells, uint32_t maps, uint32_t sx
   a.maps = (int)maps; a.border = border; a.dst_stride = (int64_t)stride;
   launch_ingest(a, stream);
   HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(h->map_ready, st));
   h->map.cells = (const uint8_t*)h->map_buf.ptr + (size_t)border * pitch + border;
   h->map.size_x = (int)sx; h->map.size_y = (int)sy; h->map.pitch = pitch;
   h->map.resolution = res; h->map.inv_resolution = 1.0 / res;
@@ -248,6 +264,19 @@ int fill_args(neo_mpc_handle* h, const neo_mpc_batch* b, SolveArgs& a) {
   a.count = (uint32_t)b->count;
   a.term_table = (const double*)h->term_buf.ptr;
   a.p = h->dp; a.map = h->map; a.lds = h->lds;
+  return NEO_MPC_OK;
+}
+
+// order a launch that reads the device map on `stream`: behind the last ingest ...
+int map_acquire(neo_mpc_handle* h, void* stream) {
+  if (h->map_ready) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, h->map_ready, 0));
+  return NEO_MPC_OK;
+}
+// ... and in front of the next one
+int map_release(neo_mpc_handle* h, void* stream) {
+  if (!h->map_in_use) HIP_TRY(hipEventCreateWithFlags(&h->map_in_use, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(h->map_in_use, (hipStream_t)stream));
+  h->map_used = true;
   return NEO_MPC_OK;
 }
 
@@ -282,6 +311,10 @@ int stage_in(neo_mpc_handle* h, const neo_mpc_batch* b, neo_mpc_batch& d, bool s
   }
   if (b->footprints && b->footprint_points) {
     const size_t bytes = n * b->footprint_points * 2 * 8;
+    for (size_t k = 0; k < n * b->footprint_points * 2; ++k)
+      if (!std::isfinite(b->footprints[k]))
+        return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "footprint vertex %zu of instance %zu is not finite",
+                    (k / 2) % b->footprint_points, k / (2 * b->footprint_points));
     if ((rc = h->footprints.reserve(bytes))) return rc;
     HIP_TRY(hipMemcpy(h->footprints.ptr, b->footprints, bytes, hipMemcpyHostToDevice));
     d.footprints = (const double*)h->footprints.ptr;
@@ -364,6 +397,7 @@ void neo_mpc_destroy(neo_mpc_handle* h) {
   for (DeviceBuffer* b : all) b->release();
   if (h->pin) (void)hipHostFree(h->pin);
   if (h->map_ready) (void)hipEventDestroy(h->map_ready);
+  if (h->map_in_use) (void)hipEventDestroy(h->map_in_use);
   delete h;
 }
 
@@ -386,13 +420,9 @@ int neo_mpc_set_costmap(neo_mpc_handle* h, const uint8_t* cells, uint32_t sx, ui
   int rc = h->raw_buf.reserve((size_t)sx * sy);
   if (rc) return rc;
   HIP_TRY(hipMemcpy(h->raw_buf.ptr, cells, (size_t)sx * sy, hipMemcpyHostToDevice));
-  rc = ingest(h, (const uint8_t*)h->raw_buf.ptr, 1, sx, sy, res, ox, oy, nullptr, nullptr);
-  if (rc) return rc;
   // no synchronisation: `cells` has been consumed by the (blocking) copy above; K3 runs on the null
-  // stream in front of the library's own launches, and the *_device entry points wait for map_ready
-  if (!h->map_ready) HIP_TRY(hipEventCreateWithFlags(&h->map_ready, hipEventDisableTiming));
-  HIP_TRY(hipEventRecord(h->map_ready, nullptr));
-  return NEO_MPC_OK;
+  // stream and every later launch waits for map_ready (recorded by ingest) on its own stream
+  return ingest(h, (const uint8_t*)h->raw_buf.ptr, 1, sx, sy, res, ox, oy, nullptr, nullptr);
 }
 
 int neo_mpc_set_costmap_device(neo_mpc_handle* h, const uint8_t* d_cells, uint32_t sx, uint32_t sy, double res,
@@ -405,7 +435,9 @@ int neo_mpc_set_costmap_device(neo_mpc_handle* h, const uint8_t* d_cells, uint32
 int neo_mpc_set_costmap_pool_device(neo_mpc_handle* h, const uint8_t* d_cells, uint32_t count, uint32_t sx,
                                     uint32_t sy, double res, const double* d_origins, void* stream) {
   if (!h || !d_cells || !d_origins) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "null argument");
-  if (count == 0 || count > (1u << 24)) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "bad costmap count %u", count);
+  if (count == 0) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "bad costmap count %u", count);
+  if (count > NEO_MPC_MAX_POOL_MAPS)   // K3 takes the map index from the grid's y coordinate
+    return fail(NEO_MPC_ERR_UNSUPPORTED, "costmap pool of %u maps: at most %u per call", count, NEO_MPC_MAX_POOL_MAPS);
   HIP_TRY(hipSetDevice(h->device));
   return ingest(h, d_cells, count, sx, sy, res, 0.0, 0.0, d_origins, stream);
 }
@@ -413,7 +445,9 @@ int neo_mpc_set_costmap_pool_device(neo_mpc_handle* h, const uint8_t* d_cells, u
 int neo_mpc_set_costmap_pool(neo_mpc_handle* h, const uint8_t* cells, uint32_t count, uint32_t sx, uint32_t sy,
                              double res, const double* origins) {
   if (!h || !cells || !origins) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "null argument");
-  if (count == 0 || count > (1u << 24)) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "bad costmap count %u", count);
+  if (count == 0) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "bad costmap count %u", count);
+  if (count > NEO_MPC_MAX_POOL_MAPS)   // K3 takes the map index from the grid's y coordinate
+    return fail(NEO_MPC_ERR_UNSUPPORTED, "costmap pool of %u maps: at most %u per call", count, NEO_MPC_MAX_POOL_MAPS);
   HIP_TRY(hipSetDevice(h->device));
   const size_t bytes = (size_t)sx * sy * count;
   int rc = h->raw_buf.reserve(bytes);
@@ -421,12 +455,8 @@ int neo_mpc_set_costmap_pool(neo_mpc_handle* h, const uint8_t* cells, uint32_t c
   if ((rc = h->origins_buf.reserve((size_t)count * 16))) return rc;
   HIP_TRY(hipMemcpy(h->raw_buf.ptr, cells, bytes, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->origins_buf.ptr, origins, (size_t)count * 16, hipMemcpyHostToDevice));
-  rc = ingest(h, (const uint8_t*)h->raw_buf.ptr, count, sx, sy, res, 0.0, 0.0, (const double*)h->origins_buf.ptr,
-              nullptr);
-  if (rc) return rc;
-  if (!h->map_ready) HIP_TRY(hipEventCreateWithFlags(&h->map_ready, hipEventDisableTiming));
-  HIP_TRY(hipEventRecord(h->map_ready, nullptr));
-  return NEO_MPC_OK;
+  return ingest(h, (const uint8_t*)h->raw_buf.ptr, count, sx, sy, res, 0.0, 0.0, (const double*)h->origins_buf.ptr,
+                nullptr);
 }
 
 int neo_mpc_solve_batch_device_timed(neo_mpc_handle* h, const neo_mpc_batch* batch, void* stream, void* start_event,
@@ -435,10 +465,10 @@ int neo_mpc_solve_batch_device_timed(neo_mpc_handle* h, const neo_mpc_batch* bat
   int rc = fill_args(h, batch, a);
   if (rc) return rc;
   HIP_TRY(hipSetDevice(h->device));  // the stream and the buffers must belong to the handle's device
-  if (h->map_ready && stream) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, h->map_ready, 0));
+  if ((rc = map_acquire(h, stream))) return rc;
   launch_solve(a, stream, start_event, stop_event);
   HIP_TRY(hipGetLastError());
-  return NEO_MPC_OK;
+  return map_release(h, stream);
 }
 
 int neo_mpc_solve_batch_device(neo_mpc_handle* h, const neo_mpc_batch* batch, void* stream) {
@@ -473,8 +503,10 @@ static int solve_batch_latency_path(neo_mpc_handle* h, const neo_mpc_batch* b) {
   if (b->predicted_path) d.predicted_path = (double*)(dev + o_path);
   SolveArgs a;
   if ((rc = fill_args(h, &d, a))) return rc;
+  if ((rc = map_acquire(h, nullptr))) return rc;
   launch_solve(a, nullptr);
   HIP_TRY(hipGetLastError());
+  if ((rc = map_release(h, nullptr))) return rc;
   HIP_TRY(hipMemcpyAsync(pin + o_state, dev + o_state, o_end - o_state, hipMemcpyDeviceToHost, nullptr));
   HIP_TRY(hipStreamSynchronize(nullptr));
   memcpy(b->states, pin + o_state, n * sizeof(neo_mpc_state));
@@ -497,8 +529,10 @@ int neo_mpc_solve_batch(neo_mpc_handle* h, const neo_mpc_batch* batch) {
   neo_mpc_batch d;
   if ((rc = stage_in(h, batch, d, false))) return rc;
   if ((rc = fill_args(h, &d, a))) return rc;
+  if ((rc = map_acquire(h, nullptr))) return rc;
   launch_solve(a, nullptr);
   HIP_TRY(hipGetLastError());
+  if ((rc = map_release(h, nullptr))) return rc;
   HIP_TRY(hipDeviceSynchronize());
   return stage_out(h, batch, true);
 }
@@ -518,8 +552,10 @@ int neo_mpc_postprocess_batch(neo_mpc_handle* h, const neo_mpc_batch* batch, con
     HIP_TRY(hipMemcpy(h->success.ptr, success, batch->count * 4, hipMemcpyHostToDevice));
     a.success = (const int32_t*)h->success.ptr;
   }
+  if ((rc = map_acquire(h, nullptr))) return rc;
   launch_postprocess(a, nullptr);
   HIP_TRY(hipGetLastError());
+  if ((rc = map_release(h, nullptr))) return rc;
   HIP_TRY(hipDeviceSynchronize());
   return stage_out(h, batch, false);
 }
@@ -545,9 +581,56 @@ int neo_mpc_objective_batch(neo_mpc_handle* h, const neo_mpc_problem* problems, 
   a.term_table = (const double*)h->term_buf.ptr;
   a.count = (uint32_t)count;
   a.p = h->dp; a.map = h->map;
+  if ((rc = map_acquire(h, nullptr))) return rc;
   launch_objective(a, nullptr);
   HIP_TRY(hipGetLastError());
+  if ((rc = map_release(h, nullptr))) return rc;
   HIP_TRY(hipMemcpy(cost_out, h->cost.ptr, count * 8, hipMemcpyDeviceToHost));
+  return NEO_MPC_OK;
+}
+
+int neo_mpc_gradient_batch(neo_mpc_handle* h, const neo_mpc_problem* problems, const double* u, double* grad_out,
+                           size_t count) {
+  if (!h || !problems || !u || !grad_out) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "null argument");
+  if (!h->has_map) return fail(NEO_MPC_ERR_NO_COSTMAP, "neo_mpc_set_costmap has not been called");
+  if (count == 0) return NEO_MPC_OK;
+  if (count > 0x7fffffffull) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "count too large");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t nv = 3 * (size_t)h->params.control_steps;
+  // K1 itself with `u` as the warm start of instances whose goal is unchanged (no reset), stopped right
+  // after its first gradient pass (DevParams.max_it = kDumpGradient): the gradient comes out of `solution`
+  std::vector<neo_mpc_state> st(count);
+  std::memset(st.data(), 0, count * sizeof(neo_mpc_state));
+  for (size_t i = 0; i < count; ++i) {
+    for (int k = 0; k < 3; ++k) st[i].old_goal[k] = problems[i].goal_xyz[k];
+    for (int k = 0; k < 4; ++k) st[i].old_goal[3 + k] = problems[i].goal_q[k];
+    st[i].has_old_goal = 1;
+  }
+  int rc;
+  if ((rc = h->problems.reserve(count * sizeof(neo_mpc_problem)))) return rc;
+  if ((rc = h->states.reserve(count * sizeof(neo_mpc_state)))) return rc;
+  if ((rc = h->warm.reserve(count * nv * 8))) return rc;
+  if ((rc = h->commands.reserve(count * sizeof(neo_mpc_command)))) return rc;
+  if ((rc = h->solution.reserve(count * nv * 8))) return rc;
+  HIP_TRY(hipMemcpy(h->problems.ptr, problems, count * sizeof(neo_mpc_problem), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->states.ptr, st.data(), count * sizeof(neo_mpc_state), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->warm.ptr, u, count * nv * 8, hipMemcpyHostToDevice));
+  neo_mpc_batch d;
+  std::memset(&d, 0, sizeof(d));
+  d.count = count;
+  d.problems = (const neo_mpc_problem*)h->problems.ptr;
+  d.states = (neo_mpc_state*)h->states.ptr;
+  d.warm_start = (double*)h->warm.ptr;
+  d.commands = (neo_mpc_command*)h->commands.ptr;
+  d.solution = (double*)h->solution.ptr;
+  SolveArgs a;
+  if ((rc = fill_args(h, &d, a))) return rc;
+  a.p.max_it = kDumpGradient;
+  if ((rc = map_acquire(h, nullptr))) return rc;
+  launch_solve(a, nullptr);
+  HIP_TRY(hipGetLastError());
+  if ((rc = map_release(h, nullptr))) return rc;
+  HIP_TRY(hipMemcpy(grad_out, h->solution.ptr, count * nv * 8, hipMemcpyDeviceToHost));
   return NEO_MPC_OK;
 }
 

@@ -11,6 +11,7 @@ constexpr int kLanes = 64;          // one CDNA4 wavefront per MPC instance
 constexpr int kMapBorder = 64;      // lethal border (cells) K3 adds around a single costmap
 constexpr int kPoolBorder = 16;     // ... around each map of a pool (every lookup is bounds-checked anyway)
 constexpr int kMaxTileWidth = 128;  // widest reach tile staged in LDS (bytes per row)
+constexpr int kDumpGradient = 0x40000000;  // DevParams.max_it value of the gradient test hook (neo_mpc_gradient_batch)
 
 // Constants of one solver configuration, precomputed on the host in float64 exactly as
 // the reference evaluates them (mpc_optimization_server.py:137, 252-268).
@@ -37,7 +38,8 @@ struct DevParams {
   int32_t compat;
   int32_t disc_in_box;       // the max_vel_trans disc lies inside the vx/vy box (README params)
   int32_t tame;              // disc_in_box and max|omega| * horizon <= 0.78 rad: the kTame kernels apply
-  int32_t newton;            // lanes 32-63 walk the projected Newton direction (control_steps == 3)
+  int32_t newton;            // search direction of lanes 32-63: 0 projected L-BFGS, 1 projected Newton with
+                             // the dense system (control_steps <= 8), 2 projected Newton by the Riccati sweep
 };
 
 // Device costmap written by the ingest kernel (K3): raw nav2 costs with a lethal border of
@@ -60,6 +62,7 @@ struct LdsLayout {
   int32_t prob, state, tol, term, u, gs, gt, gr, d, u_prev, gt_prev, u_new, S, Y, rho;
   int32_t cs, sn, dxs, dys, rx, ry, rt, nx, ny, mode;  // per-step scratch
   int32_t hess;        // Newton: (3N)^2 Hessian, only when 3N <= 24
+  int32_t ric;         // Riccati: per-stage block curvature (6 N) then gains (12 N), riccati.h
   int32_t tile;        // byte tile starts here (double index)
   int32_t total_bytes;
   int32_t tile_w;      // row stride of the tile in bytes (power of two), 0: no tile
@@ -70,7 +73,7 @@ struct LdsLayout {
 // The carve-up depends on control_steps and the L-BFGS memory only, so the control_steps
 // specialisations of K1 evaluate it at compile time (offsets become immediates); the host uses the
 // same function and adds the reach tile geometry.
-constexpr LdsLayout make_lds_layout(int n, int mem) {
+constexpr LdsLayout make_lds_layout(int n, int mem, bool riccati) {
   LdsLayout l{};
   const int nv = 3 * n;
   int off = 0;
@@ -99,7 +102,8 @@ constexpr LdsLayout make_lds_layout(int n, int mem) {
   l.nx = off; off += n;
   l.ny = off; off += n;
   l.mode = off; off += 2 * n;  // int[4n]: mode, omega-frozen, near-kink, near-kink at the previous iterate
-  l.hess = off; off += (nv <= 24) ? nv * nv : 0;
+  l.hess = off; off += (nv <= 24 && !riccati) ? nv * nv : 0;
+  l.ric = off; off += riccati ? 18 * n : 0;
   off = (off + 1) & ~1;        // 16-byte align the tile
   l.tile = off;
   l.total_bytes = off * 8;

@@ -40,6 +40,7 @@
 #include "costmap.h"
 #include "feasible_set.h"
 #include "rollout.h"
+#include "riccati.h"
 
 namespace neo_mpc {
 namespace {
@@ -90,14 +91,20 @@ constexpr int kNewtonMaxSteps = 8;
 // kStaticTile > 0 (with kSteps > 0): LDS is a static array sized for the compile-time layout plus a reach
 // tile of at most kStaticTile bytes -- every LDS address is then an instruction immediate instead of a
 // "dynamic LDS base + offset" value that lives in (and gets spilled from) a scalar register.
-template <int kMinWavesPerSimd, int kSteps, bool kNewton = false, bool kTame = false, int kStaticTile = 0>
+// kDir: search direction of lanes 32-63 -- 0 projected L-BFGS, 1 projected Newton with the dense system
+// (above), 2 projected Newton solved stage by stage (riccati.h; kSteps == 0 only, any control_steps).
+template <int kMinWavesPerSimd, int kSteps, int kDir = 0, bool kTame = false, int kStaticTile = 0>
 __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveArgs args) {
+  constexpr bool kNewton = kDir == 1;    // dense system in registers
+  constexpr bool kRiccati = kDir == 2;   // stage-wise recursion
+  constexpr bool kSecond = kDir != 0;    // either: Newton stop rules, no quasi-Newton state
+  static_assert(!kRiccati || kSteps == 0, "the Riccati direction lives in the run-time-sized kernel");
   // Newton: control_steps == kSteps, or (kSteps == 0) any control_steps <= kNewtonMaxSteps -- the
   // system's arrays are sized for the bound and every loop over them is guarded by the run-time size
   constexpr int kNwSteps = !kNewton ? 1 : kSteps ? kSteps : kNewtonMaxSteps;
   extern __shared__ __align__(16) double Ldyn[];
   // (the run-time-sized Newton kernel carves LDS for its largest system and no L-BFGS pairs)
-  constexpr LdsLayout kStaticLayout = make_lds_layout(kSteps ? kSteps : kNewtonMaxSteps, kSteps ? 4 : 0);
+  constexpr LdsLayout kStaticLayout = make_lds_layout(kSteps ? kSteps : kNewtonMaxSteps, kSteps ? 4 : 0, false);
   constexpr int kStaticDoubles = kStaticTile ? (kStaticLayout.total_bytes + kStaticTile) / 8 : 2;
   __shared__ __align__(16) double Lstat[kStaticDoubles];
   double* const L = kStaticTile ? Lstat : Ldyn;
@@ -180,6 +187,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   constexpr int kNewtonRecord = 13;
   static_assert(2 * 7 >= kNewtonRecord, "Newton records do not fit the step arrays");
   float* NB = reinterpret_cast<float*>(L + a.lds.cs);
+  double* RC = L + a.lds.ric;   // Riccati: block curvature records (then the gains, riccati.h)
 
   // x0 clipped to the feasible set (SciPy clips x0 to the bounds, _slsqp_py.py:268)
   for (int i = lane; i < n; i += kLanes) project_block<kTame>(p, u[3 * i], u[3 * i + 1], u[3 * i + 2]);
@@ -191,6 +199,13 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
 
   for (int i = lane; i < n; i += kLanes) { AMODE[4 * i + 2] = 0; AMODE[4 * i + 3] = 0; }
   double alpha = 1.0;
+  // Riccati: a block may be sent straight onto the kink u_i = v_cur only when v_cur is feasible
+  bool v_feasible = false;
+  if (kRiccati) {
+    double b0 = c.v0, b1 = c.v1, b2 = c.v2;
+    project_block<kTame>(p, b0, b1, b2);
+    v_feasible = b0 == c.v0 && b1 == c.v1 && b2 == c.v2;
+  }
   int npairs = 0, head = 0, nfev = 1, it = 0, status = NEO_MPC_STATUS_MAX_ITER, stall = 0;
   double gain1 = INFINITY, gain2 = INFINITY;  // objective decrease of the previous two iterations
   bool final_step = false;
@@ -280,7 +295,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       }
       WAVE_SYNC();
     } else if (!kSteps) {
-      // any control_steps <= 64: lane i owns step i; the rollout recursion (py:230-232) is three
+      // (L-BFGS and Riccati) any control_steps <= 64: lane i owns step i; the rollout recursion (py:230-232) is three
       // prefix sums, the adjoint three suffix sums -- one sincos per lane instead of N in a row
       const bool on = lane < n;
       const double vx = on ? u[3 * lane] : 0.0, vy = on ? u[3 * lane + 1] : 0.0, w = on ? u[3 * lane + 2] : 0.0;
@@ -302,6 +317,15 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         gs[3 * lane] = p.dt * (cs * SX + sn * SY);
         gs[3 * lane + 1] = p.dt * (-sn * SX + cs * SY);
         gs[3 * lane + 2] = p.dt * ST;
+        if (kRiccati) {
+          // stage record of the Riccati sweep: trigonometry, position increments and the second-order
+          // terms of this step weighted by the position costates (SX, SY) of its result:
+          // d2(lambda . p)/d(vx, vy, xi)^2 = [[0 0 ax] [0 0 ay] [ax ay kappa]], xi = theta_{i-1} + w dt
+          ACS[lane] = cs; ASN[lane] = sn; ADX[lane] = ddx; ADY[lane] = ddy;
+          ARX[lane] = p.dt * (-SX * sn + SY * cs);
+          ARY[lane] = p.dt * (-SX * cs - SY * sn);
+          ART[lane] = -(SX * ddx + SY * ddy);
+        }
       }
       WAVE_SYNC();
     } else {
@@ -357,7 +381,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         const double sh = (ng2 > p.wc_n * p.wc_n) ? 1.0 - p.wc_n * rsq_fast(ng2) : 0.0;
         t0 = g0 * sh; t1 = g1 * sh; t2 = g2 * sh;
       }
-      AMODE[4 * i + 3] = AMODE[4 * i + 2];
+      if (!kRiccati) AMODE[4 * i + 3] = AMODE[4 * i + 2];   // (Riccati: slot 3 is its to-the-kink flag)
       if (ne < TOL[T_KINK]) {  // next to the kink: prox-only block, outside the quasi-Newton model
         gt[3 * i] = 0.0; gt[3 * i + 1] = 0.0; gt[3 * i + 2] = 0.0;
         gr[3 * i] = 0.0; gr[3 * i + 1] = 0.0; gr[3 * i + 2] = 0.0;
@@ -365,6 +389,10 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         if (kNewton) {
 #pragma unroll
           for (int k = 0; k < kNewtonRecord; ++k) NB[kNewtonRecord * i + k] = 0.0f;  // P = 0: row/column of I
+        }
+        if (kRiccati) {
+#pragma unroll
+          for (int k = 0; k < kRicCurv; ++k) RC[kRicCurv * i + k] = 0.0;
         }
         continue;
       }
@@ -431,14 +459,34 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         nb[7] = c01; nb[8] = c11; nb[9] = c12;
         nb[10] = c02; nb[11] = c12; nb[12] = c22;
       }
+      if (kRiccati) {
+        // block curvature R_i of the stage model: the control norm's Hessian (w/|e|)(I - e e^T/|e|^2)
+        // plus lambda/r t t^T of a binding disc, t = (-ny, nx)
+        double* rc = RC + kRicCurv * i;
+        const double sN = p.wc_n * ine, h0 = e0 * ine, h1 = e1 * ine, h2 = e2 * ine;
+        const double k2 = (mode == 1 && mslot == 2) ? mlam * rcp_fast(p.r) : 0.0;
+        const double tx = -mny, ty = mnx;
+        rc[0] = sN * (1.0 - h0 * h0) + k2 * tx * tx; rc[1] = -sN * h0 * h1 + k2 * tx * ty; rc[2] = -sN * h0 * h2;
+        rc[3] = sN * (1.0 - h1 * h1) + k2 * ty * ty; rc[4] = -sN * h1 * h2; rc[5] = sN * (1.0 - h2 * h2);
+      }
     }
     WAVE_SYNC();
     NEO_PHASE(2);
-    if (kNewton && it == 0 && cold) {
+    if (p.max_it == kDumpGradient) {
+      // test hook (neo_mpc_gradient_batch): hand back the total gradient this kernel variant works with at
+      // the projected x0 -- adjoint gradient of the smooth part + gradient of the control norm -- and stop
+      for (int k = lane; k < nv; k += kLanes) a.solution[(size_t)b * nv + k] = gt[k];
+      return;
+    }
+    if (kSecond && it == 0 && cold) {
       // a cold start (x0 = 0, the reference's reset state py:359) is far from the minimiser and the
       // Newton step almost never wins there: steepest descent on the face for this one iteration
-      if (lane < nvr) d[lane] = -gr[lane];
+      if (kRiccati) { for (int k = lane; k < nv; k += kLanes) d[k] = -gr[k]; }
+      else if (lane < nvr) d[lane] = -gr[lane];
+      if (kRiccati) for (int i = lane; i < n; i += kLanes) AMODE[4 * i + 3] = 0;
       WAVE_SYNC();
+    } else if (kRiccati) {
+      riccati_direction<kTame>(a, c, L, n, lane, v_feasible);
     } else if (kNewton) {
       // From here on the Newton system lives in float32: it only yields a search direction (the arc
       // search and the float64 objective decide), and single precision halves registers, readlanes
@@ -540,7 +588,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     }
     NEO_PHASE(3);
     // ---- new curvature pair
-    if (!kNewton && it > 0) {
+    if (!kSecond && it > 0) {
       double* s = Sm + head * nv;
       double* yv = Ym + head * nv;
       double sy = 0.0, ss = 0.0, yy = 0.0;
@@ -562,7 +610,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     }
     // ---- L-BFGS two-loop recursion on the reduced gradient; lanes take vector elements.
     //      Pair slots are walked with compile-time indices so the alphas stay in registers.
-    if (!kNewton) {
+    if (!kSecond) {
       constexpr bool kWide = (kSteps == 0) || (3 * kSteps > 64);  // more than 64 variables
       double al[kPairs];
       double q0 = lane < nv ? gr[lane] : 0.0;
@@ -615,7 +663,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       if (lane + 128 < nv) d[lane + 128] = -q2;
       WAVE_SYNC();
     }
-    if (!kNewton) {
+    if (!kSecond) {
       // (the Newton system is built on the face: H_r = P H P + (I - P) with a right-hand side inside
       // it, so its solution needs no restriction -- what rounding leaves outside is removed by the
       // projection of every candidate)
@@ -632,12 +680,14 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       }
       WAVE_SYNC();
     }
-    if (kNewton && it > 0) {
+    if (kSecond && it > 0) {
       // the full Newton step is already below the step tolerance: u is the answer (blocks next to
       // the kink are moved by the prox step, which d does not describe -- keep iterating then)
       float dm = 0.0f;
       int anynear = 0;
-      if (lane < nvr) { dm = fabsf(newton_sol); anynear = AMODE[4 * (lane / 3) + 2]; }   // (d[lane], still in a register)
+      if (kRiccati) {
+        for (int k = lane; k < nv; k += kLanes) { dm = fmaxf(dm, (float)fabs(d[k])); anynear |= AMODE[4 * (k / 3) + 2]; }
+      } else if (lane < nvr) { dm = fabsf(newton_sol); anynear = AMODE[4 * (lane / 3) + 2]; }   // (d[lane], still in a register)
       dm = wave_max_f(dm);
       const bool near_any = __ballot(anynear != 0) != 0ull;
       if ((double)dm < TOL[T_EARLY] && !near_any) { status = NEO_MPC_STATUS_CONVERGED; break; }
@@ -652,7 +702,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     double fc = rollout_cost<kSteps, kTame>(
         a, c, L,
         [&](int i, double& b0, double& b1, double& b2) {
-          candidate_block<kTame>(a, c, L, lane, step, pstep, i, b0, b1, b2);
+          candidate_block<kTame, kRiccati>(a, c, L, lane, step, pstep, i, b0, b1, b2);
           if (it == 0 && lane == 0) { b0 = u[3 * i]; b1 = u[3 * i + 1]; b2 = u[3 * i + 2]; }
           if (kSteps) { cand[3 * i] = b0; cand[3 * i + 1] = b1; cand[3 * i + 2] = b2; }
         },
@@ -695,7 +745,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         const double bstep = lane_value(step, best), bpstep = lane_value(pstep, best);
         for (int i = lane; i < n; i += kLanes) {
           double b0, b1, b2;
-          candidate_block<kTame>(a, c, L, best, bstep, bpstep, i, b0, b1, b2);
+          candidate_block<kTame, kRiccati>(a, c, L, best, bstep, bpstep, i, b0, b1, b2);
           u_new[3 * i] = b0; u_new[3 * i + 1] = b1; u_new[3 * i + 2] = b2;
         }
       }
@@ -704,7 +754,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       for (int k = lane; k < nv; k += kLanes) {
         const double nu = u_new[k], ou = u[k];
         stepmax = fmaxf(stepmax, (float)fabs(nu - ou));
-        if (!kNewton) { u_prev[k] = ou; gt_prev[k] = gt[k]; }
+        if (!kSecond) { u_prev[k] = ou; gt_prev[k] = gt[k]; }
         u[k] = nu;
       }
       stepmax = wave_max_f(stepmax);
@@ -942,41 +992,45 @@ void launch_solve(const SolveArgs& a, void* stream, void* ev_start, void* ev_sto
   const bool generic = getenv("NEO_MPC_GENERIC_STEPS") != nullptr || a.p.mem != 4;  // A/B: LDS-only path
   const bool disc = a.p.tame != 0 && getenv("NEO_MPC_NO_TAME_SPECIALISATION") == nullptr;
   const size_t lds = a.lds.total_bytes;
+  const bool small_tile = a.lds.tile_w * a.lds.tile_h <= 1024 && getenv("NEO_MPC_DYNAMIC_LDS") == nullptr;
   // with events: hipExtLaunchKernel stamps them from the dispatch packet itself (no barrier packets in
   // front of and behind the kernel, which is what separate hipEventRecord calls put on the queue)
   hipEvent_t e0 = (hipEvent_t)ev_start, e1 = (hipEvent_t)ev_stop;
-#define NEO_LAUNCH(...)                                                                             \
-  do {                                                                                              \
-    if (e0 || e1) hipExtLaunchKernelGGL((k_solve<__VA_ARGS__>), grid, block, lds, st, e0, e1, 0, a); \
-    else hipLaunchKernelGGL((k_solve<__VA_ARGS__>), grid, block, lds, st, a);                       \
+#define NEO_LAUNCH_LDS(bytes, ...)                                                                       \
+  do {                                                                                                   \
+    if (e0 || e1) hipExtLaunchKernelGGL((k_solve<__VA_ARGS__>), grid, block, bytes, st, e0, e1, 0, a);   \
+    else hipLaunchKernelGGL((k_solve<__VA_ARGS__>), grid, block, bytes, st, a);                          \
   } while (0)
-  if (a.p.n == 3 && a.p.newton) {  // projected Newton (its layout does not depend on lbfgs_memory)
+#define NEO_LAUNCH(...) NEO_LAUNCH_LDS(lds, __VA_ARGS__)
+#define NEO_LAUNCH_W(w, ...)                                                                             \
+  do {                                                                                                   \
+    if ((w) == 4) NEO_LAUNCH(4, __VA_ARGS__); else if ((w) == 3) NEO_LAUNCH(3, __VA_ARGS__); else NEO_LAUNCH(2, __VA_ARGS__); \
+  } while (0)
+  if (a.p.n == 3 && a.p.newton == 1) {  // projected Newton, dense 9 x 9 system (its layout does not depend on lbfgs_memory)
     const int w = solve_variant(disc ? 4 : 3);
-    if (disc && w == 4 && a.lds.tile_w * a.lds.tile_h <= 1024 && getenv("NEO_MPC_DYNAMIC_LDS") == nullptr) {
-      const size_t lds_dyn = lds;   // (the static variant takes no dynamic LDS)
-      (void)lds_dyn;
-      if (e0 || e1) hipExtLaunchKernelGGL((k_solve<4, 3, true, true, 1024>), grid, block, 0, st, e0, e1, 0, a);
-      else hipLaunchKernelGGL((k_solve<4, 3, true, true, 1024>), grid, block, 0, st, a);
-    } else if (disc) { if (w == 4) NEO_LAUNCH(4, 3, true, true); else if (w == 3) NEO_LAUNCH(3, 3, true, true); else NEO_LAUNCH(2, 3, true, true); }
-    else { if (w == 4) NEO_LAUNCH(4, 3, true); else if (w == 3) NEO_LAUNCH(3, 3, true); else NEO_LAUNCH(2, 3, true); }
-  } else if (a.p.n == 3 && !generic) {
+    if (disc && w == 4 && small_tile) NEO_LAUNCH_LDS(0, 4, 3, 1, true, 1024);   // (the static variant takes no dynamic LDS)
+    else if (disc) NEO_LAUNCH_W(w, 3, 1, true);
+    else NEO_LAUNCH_W(w, 3, 1);
+  } else if (a.p.n == 3 && a.p.newton == 0 && !generic) {
+    NEO_LAUNCH_W(solve_variant(3), 3);
+  } else if (a.p.newton == 2) {  // any control_steps: Newton direction by the Riccati sweep (riccati.h)
+    const int w = solve_variant(3);   // (167 VGPRs: spill-free at 3 waves/SIMD)
+    if (disc) NEO_LAUNCH_W(w, 0, 2, true);
+    else NEO_LAUNCH_W(w, 0, 2);
+  } else if (a.p.newton == 1) {  // control_steps <= kNewtonMaxSteps, dense system with run-time size
+    // (a 24-entry row per lane: 158 VGPRs, 187 without the tame specialisation -- spill-free at 3 and 2 waves/SIMD)
+    const int w = solve_variant(disc ? 3 : 2);
+    if (disc && w == 3 && small_tile) NEO_LAUNCH_LDS(0, 3, 0, 1, true, 1024);
+    else if (disc) NEO_LAUNCH_W(w, 0, 1, true);
+    else NEO_LAUNCH_W(w, 0, 1);
+  } else {  // projected L-BFGS, any control_steps
     const int w = solve_variant(3);
-    if (w == 4) NEO_LAUNCH(4, 3); else if (w == 3) NEO_LAUNCH(3, 3); else NEO_LAUNCH(2, 3);
-  } else {  // any other control_steps (measured: at N = 8 the scan-based generic path beats a register
-            // specialisation, 8.5 vs 10.1 ms per 65 536 instances)
-    // (the run-time-sized Newton kernel keeps a 24-entry row per lane: 158 VGPRs, 187 without the
-    // tame specialisation -- spill-free at 3 and 2 waves/SIMD)
-    const int w = solve_variant(a.p.newton && !disc ? 2 : 3);
-    if (a.p.newton) {  // control_steps <= kNewtonMaxSteps
-      if (disc && w == 3 && a.lds.tile_w * a.lds.tile_h <= 1024 && getenv("NEO_MPC_DYNAMIC_LDS") == nullptr) {
-        if (e0 || e1) hipExtLaunchKernelGGL((k_solve<3, 0, true, true, 1024>), grid, block, 0, st, e0, e1, 0, a);
-        else hipLaunchKernelGGL((k_solve<3, 0, true, true, 1024>), grid, block, 0, st, a);
-      } else if (disc) { if (w == 4) NEO_LAUNCH(4, 0, true, true); else if (w == 3) NEO_LAUNCH(3, 0, true, true); else NEO_LAUNCH(2, 0, true, true); }
-      else { if (w == 4) NEO_LAUNCH(4, 0, true); else if (w == 3) NEO_LAUNCH(3, 0, true); else NEO_LAUNCH(2, 0, true); }
-    } else if (disc) { if (w == 4) NEO_LAUNCH(4, 0, false, true); else if (w == 3) NEO_LAUNCH(3, 0, false, true); else NEO_LAUNCH(2, 0, false, true); }
-    else { if (w == 4) NEO_LAUNCH(4, 0); else if (w == 3) NEO_LAUNCH(3, 0); else NEO_LAUNCH(2, 0); }
+    if (disc) NEO_LAUNCH_W(w, 0, 0, true);
+    else NEO_LAUNCH_W(w, 0, 0);
   }
+#undef NEO_LAUNCH_W
 #undef NEO_LAUNCH
+#undef NEO_LAUNCH_LDS
 }
 void launch_carrots(const CarrotArgs& a, void* stream) {
   if (a.b.count == 0) return;

@@ -102,6 +102,7 @@ def request_record(request, delta_t=0.0, footprint_cost=0.0):
     r["control_interval"] = request.control_interval
     r["delta_t"] = delta_t
     r["footprint_cost"] = footprint_cost
+    r["switch_opt"] = 1 if getattr(request, "switch_opt", False) else 0    # cpp:245 (stored py:354, never read)
     return r
 
 
@@ -165,7 +166,10 @@ class MpcOptimizationServer:
     def cb_params(self, data):                               # py:405-439
         changes = {}
         for parameter in data:
-            if getattr(parameter, "type_", 3) != 3:      # py:407: Parameter.Type.DOUBLE only
+            # py:407: Parameter.Type.DOUBLE only.  rclpy's Parameter.Type is a plain Enum (DOUBLE.value == 3),
+            # stand-ins may carry the int itself
+            kind = getattr(parameter, "type_", 3)
+            if getattr(kind, "value", kind) != 3:
                 continue
             if parameter.name in DYNAMIC_PARAMS:
                 changes[parameter.name] = float(parameter.value)

@@ -147,6 +147,18 @@ class BatchSolver:
             C.c_void_p(out.ctypes.data), len(problems)))
         return out
 
+    def gradient(self, problems, u):
+        """Test hook: the total gradient the solve kernel works with at `u` (projected like x0):
+        analytic adjoint gradient + gradient of the control norm, from inside the kernel variant
+        the current parameters select."""
+        problems = np.ascontiguousarray(problems, dtype=abi.PROBLEM_DTYPE)
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        out = np.zeros_like(u)
+        _lib.check(self._lib.neo_mpc_gradient_batch(
+            self._handle, C.c_void_p(problems.ctypes.data), C.c_void_p(u.ctypes.data),
+            C.c_void_p(out.ctypes.data), len(problems)))
+        return out
+
     # -- carrot selection (the step before the solver) ------------------------------------
     def select_carrots(self, plan_poses, plan_offsets, robot_poses, slow_down, footprint_costs=None,
                        problems=None, lookahead_dist_min=0.5, lookahead_dist_max=0.5,

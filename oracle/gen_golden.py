@@ -9,7 +9,7 @@ and the reference's outputs.
 
 Fixture sets: G1 objective/f_constraint values, G2 yaw extraction,
 G3 cold-start SLSQP solves (ftol 1e-3 and 1e-12), G4 stateful optimizer() episodes,
-G5 warm-start shift, G6 SciPy forward-difference gradients.
+G5 warm-start shift, G6 SciPy forward-difference gradients, G7 publishLocalPlan paths.
 """
 import contextlib
 import io
@@ -174,14 +174,16 @@ def gen_g2(mod):
     print("G2: 256 + 64 cases")
 
 
-def gen_g3(mod):
-    """Cold-start solves through the reference's own objective/bounds/constraints."""
+def _g3_group(mod, n_steps, count, seed):
+    """`count` cold-start solves at control_steps = n_steps through the reference's own
+    objective / bounds / constraints objects (py:125-134, 363-364): SLSQP as shipped (ftol 1e-3,
+    maxiter 100) and run to the end (ftol 1e-12, maxiter 500); odd cases on the costmap, even ones
+    on an all-free map (unique minimiser)."""
     from scipy.optimize import minimize
-    count = 128
-    params = dict(README_PARAMS)
+    params = dict(README_PARAMS, control_steps=n_steps)
     cmap = synthetic.make_costmap(200, seed=3)
     zero = (np.zeros((200, 200), np.uint8),) + cmap[1:]
-    probs = synthetic.make_problems(count, 200, seed=303)
+    probs = synthetic.make_problems(count, 200, seed=seed)
     res = {k: [] for k in ("x_loose", "f_loose", "nit_loose", "nfev_loose", "status_loose",
                            "x_tight", "f_tight", "nit_tight", "nfev_tight", "status_tight")}
     refs = (Ref(mod, params, zero), Ref(mod, params, cmap))
@@ -193,7 +195,7 @@ def gen_g3(mod):
         ref.load(probs[j])
         s = ref.srv
         for tag, ftol, maxiter in (("loose", 1e-3, 100), ("tight", 1e-12, 500)):
-            r = minimize(s.objective, np.zeros(9), method="SLSQP", bounds=s.bnds,
+            r = minimize(s.objective, np.zeros(3 * n_steps), method="SLSQP", bounds=s.bnds,
                          constraints=s.cons, options={"ftol": ftol, "disp": False,
                                                       "maxiter": maxiter})
             res["x_" + tag].append(r.x)
@@ -201,12 +203,27 @@ def gen_g3(mod):
             res["nit_" + tag].append(r.nit)
             res["nfev_" + tag].append(r.nfev)
             res["status_" + tag].append(r.status)
-    print("G3: %d solves x2 in %.1fs" % (count, time.time() - t0))
-    np.savez_compressed(os.path.join(OUT, "g3_solves.npz"), versions=np.array(repr(versions())),
-                        param_keys=np.array(PARAM_KEYS), params=params_vec(params),
-                        cells=cmap[0], map_meta=np.array(cmap[1:]), has_map=has_map,
-                        problems=probs.view(np.uint8).reshape(count, -1),
-                        **{k: np.array(v) for k, v in res.items()})
+    print("G3: control_steps %d: %d solves x2 in %.1fs" % (n_steps, count, time.time() - t0), flush=True)
+    out = dict(params=params_vec(params), cells=cmap[0], map_meta=np.array(cmap[1:]), has_map=has_map,
+               problems=probs.view(np.uint8).reshape(count, -1))
+    out.update({k: np.array(v) for k, v in res.items()})
+    return out
+
+
+def gen_g3(mod):
+    """Cold-start solves through the reference's own objective/bounds/constraints: control_steps 3
+    (top-level keys), 8 and 32 (keys prefixed n8_ / n32_; BASELINE configs 3 and 5)."""
+    out = dict(versions=np.array(repr(versions())), param_keys=np.array(PARAM_KEYS))
+    out.update(_g3_group(mod, 3, 128, 303))
+    for n_steps, count, seed in ((8, 64, 308), (32, 24, 332)):
+        out.update({"n%d_%s" % (n_steps, k): v for k, v in _g3_group(mod, n_steps, count, seed).items()})
+    np.savez_compressed(os.path.join(OUT, "g3_solves.npz"), **out)
+
+
+def path_array(path):
+    """nav_msgs/Path -> [poses][x, y, qx, qy, qz, qw] (the fields py:288-306 set)."""
+    return np.array([[p.pose.position.x, p.pose.position.y, p.pose.orientation.x, p.pose.orientation.y,
+                      p.pose.orientation.z, p.pose.orientation.w] for p in path.poses], dtype=np.float64)
 
 
 class FakeClock:
@@ -228,7 +245,7 @@ def gen_g4(mod, n_steps=3, n_ep=8, n_calls=50, fname="g4_episodes.npz"):
     dt_tick = 1.0 / 30.0
     rec = dict(problems=[], delta_t=[], raw_x=[], success=[], out=[], init_guess=[],
                last_control=[], collision=[], collision_footprint=[], waiting_time=[],
-               footprint=[])
+               footprint=[], local_plan=[])
     from scipy.optimize import minimize as sp_min
     for ep in range(n_ep):
         ref = Ref(mod, params, cmap)
@@ -274,8 +291,13 @@ def gen_g4(mod, n_steps=3, n_ep=8, n_calls=50, fname="g4_episodes.npz"):
             delta_t = clock.t - s.last_time       # what py:370 will compute
             pts = footprint_world(row) if use_fp else []
             ref.set_footprint(pts)
+            # tf map -> base_link (py:275-278) = the request's current pose, so that the `local_plan`
+            # the reference publishes (py:271-310) can be compared with the build's predicted_path
+            ros_stubs.Buffer.pending = (row["cur_xy"][0], row["cur_xy"][1], row["cur_q"])
             with contextlib.redirect_stdout(io.StringIO()):   # the reference print()s on collisions
                 resp = s.optimizer(ref.request(row), ros_stubs.Optimizer.Response())
+            ros_stubs.Buffer.pending = None
+            rec["local_plan"].append(path_array(s.PubRaysPath.last))
             out = np.array([resp.output_vel.twist.linear.x, resp.output_vel.twist.linear.y,
                             resp.output_vel.twist.angular.z], dtype=np.float64)
             prow = row.copy()
@@ -314,7 +336,8 @@ def gen_g4(mod, n_steps=3, n_ep=8, n_calls=50, fname="g4_episodes.npz"):
         collision=np.array(rec["collision"]).reshape(shape),
         collision_footprint=np.array(rec["collision_footprint"]).reshape(shape),
         waiting_time=np.array(rec["waiting_time"]).reshape(shape),
-        footprint=np.array(rec["footprint"]).reshape(shape + (4, 2)))
+        footprint=np.array(rec["footprint"]).reshape(shape + (4, 2)),
+        local_plan=np.array(rec["local_plan"]).reshape(shape + (n_steps + 1, 6)))
     n_col = int(np.sum(rec["collision"]))
     n_fp = int(np.sum(rec["collision_footprint"]))
     print("G4 (%s, control_steps %d): %d episodes x %d calls; collision-latched calls %d, footprint-collision "
@@ -336,32 +359,73 @@ def gen_g5(mod):
 
 
 def gen_g6(mod):
-    """SciPy's forward-difference gradient of the reference objective (zero costmap)."""
+    """SciPy's forward-difference gradient of the reference objective (py:204-269, zero costmap) at
+    FEASIBLE controls -- what SLSQP sees through `approx_derivative` (_slsqp_py.py:381) -- for
+    control_steps 3, 8 and 32.  Checks the build's analytic adjoint (agreement ~1e-6: the FD error)."""
     from scipy.optimize._numdiff import approx_derivative
     rng = np.random.default_rng(106)
     out = dict(versions=np.array(repr(versions())), param_keys=np.array(PARAM_KEYS))
-    for n_steps in (3, 8):
+    for n_steps, count in ((3, 32), (8, 32), (32, 16)):
         params = dict(README_PARAMS, control_steps=n_steps)
         zero = (np.zeros((200, 200), np.uint8), 0.05, -5.0, -5.0)
         ref = Ref(mod, params, zero)
-        probs = synthetic.make_problems(32, 200, seed=600 + n_steps)
-        u = rng.uniform(-0.6, 0.6, size=(32, 3 * n_steps))
+        probs = synthetic.make_problems(count, 200, seed=600 + n_steps)
+        u = rng.uniform(-0.6, 0.6, size=(count, 3 * n_steps))
+        blk = u.reshape(count, n_steps, 3)
+        speed = np.hypot(blk[:, :, 0], blk[:, :, 1])
+        blk[:, :, :2] *= np.minimum(1.0, 0.69 / np.maximum(speed, 1e-12))[:, :, None]   # inside the disc
         grads = np.zeros_like(u)
-        for j in range(32):
+        for j in range(count):
             ref.load(probs[j])
             grads[j] = approx_derivative(ref.srv.objective, u[j], method="2-point",
                                          abs_step=math.sqrt(np.finfo(float).eps))
         k = "n%d_" % n_steps
         out[k + "params"] = params_vec(params)
-        out[k + "problems"] = probs.view(np.uint8).reshape(32, -1)
+        out[k + "problems"] = probs.view(np.uint8).reshape(count, -1)
         out[k + "u"], out[k + "grad"] = u, grads
     np.savez_compressed(os.path.join(OUT, "g6_fd_gradient.npz"), **out)
-    print("G6: 2 x 32 cases")
+    print("G6: 3 groups")
+
+
+def gen_g7(mod):
+    """`publishLocalPlan` (py:271-310) on random controls: the nav_msgs/Path the reference publishes
+    on `local_plan` for a given map -> base_link transform (planar, non-planar and non-unit
+    rotations), incl. the w-first `quaternion_from_euler` (py:182-196, 301-305)."""
+    rng = np.random.default_rng(107)
+    out = dict(versions=np.array(repr(versions())), param_keys=np.array(PARAM_KEYS))
+    for n_steps in (3, 8, 32):
+        params = dict(README_PARAMS, control_steps=n_steps)
+        ref = Ref(mod, params, None)
+        count = 48
+        x = rng.uniform(-0.7, 0.7, size=(count, 3 * n_steps))
+        pos = rng.uniform(-4.0, 4.0, size=(count, 2))
+        q = synthetic.yaw_quat(rng.uniform(-math.pi, math.pi, size=count))
+        q[32:] = rng.normal(size=(count - 32, 4))            # non-planar / non-unit rotations
+        paths = np.zeros((count, n_steps + 1, 6))
+        for j in range(count):
+            ros_stubs.Buffer.pending = (pos[j, 0], pos[j, 1], q[j])
+            ref.srv.publishLocalPlan(x[j].copy())
+            paths[j] = path_array(ref.srv.PubRaysPath.last)
+        ros_stubs.Buffer.pending = None
+        k = "n%d_" % n_steps
+        out[k + "params"] = params_vec(params)
+        out[k + "x"], out[k + "tf_xy"], out[k + "tf_q"], out[k + "path"] = x, pos, q, paths
+    np.savez_compressed(os.path.join(OUT, "g7_local_plan.npz"), **out)
+    print("G7: 3 x 48 cases")
 
 
 def main():
     os.makedirs(OUT, exist_ok=True)
     mod = ros_stubs.load_reference()
+    only = set(sys.argv[1:])      # e.g. `gen_golden.py g3 g7`: regenerate some sets only
+    if only:
+        for name in sorted(only):
+            if name == "g4":
+                gen_g4(mod)
+                gen_g4(mod, n_steps=8, n_ep=4, n_calls=30, fname="g4_episodes_n8.npz")
+            else:
+                globals()["gen_" + name](mod)
+        return
     gen_g1(mod)
     gen_g2(mod)
     gen_g3(mod)
@@ -369,6 +433,7 @@ def main():
     gen_g4(mod, n_steps=8, n_ep=4, n_calls=30, fname="g4_episodes_n8.npz")
     gen_g5(mod)
     gen_g6(mod)
+    gen_g7(mod)
 
 
 if __name__ == "__main__":

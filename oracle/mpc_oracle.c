@@ -354,6 +354,8 @@ typedef struct orc_active {
   uint8_t disc[ORC_MAXN];  /* mode 1 and the binding constraint is the disc (curved) */
   double nx[ORC_MAXN], ny[ORC_MAXN];
   double lambda[ORC_MAXN]; /* mode 1: n . (-g) > 0, the multiplier estimate of the binding constraint */
+  uint8_t tokink[ORC_MAXN]; /* Riccati direction: the stage model's minimiser is the kink itself (d_i = v - u_i) */
+  int riccati;              /* the Riccati kernel's candidate rules apply (per-block prox step) */
 } orc_active;
 
 
@@ -362,6 +364,7 @@ static void orc_reduce(const orc_ctx* c, const double* u, const double* gs, doub
   for (int i = 0; i < c->n; ++i) {
     const double* ui = u + 3 * i;
     const double* gsi = gs + 3 * i;
+    a->tokink[i] = 0;
     double e[3] = {ui[0] - c->v[0], ui[1] - c->v[1], ui[2] - c->v[2]};
     double ne = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
     double gi[3];
@@ -425,6 +428,7 @@ static void orc_reduce(const orc_ctx* c, const double* u, const double* gs, doub
 
 static void orc_apply_active(const orc_ctx* c, const orc_active* a, double* d) {
   for (int i = 0; i < c->n; ++i) {
+    if (a->tokink[i]) continue;
     if (a->near[i]) { d[3 * i] = 0.0; d[3 * i + 1] = 0.0; d[3 * i + 2] = 0.0; continue; }
     if (a->wfroz[i]) d[3 * i + 2] = 0.0;
     if (a->mode[i] == 1) {
@@ -442,6 +446,7 @@ static void orc_apply_active(const orc_ctx* c, const orc_active* a, double* d) {
  * binding disc; restricted to the tangent cone's face with the projector P (H_r = P H P + I - P)
  * and solved by Gaussian elimination without pivoting, non-positive pivots replaced. */
 #define ORC_NEWTON_MAXV 24
+static int orc_newton_f64 = 0;
 static void orc_newton_direction(const orc_ctx* c, const double* u, const double* gs, const double* gr,
                                  const orc_active* a, double* d) {
   const int n = c->n, nv = 3 * n;
@@ -498,6 +503,25 @@ static void orc_newton_direction(const orc_ctx* c, const double* u, const double
     H[3 * i + 2][3 * i + 2] += 1.0 - PW[i];
   }
   for (int j = 0; j < nv; ++j) { rhs[j] = -gr[j]; dmax = fmax(dmax, fabs(H[j][j])); }
+  if (orc_newton_f64) { /* test hook: the same elimination in float64 */
+    const double delta = fmax(1e-6 * dmax, 1e-30);
+    for (int p = 0; p < nv; ++p) {
+      double piv = H[p][p];
+      if (!(piv > delta)) piv = fmax(fabs(piv), delta);
+      H[p][p] = piv;
+      for (int j = p + 1; j < nv; ++j) {
+        const double fac = H[j][p] / piv;
+        for (int q = p + 1; q < nv; ++q) H[j][q] -= fac * H[p][q];
+        rhs[j] -= fac * rhs[p];
+      }
+    }
+    for (int p = nv - 1; p >= 0; --p) {
+      double acc = rhs[p];
+      for (int q = p + 1; q < nv; ++q) acc -= H[p][q] * d[q];
+      d[p] = acc / H[p][p];
+    }
+    return;
+  }
   /* the reduced system is solved in float32 (as the kernel does): it only yields a search direction */
   float Hf[ORC_NEWTON_MAXV][ORC_NEWTON_MAXV], rf[ORC_NEWTON_MAXV], df[ORC_NEWTON_MAXV];
   for (int j = 0; j < nv; ++j) { rf[j] = (float)rhs[j]; for (int q = 0; q < nv; ++q) Hf[j][q] = (float)H[j][q]; }
@@ -520,6 +544,199 @@ static void orc_newton_direction(const orc_ctx* c, const double* u, const double
     d[p] = (double)df[p];
   }
 }
+
+/* Projected Newton direction by the stage-wise (Riccati) recursion (method RICCATI), any control_steps.
+ * The same system as orc_newton_direction -- H_r d = -g_r with H the exact Hessian of the smooth part
+ * plus the control norm's and a binding disc's curvature, restricted to the tangent cone's face --
+ * but solved as the linear-quadratic problem it is: the rollout (py:230-232) is a chain
+ * z_i = F(z_{i-1}, u_i), z = (x, y, theta), so
+ *     H = sum_i J_i^T W_i J_i + sum_i lambda_i . d2F_i + blockdiag(R_i),
+ * W_i the stage cost's Hessian, lambda_i = (SX_i, SY_i) the costate of the adjoint sweep, J_i the
+ * sensitivity of z_i.  One backward sweep over the stages with 3x3 value-function Hessians and one
+ * forward sweep give d in O(control_steps) -- no (3N)^2 matrix, no finite differences. */
+static void orc_sym3_solve_prepare(double Q[3][3], double L[3][3], double delta) {
+  /* LDL^T-free Cholesky-like elimination without pivoting, non-positive pivots replaced:
+   * L holds the eliminated upper triangle rows (as orc_newton_direction does for the dense system) */
+  for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) L[r][q] = Q[r][q];
+  for (int p = 0; p < 3; ++p) {
+    double piv = L[p][p];
+    if (!(piv > delta)) piv = fmax(fabs(piv), delta);
+    L[p][p] = piv;
+    for (int j = p + 1; j < 3; ++j) {
+      const double fac = L[j][p] / piv;
+      L[j][p] = fac; /* multiplier kept below the diagonal */
+      for (int q = p + 1; q < 3; ++q) L[j][q] -= fac * L[p][q];
+    }
+  }
+}
+static void orc_sym3_solve(double L[3][3], const double* b, double* x) {
+  double y[3] = {b[0], b[1], b[2]};
+  for (int p = 0; p < 3; ++p)
+    for (int j = p + 1; j < 3; ++j) y[j] -= L[j][p] * y[p];
+  for (int p = 2; p >= 0; --p) {
+    double acc = y[p];
+    for (int q = p + 1; q < 3; ++q) acc -= L[p][q] * x[q];
+    x[p] = acc / L[p][p];
+  }
+}
+
+static int orc_kink_predict = 1; /* (the debug hook switches it off to compare with the dense direction) */
+static void orc_riccati_direction(const orc_ctx* c, const double* u, const double* gs, const double* gt, orc_active* a,
+                                  double* d) {
+  const int n = c->n;
+  const double dt = c->dt;
+  double cs[ORC_MAXN], sn[ORC_MAXN], px[ORC_MAXN], py[ORC_MAXN], SX[ORC_MAXN], SY[ORC_MAXN];
+  { /* nominal rollout and position costates */
+    double x = 0.0, y = 0.0, th = 0.0, rx[ORC_MAXN], ry[ORC_MAXN];
+    for (int i = 0; i < n; ++i) {
+      th += u[3 * i + 2] * dt;
+      cs[i] = cos(th); sn[i] = sin(th);
+      px[i] = (u[3 * i] * cs[i] - u[3 * i + 1] * sn[i]) * dt;
+      py[i] = (u[3 * i] * sn[i] + u[3 * i + 1] * cs[i]) * dt;
+      x += px[i]; y += py[i];
+      rx[i] = -2.0 * c->wt_n * (c->cx - x);
+      ry[i] = -2.0 * c->wt_n * (c->cy - y);
+    }
+    double ax = 0.0, ay = 0.0;
+    for (int i = n - 1; i >= 0; --i) { ax += rx[i]; ay += ry[i]; SX[i] = ax; SY[i] = ay; }
+  }
+  static _Thread_local double Kf[ORC_MAXN][3][3], kf[ORC_MAXN][3];
+  double V[3][3] = {{0}}, v[3] = {0.0, 0.0, 0.0};
+  for (int i = n - 1; i >= 0; --i) {
+    /* S = W_i + V: Hessian of (stage cost at z_i + cost to go) */
+    double S[3][3];
+    for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) S[r][q] = V[r][q];
+    S[0][0] += 2.0 * c->wt_n; S[1][1] += 2.0 * c->wt_n;
+    S[2][2] += 2.0 * c->wo_n + (i == n - 1 ? 2.0 * c->wterm_o : 0.0);
+    const double A[3][3] = {{1, 0, -py[i]}, {0, 1, px[i]}, {0, 0, 1}};
+    const double B[3][3] = {{dt * cs[i], -dt * sn[i], -py[i] * dt}, {dt * sn[i], dt * cs[i], px[i] * dt}, {0, 0, dt}};
+    double SA[3][3], SB[3][3], Qzz[3][3], Quz[3][3], Quu[3][3], Qz[3], Qu[3];
+    for (int r = 0; r < 3; ++r)
+      for (int q = 0; q < 3; ++q) {
+        SA[r][q] = 0.0; SB[r][q] = 0.0;
+        for (int k = 0; k < 3; ++k) { SA[r][q] += S[r][k] * A[k][q]; SB[r][q] += S[r][k] * B[k][q]; }
+      }
+    for (int r = 0; r < 3; ++r) {
+      Qz[r] = 0.0; Qu[r] = gt[3 * i + r];
+      for (int k = 0; k < 3; ++k) { Qz[r] += A[k][r] * v[k]; Qu[r] += B[k][r] * v[k]; }
+      for (int q = 0; q < 3; ++q) {
+        Qzz[r][q] = 0.0; Quz[r][q] = 0.0; Quu[r][q] = 0.0;
+        for (int k = 0; k < 3; ++k) {
+          Qzz[r][q] += A[k][r] * SA[k][q]; Quz[r][q] += B[k][r] * SA[k][q]; Quu[r][q] += B[k][r] * SB[k][q];
+        }
+      }
+    }
+    /* second-order terms of the rollout step, weighted by the costate (SX_i, SY_i) of its result:
+     * with xi = theta_{i-1} + w dt, d2(lambda . p)/d(vx, vy, xi)^2 = [[0 0 ax], [0 0 ay], [ax ay kappa]] */
+    const double ax = dt * (-SX[i] * sn[i] + SY[i] * cs[i]), ay = dt * (-SX[i] * cs[i] - SY[i] * sn[i]);
+    const double kappa = -(SX[i] * px[i] + SY[i] * py[i]);
+    Qzz[2][2] += kappa;
+    Quz[0][2] += ax; Quz[1][2] += ay; Quz[2][2] += dt * kappa;
+    Quu[0][2] += dt * ax; Quu[2][0] += dt * ax; Quu[1][2] += dt * ay; Quu[2][1] += dt * ay; Quu[2][2] += dt * dt * kappa;
+    /* block curvature R_i and the face projector P_i (as in orc_newton_direction) */
+    double P[3][3] = {{0}};
+    a->tokink[i] = 0;
+    if (!a->near[i] && orc_kink_predict) {
+      /* does the stage model put this block ON the kink u_i = v_cur?  0 in Qu_s + Quu_s k + w d|u_i + k - v|
+       * at k = v - u_i  <=>  |Qu_s + Quu_s (v - u_i)| <= w  (smooth parts only) */
+      const double* ui = u + 3 * i;
+      double kk[3] = {c->v[0] - ui[0], c->v[1] - ui[1], c->v[2] - ui[2]}, r[3];
+      for (int q = 0; q < 3; ++q) {
+        r[q] = gs[3 * i + q];
+        for (int k = 0; k < 3; ++k) r[q] += B[k][q] * v[k] + Quu[q][k] * kk[k];
+      }
+      double vv[3] = {c->v[0], c->v[1], c->v[2]}, vp[3] = {c->v[0], c->v[1], c->v[2]};
+      orc_project(c, vp);
+      const int feasible = vp[0] == vv[0] && vp[1] == vv[1] && vp[2] == vv[2];
+      if (feasible && r[0] * r[0] + r[1] * r[1] + r[2] * r[2] <= c->wc_n * c->wc_n) a->tokink[i] = 1;
+    }
+    if (a->tokink[i]) {
+      const double* ui = u + 3 * i;
+      for (int r = 0; r < 3; ++r) {
+        kf[i][r] = c->v[r] - ui[r];
+        for (int q = 0; q < 3; ++q) Kf[i][r][q] = 0.0;
+      }
+      /* fixed step, no feedback: v = Qz + Quz^T k, V = Qzz */
+      for (int r = 0; r < 3; ++r) {
+        v[r] = Qz[r];
+        for (int k = 0; k < 3; ++k) v[r] += Quz[k][r] * kf[i][k];
+        for (int q = 0; q < 3; ++q) V[r][q] = Qzz[r][q];
+      }
+      continue;
+    }
+    if (!a->near[i]) {
+      const double* ui = u + 3 * i;
+      double e[3] = {ui[0] - c->v[0], ui[1] - c->v[1], ui[2] - c->v[2]};
+      double ne = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+      if (ne > 0.0) {
+        const double s = c->wc_n / ne;
+        for (int r = 0; r < 3; ++r)
+          for (int q = 0; q < 3; ++q) Quu[r][q] += s * ((r == q ? 1.0 : 0.0) - (e[r] / ne) * (e[q] / ne));
+      }
+      P[2][2] = a->wfroz[i] ? 0.0 : 1.0;
+      if (a->mode[i] == 0) { P[0][0] = 1.0; P[1][1] = 1.0; }
+      else if (a->mode[i] == 1) {
+        const double nx = a->nx[i], ny = a->ny[i];
+        P[0][0] = 1.0 - nx * nx; P[0][1] = P[1][0] = -nx * ny; P[1][1] = 1.0 - ny * ny;
+        if (a->disc[i]) {
+          const double k2 = a->lambda[i] / c->r, tx = -ny, ty = nx;
+          Quu[0][0] += k2 * tx * tx; Quu[0][1] += k2 * tx * ty; Quu[1][0] += k2 * ty * tx; Quu[1][1] += k2 * ty * ty;
+        }
+      }
+    }
+    double T[3][3], Qur[3], Quzr[3][3], Quur[3][3];
+    for (int r = 0; r < 3; ++r) {
+      Qur[r] = 0.0;
+      for (int k = 0; k < 3; ++k) Qur[r] += P[r][k] * Qu[k];
+      for (int q = 0; q < 3; ++q) {
+        T[r][q] = 0.0; Quzr[r][q] = 0.0;
+        for (int k = 0; k < 3; ++k) { T[r][q] += P[r][k] * Quu[k][q]; Quzr[r][q] += P[r][k] * Quz[k][q]; }
+      }
+    }
+    double dmax = 0.0;
+    for (int r = 0; r < 3; ++r)
+      for (int q = 0; q < 3; ++q) {
+        Quur[r][q] = (r == q ? 1.0 : 0.0) - P[r][q];
+        for (int k = 0; k < 3; ++k) Quur[r][q] += T[r][k] * P[k][q];
+      }
+    for (int r = 0; r < 3; ++r) dmax = fmax(dmax, fabs(Quur[r][r]));
+    double L[3][3];
+    orc_sym3_solve_prepare(Quur, L, fmax(1e-6 * dmax, 1e-30));
+    double rhs[3] = {-Qur[0], -Qur[1], -Qur[2]};
+    orc_sym3_solve(L, rhs, kf[i]);
+    for (int q = 0; q < 3; ++q) {
+      double col[3] = {-Quzr[0][q], -Quzr[1][q], -Quzr[2][q]}, sol[3];
+      orc_sym3_solve(L, col, sol);
+      for (int r = 0; r < 3; ++r) Kf[i][r][q] = sol[r];
+    }
+    for (int r = 0; r < 3; ++r) {
+      v[r] = Qz[r];
+      for (int k = 0; k < 3; ++k) v[r] += Quzr[k][r] * kf[i][k];
+      for (int q = 0; q < 3; ++q) {
+        V[r][q] = Qzz[r][q];
+        for (int k = 0; k < 3; ++k) V[r][q] += Quzr[k][r] * Kf[i][k][q];
+      }
+    }
+    for (int r = 0; r < 3; ++r) for (int q = r + 1; q < 3; ++q) { V[r][q] = V[q][r] = 0.5 * (V[r][q] + V[q][r]); }
+  }
+  double dz[3] = {0.0, 0.0, 0.0};
+  for (int i = 0; i < n; ++i) {
+    double du[3];
+    for (int r = 0; r < 3; ++r) {
+      du[r] = kf[i][r];
+      for (int q = 0; q < 3; ++q) du[r] += Kf[i][r][q] * dz[q];
+      d[3 * i + r] = du[r];
+    }
+    const double nx0 = dz[0] - py[i] * dz[2] + dt * (cs[i] * du[0] - sn[i] * du[1]) - py[i] * dt * du[2];
+    const double ny0 = dz[1] + px[i] * dz[2] + dt * (sn[i] * du[0] + cs[i] * du[1]) + px[i] * dt * du[2];
+    dz[2] += dt * du[2]; dz[0] = nx0; dz[1] = ny0;
+  }
+}
+
+/* debug/test hook: both Newton directions at a feasible point u (the dense one in float64) */
+void orc_debug_newton_directions(const neo_mpc_params* p, const uint8_t* cells, int32_t sx, int32_t sy, double res,
+                                 double ox, double oy, const neo_mpc_problem* q, const double* u, double* d_dense,
+                                 double* d_stage, double* grad_total);
 
 static double orc_dot(const double* a, const double* b, int n) {
   double s = 0.0;
@@ -546,14 +763,18 @@ static void orc_candidate(const orc_ctx* c, const orc_active* act, int lane, dou
   for (int i = 0; i < c->n; ++i) {
     double b[3];
     if (lane < 32 || act->near[i]) {
-      const double a = alpha * sc;
+      /* per-block step: the curvature of block i's own tracking terms is proportional to the number
+       * of stages it still moves, N - i (diagonal of the Gauss-Newton Hessian: 2 w_trans/N dt^2 (N - i)) */
+      const double a = alpha * sc * (act->riccati ? (double)c->n / (double)(c->n - i) : 1.0);
       double e[3], ne2 = 0.0;
       for (int k = 0; k < 3; ++k) { e[k] = (u[3 * i + k] - a * gs[3 * i + k]) - c->v[k]; ne2 += e[k] * e[k]; }
       double ne = sqrt(ne2);
       double sh = (ne > 0.0) ? fmax(0.0, 1.0 - a * c->wc_n / ne) : 0.0;
       for (int k = 0; k < 3; ++k) b[k] = c->v[k] + sh * e[k];
     } else {
-      for (int k = 0; k < 3; ++k) b[k] = u[3 * i + k] + sc * d[3 * i + k];
+      const double t = act->tokink[i] ? fmin(sc, 1.0) : sc;
+      for (int k = 0; k < 3; ++k) b[k] = u[3 * i + k] + t * d[3 * i + k];
+      if (act->tokink[i] && t == 1.0) for (int k = 0; k < 3; ++k) b[k] = c->v[k];
     }
     orc_project(c, b);
     for (int k = 0; k < 3; ++k) cand[3 * i + k] = b[k];
@@ -575,7 +796,10 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
   if (mem > NEO_MPC_MAX_LBFGS_MEMORY) mem = NEO_MPC_MAX_LBFGS_MEMORY;
   const double xtol = p->step_tolerance > 0.0 ? p->step_tolerance : 1e-3 * p->opt_tolerance;
   const double stall_step = p->stall_step > 0.0 ? p->stall_step : 0.3 * p->opt_tolerance;
-  const int newton = p->method != NEO_MPC_METHOD_LBFGS && 3 * p->control_steps <= ORC_NEWTON_MAXV;
+  /* search direction of lanes 32-63: stage-wise (Riccati) Newton, dense Newton (control_steps <= 8) or L-BFGS */
+  const int riccati = p->method == NEO_MPC_METHOD_RICCATI ||
+                      (p->method == NEO_MPC_METHOD_AUTO && p->control_steps != 3);
+  const int newton = riccati || (p->method != NEO_MPC_METHOD_LBFGS && 3 * p->control_steps <= ORC_NEWTON_MAXV);
   /* Newton converges quadratically, so a run of tiny gains means creeping along a costmap cell
    * edge much earlier than with L-BFGS: looser default */
   const double ftol = p->cost_tolerance > 0.0 ? p->cost_tolerance : (newton ? 3e-4 : 3e-6) * p->opt_tolerance;
@@ -586,6 +810,8 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
   double rho[NEO_MPC_MAX_LBFGS_MEMORY];
   int npairs = 0, head = 0; /* ring: newest at (head-1) mod mem */
   orc_active act;
+  memset(&act, 0, sizeof(act));
+  act.riccati = riccati;
   uint8_t near_prev[ORC_MAXN];
   memset(near_prev, 0, sizeof(near_prev));
 
@@ -600,8 +826,11 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
   double alpha = 1.0;
   int nfev = 1, it = 0, status = NEO_MPC_STATUS_MAX_ITER, stall = 0;
   /* three iterations in a row that together gain less than wtol end the search (Newton only by default) */
+  /* (beyond 8 control steps the objective is flatter per block -- weights are divided by N: the window
+   * shrinks with (8/N)^2, measured on the control_steps 32 reference solves) */
+  const double wscale = n > 8 ? (8.0 / n) * (8.0 / n) : 1.0;
   const double wtol = p->window_tolerance > 0.0 ? p->window_tolerance
-                      : (p->window_tolerance == 0.0 && newton) ? 3e-3 * p->opt_tolerance : 0.0;
+                      : (p->window_tolerance == 0.0 && newton) ? 3e-3 * p->opt_tolerance * wscale : 0.0;
   double gain1 = INFINITY, gain2 = INFINITY;
   const double final_tol = p->step_tolerance > 0.0 ? p->step_tolerance : p->opt_tolerance;
   int final = 0;
@@ -613,6 +842,7 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
        * Newton step almost never wins there (9 % of the cases): lanes 32-63 walk the reduced
        * steepest-descent direction in that first iteration instead */
       if (it == 0 && cold) for (int k = 0; k < nv; ++k) d[k] = -gr[k];
+      else if (riccati) orc_riccati_direction(&c, u, gs, gt, &act, d);
       else orc_newton_direction(&c, u, gs, gr, &act, d);
       orc_apply_active(&c, &act, d);
       if (it > 0) { /* the full Newton step is already below the step tolerance: u is the answer
@@ -667,13 +897,14 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
       orc_apply_active(&c, &act, d);
     }
     /* 64 candidates, lowest objective wins (ties: lowest lane) */
-    double fb = INFINITY;
-    int best = -1;
+    double fb = INFINITY, fb_qn = INFINITY;
+    int best = -1, best_qn = -1;
     for (int lane = 0; lane < ORC_LANES; ++lane) {
       orc_candidate(&c, &act, lane, alpha, u, gs, d, cand);
       if (it == 0 && lane == 0) memcpy(cand, u, sizeof(double) * nv); /* the kernel gets f(x0) from this lane */
       double fc = orc_eval(&c, cand);
       if (fc < fb) { fb = fc; best = lane; memcpy(best_c, cand, sizeof(double) * nv); }
+      if (lane >= 32 && fc < fb_qn) { fb_qn = fc; best_qn = lane; }
       if (orc_trace > 1 && it == orc_trace) {
         fprintf(stderr, "  lane %2d sc %.3e fc-f %.3e cand", lane, orc_lane_scale(lane), fc - f);
         for (int k = 0; k < nv; ++k) fprintf(stderr, " %.7f", cand[k] - u[k]);
@@ -691,8 +922,10 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
     if (orc_trace) {
       double gn = 0.0;
       for (int k = 0; k < nv; ++k) gn = fmax(gn, fabs(gr[k]));
-      fprintf(stderr, "it %3d f %.15g fb-f %.3e best %2d alpha %.3e |gr|inf %.3e npairs %d\n", it, f, fb - f, best,
-              alpha, gn, npairs);
+      int nact = 0, nnear = 0;
+      for (int i = 0; i < n; ++i) { nact += act.mode[i] != 0 || act.wfroz[i]; nnear += act.near[i]; }
+      fprintf(stderr, "it %3d f %.15g fb-f %.3e best %2d alpha %.3e |gr|inf %.3e npairs %d | qn best %2d df %.3e active %d near %d\n",
+              it, f, fb - f, best, alpha, gn, npairs, best_qn, fb_qn - f, nact, nnear);
     }
     if (!(fb < f)) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
     double step = 0.0;
@@ -792,6 +1025,50 @@ void orc_solve_batch(const neo_mpc_params* p, const uint8_t* cells, int32_t sx, 
   }
 }
 
+
+/* test hooks of the solver mirror: the total gradient the solver uses at a (projected) point u --
+ * adjoint gradient of the smooth part + control-norm gradient -- and both Newton directions */
+void orc_gradient_batch(const neo_mpc_params* p, const uint8_t* cells, int32_t sx, int32_t sy, double res,
+                        double ox, double oy, const neo_mpc_problem* probs, const double* u, double* g_out,
+                        size_t count) {
+  orc_map m = orc_make_map(cells, sx, sy, res, ox, oy);
+  const int nv = 3 * p->control_steps;
+  for (size_t i = 0; i < count; ++i) {
+    orc_ctx c;
+    orc_ctx_init(&c, p, &m, &probs[i], probs[i].footprint_cost);
+    c.kink_radius = 0.0; /* plain gradient: no block is treated as sitting on the kink */
+    double gs[ORC_MAXV], gr[ORC_MAXV];
+    orc_active act;
+    orc_grad_smooth(&c, u + i * nv, gs);
+    orc_reduce(&c, u + i * nv, gs, g_out + i * nv, gr, &act);
+  }
+}
+
+void orc_debug_newton_directions(const neo_mpc_params* p, const uint8_t* cells, int32_t sx, int32_t sy, double res,
+                                 double ox, double oy, const neo_mpc_problem* q, const double* u, double* d_dense,
+                                 double* d_stage, double* grad_total) {
+  orc_map m = orc_make_map(cells, sx, sy, res, ox, oy);
+  orc_ctx c;
+  orc_ctx_init(&c, p, &m, q, q->footprint_cost);
+  double gs[ORC_MAXV], gt[ORC_MAXV], gr[ORC_MAXV];
+  orc_active act;
+  orc_grad_smooth(&c, u, gs);
+  orc_reduce(&c, u, gs, gt, gr, &act);
+  const int nv = 3 * c.n;
+  if (grad_total) memcpy(grad_total, gt, sizeof(double) * nv);
+  if (d_dense && nv <= ORC_NEWTON_MAXV) {
+    orc_newton_f64 = 1;
+    orc_newton_direction(&c, u, gs, gr, &act, d_dense);
+    orc_newton_f64 = 0;
+    orc_apply_active(&c, &act, d_dense);
+  }
+  if (d_stage) {
+    orc_kink_predict = 0;
+    orc_riccati_direction(&c, u, gs, gt, &act, d_stage);
+    orc_kink_predict = 1;
+    orc_apply_active(&c, &act, d_stage);
+  }
+}
 
 /* ------------------------------------------------------------------ Part 3: carrot selection (cpp: = src/NeoMpcPlanner.cpp) */
 /* createYawFromQuat (cpp:54-62) of a planar quaternion */

@@ -300,10 +300,33 @@ class TransformException(Exception):
     pass
 
 
+class _Vec3:
+    def __init__(self, x=0.0, y=0.0, z=0.0):
+        self.x, self.y, self.z = x, y, z
+
+
+class _Transform:
+    def __init__(self, x, y, q):
+        self.translation = _Vec3(x, y, 0.0)
+        self.rotation = Quaternion()
+        self.rotation.x, self.rotation.y, self.rotation.z, self.rotation.w = q
+
+
+class TransformStamped:
+    def __init__(self, x, y, q):
+        self.header, self.transform = Header(), _Transform(x, y, q)
+
+
 class Buffer:
+    #: (x, y, (qx, qy, qz, qw)) = the map -> base_link transform `lookup_transform` answers with
+    #: (py:275-278).  None: no tf -- publishLocalPlan returns early (py:279-282).
+    pending = None
+
     def lookup_transform(self, *a, **k):
-        # makes publishLocalPlan return early (py:279-282): visualisation only
-        raise TransformException("no tf in the oracle harness")
+        if Buffer.pending is None:
+            raise TransformException("no tf in the oracle harness")
+        x, y, q = Buffer.pending
+        return TransformStamped(float(x), float(y), tuple(float(v) for v in q))
 
 
 class TransformListener:
