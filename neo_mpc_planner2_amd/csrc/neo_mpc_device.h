@@ -62,7 +62,7 @@ struct LdsLayout {
   int32_t prob, state, tol, term, u, gs, gt, gr, d, u_prev, gt_prev, u_new, S, Y, rho;
   int32_t cs, sn, dxs, dys, rx, ry, rt, nx, ny, mode;  // per-step scratch
   int32_t hess;        // Newton: (3N)^2 Hessian, only when 3N <= 24
-  int32_t ric;         // Riccati: per-stage block curvature (6 N) then gains (12 N), riccati.h
+  int32_t ric;         // Riccati: per-stage block curvature (6 N), gains (12 N), wall penalties (3 N), riccati.h
   int32_t tile;        // byte tile starts here (double index)
   int32_t total_bytes;
   int32_t tile_w;      // row stride of the tile in bytes (power of two), 0: no tile
@@ -103,7 +103,7 @@ constexpr LdsLayout make_lds_layout(int n, int mem, bool riccati) {
   l.ny = off; off += n;
   l.mode = off; off += 2 * n;  // int[4n]: mode, omega-frozen, near-kink, near-kink at the previous iterate
   l.hess = off; off += (nv <= 24 && !riccati) ? nv * nv : 0;
-  l.ric = off; off += riccati ? 18 * n : 0;
+  l.ric = off; off += riccati ? 21 * n : 0;
   off = (off + 1) & ~1;        // 16-byte align the tile
   l.tile = off;
   l.total_bytes = off * 8;

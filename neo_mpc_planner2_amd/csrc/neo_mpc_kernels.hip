@@ -325,6 +325,10 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
           ARX[lane] = p.dt * (-SX * sn + SY * cs);
           ARY[lane] = p.dt * (-SX * cs - SY * sn);
           ART[lane] = -(SX * ddx + SY * ddy);
+          double wxx, wxy, wyy;
+          edge_stickiness(a, c, L, x, y, wxx, wxy, wyy);
+          double* wl = RC + (kRicCurv + kRicGain) * n + kRicWall * lane;
+          wl[0] = wxx; wl[1] = wxy; wl[2] = wyy;
         }
       }
       WAVE_SYNC();

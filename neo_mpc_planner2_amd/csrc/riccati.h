@@ -25,13 +25,15 @@ namespace {
 
 constexpr int kRicCurv = 6;    // doubles per stage: block curvature R_i (symmetric 3x3: 00 01 02 11 12 22)
 constexpr int kRicGain = 12;   // doubles per stage: feedback K_i (3x3, row-major) and feed-forward k_i
+constexpr int kRicWall = 3;    // doubles per stage: wall-sliding penalty on the stage position (xx xy yy), costmap.h
 
 // non-positive pivots are replaced (the exact Hessian is indefinite away from the minimiser): the
 // factorisation is then that of a positive definite matrix and the stage step a descent direction
 __device__ __forceinline__ double ric_pivot(double p, double delta) { return p > delta ? p : fmax(fabs(p), delta); }
 
 // Backward + forward sweep.  Inputs per stage i (LDS, doubles): cs/sn/px/py = rollout trigonometry and
-// position increments, ax/ay/kap = costate-weighted second-order terms of the step, curv = R_i,
+// position increments, ax/ay/kap = costate-weighted second-order terms of the step, curv = R_i, wall =
+// the wall-sliding penalty on the stage position,
 // gt = total gradient (0 on blocks next to the kink), gs = smooth gradient, u, and the tangent-cone
 // description (mode, wfroz, near | nx, ny).  Output: d (3N) and, per block, tokink (AMODE slot 3): the
 // stage model's minimiser is the kink u_i = v_cur itself, d_i = v_cur - u_i.
@@ -51,6 +53,7 @@ __device__ __forceinline__ void riccati_direction(const SolveArgs& a, const Ctx&
   const double* ANY = L + a.lds.ny;
   const double* CURV = L + a.lds.ric;
   double* GAIN = L + a.lds.ric + kRicCurv * n;
+  const double* WALL = GAIN + kRicGain * n;
   int* AMODE = reinterpret_cast<int*>(L + a.lds.mode);
   const double* u = L + a.lds.u;
   const double* gs = L + a.lds.gs;
@@ -63,7 +66,8 @@ __device__ __forceinline__ void riccati_direction(const SolveArgs& a, const Ctx&
   for (int i = n - 1; i >= 0; --i) {
     const double cs = ACS[i], sn = ASN[i], px = APX[i], py = APY[i];
     // S = W_i + V; M = A^T S A with A = [[1 0 -py] [0 1 px] [0 0 1]]
-    const double S00 = V00 + w2, S01 = V01, S02 = V02, S11 = V11 + w2, S12 = V12;
+    const double* wl = WALL + kRicWall * i;
+    const double S00 = V00 + w2 + wl[0], S01 = V01 + wl[1], S02 = V02, S11 = V11 + w2 + wl[2], S12 = V12;
     const double S22 = V22 + wo2 + (i == n - 1 ? 2.0 * p.wterm_o : 0.0);
     const double M02 = fma(-py, S00, fma(px, S01, S02));
     const double M12 = fma(-py, S01, fma(px, S11, S12));

@@ -580,12 +580,20 @@ static void orc_sym3_solve(double L[3][3], const double* b, double* x) {
   }
 }
 
+#define ORC_STICKY 100.0     /* penalty on motion across a rising cost step, in units of the tracking curvature */
+#define ORC_STICKY_DIST 0.02 /* ... for stage positions closer than this to the cell edge (fraction of a cell) */
+static double orc_term_at(const orc_ctx* c, int64_t mx, int64_t my) {
+  int raw = 254;
+  if (mx >= 0 && my >= 0 && mx < c->map->size_x && my < c->map->size_y)
+    raw = c->map->cells[my * (int64_t)c->map->size_x + mx];
+  return c->term[raw];
+}
 static int orc_kink_predict = 1; /* (the debug hook switches it off to compare with the dense direction) */
 static void orc_riccati_direction(const orc_ctx* c, const double* u, const double* gs, const double* gt, orc_active* a,
                                   double* d) {
   const int n = c->n;
   const double dt = c->dt;
-  double cs[ORC_MAXN], sn[ORC_MAXN], px[ORC_MAXN], py[ORC_MAXN], SX[ORC_MAXN], SY[ORC_MAXN];
+  double cs[ORC_MAXN], sn[ORC_MAXN], px[ORC_MAXN], py[ORC_MAXN], SX[ORC_MAXN], SY[ORC_MAXN], xs_[ORC_MAXN], ys_[ORC_MAXN];
   { /* nominal rollout and position costates */
     double x = 0.0, y = 0.0, th = 0.0, rx[ORC_MAXN], ry[ORC_MAXN];
     for (int i = 0; i < n; ++i) {
@@ -594,6 +602,7 @@ static void orc_riccati_direction(const orc_ctx* c, const double* u, const doubl
       px[i] = (u[3 * i] * cs[i] - u[3 * i + 1] * sn[i]) * dt;
       py[i] = (u[3 * i] * sn[i] + u[3 * i + 1] * cs[i]) * dt;
       x += px[i]; y += py[i];
+      xs_[i] = x; ys_[i] = y;
       rx[i] = -2.0 * c->wt_n * (c->cx - x);
       ry[i] = -2.0 * c->wt_n * (c->cy - y);
     }
@@ -608,6 +617,27 @@ static void orc_riccati_direction(const orc_ctx* c, const double* u, const doubl
     for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) S[r][q] = V[r][q];
     S[0][0] += 2.0 * c->wt_n; S[1][1] += 2.0 * c->wt_n;
     S[2][2] += 2.0 * c->wo_n + (i == n - 1 ? 2.0 * c->wterm_o : 0.0);
+    { /* wall sliding: a stage whose position sits within ORC_STICKY_DIST cells of a cell edge behind which
+       * the costmap term is higher gets motion along that edge's normal penalised (ORC_STICKY x the tracking
+       * curvature) -- the Newton direction then slides along the cost step instead of running into it at
+       * every step length (searches used to die creeping towards such an edge) */
+      const double X = c->X0 + (c->c0 * xs_[i] - c->s0 * ys_[i]), Y = c->Y0 + (c->s0 * xs_[i] + c->c0 * ys_[i]);
+      const orc_map* m = c->map;
+      int64_t mx, my;
+      orc_world_to_map(m, X, Y, &mx, &my);
+      const double fx = (X - m->origin_x) / m->resolution - (double)mx, fy = (Y - m->origin_y) / m->resolution - (double)my;
+      const double here = orc_term_at(c, mx, my);
+      const int64_t nbx[4] = {mx - 1, mx + 1, mx, mx}, nby[4] = {my, my, my - 1, my + 1};
+      const double dist[4] = {fx, 1.0 - fx, fy, 1.0 - fy};
+      for (int k = 0; k < 4; ++k) {
+        if (dist[k] < ORC_STICKY_DIST && orc_term_at(c, nbx[k], nby[k]) > here) {
+          /* edge normal (a world axis) in the rollout's frame */
+          const double nlx = k < 2 ? c->c0 : c->s0, nly = k < 2 ? -c->s0 : c->c0;
+          const double rho = ORC_STICKY * 2.0 * c->wt_n;
+          S[0][0] += rho * nlx * nlx; S[0][1] += rho * nlx * nly; S[1][0] += rho * nlx * nly; S[1][1] += rho * nly * nly;
+        }
+      }
+    }
     const double A[3][3] = {{1, 0, -py[i]}, {0, 1, px[i]}, {0, 0, 1}};
     const double B[3][3] = {{dt * cs[i], -dt * sn[i], -py[i] * dt}, {dt * sn[i], dt * cs[i], px[i] * dt}, {0, 0, dt}};
     double SA[3][3], SB[3][3], Qzz[3][3], Quz[3][3], Quu[3][3], Qz[3], Qu[3];
