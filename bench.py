@@ -6,7 +6,7 @@ low-pass + collision check + acceleration clamp + warm-start shift) over one bat
 synthetic instances that is already resident in HBM.  Workload = BASELINE config 2:
 4 096 independent instances per GPU, control_steps=3, 500x500 costmap, README params.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1 without WORLD_SIZE: spawns the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Multi-GPU: weak scaling, instances shard embarrassingly (one process per GPU, each
@@ -62,6 +62,24 @@ def cpu_baseline(params, cmap, probs, seconds=15.0):
     return done / dt, done, dt
 
 
+def pcie_inclusive(solver, probs, st, warm, n, seconds=3.0):
+    """SURVEY 8d's metric with the transfers inside: the host-buffer entry point neo_mpc_solve_batch (H2D of the
+    requests / state / warm start, K1, D2H of commands / state / warm start / solution per call) on the SAME
+    instances, timed on the host clock around the synchronous call.  Reported beside `value`, never as it."""
+    count = len(probs)
+    reps, t_all = 0, 0.0
+    solver.solve(probs, st.copy(), warm.copy())            # staging buffers allocated
+    while t_all < seconds and reps < 200:
+        s_i, w_i = st.copy(), warm.copy()
+        t0 = time.perf_counter()
+        solver.solve(probs, s_i, w_i)
+        t_all += time.perf_counter() - t0
+        reps += 1
+    return {"value": count * reps / t_all, "unit": "solves/s", "ms_per_call": 1e3 * t_all / reps, "calls": reps,
+            "bytes_in_per_call": count * (256 + 128 + 24 * n), "bytes_out_per_call": count * (48 + 128 + 48 * n),
+            "what": "neo_mpc_solve_batch on host buffers (pageable NumPy arrays), same instances, cold start"}
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -81,14 +99,48 @@ def cpu_mirror_rate(params, cmap, probs, st, warm):
     return len(probs) / (time.perf_counter() - t0)
 
 
+def source_sha():
+    """sha256 over the device sources K1 is built from: a PMC figure in profiles/hbm_traffic.json is only
+    reported while the kernel it was measured on is the kernel that runs."""
+    import hashlib
+    d = os.path.join(ROOT, "neo_mpc_planner2_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it: re-exec under torch.distributed.run, one rank per
+    GPU of this node (RCCL over xGMI).  Fails loudly when the node has fewer devices."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible" % (n, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="C2", choices=["C2", "C3", "C5"])
+    ap.add_argument("--workload", default="C2", choices=["C2", "C3", "C4", "C5"],
+                    help="BASELINE config: C2 (default, the metric's), C3, C5; C4 = its per-GPU shard "
+                         "(262 144 instances of the C2 problem per GPU; with --gpus 8 the full 2 097 152)")
     ap.add_argument("--batch", type=int, default=None, help="instances per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) leg")
     ap.add_argument("--max-iterations", type=int, default=None, help="study knob: cap the solver iterations")
     ap.add_argument("--control-steps", type=int, default=None, help="study knob: override the config's control_steps")
     ap.add_argument("--streams", type=int, default=1,
@@ -103,11 +155,15 @@ def main():
     from neo_mpc_planner2_amd.solver import BatchSolver, DeviceBatch
     from neo_mpc_planner2_amd.sharding import gather_commands
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)      # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("rank %d: HIP device %d is not visible (%d devices)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     # NEO_MPC_BENCH_FORCE_DIST=1 exercises the RCCL path with a single rank (used to smoke-test the
@@ -121,6 +177,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device(dev))
 
     cfg = dict(synthetic.CONFIGS[args.workload])
+    if args.workload == "C4":
+        cfg["batch"] //= 8          # the per-GPU shard of BASELINE config 4 (2 097 152 over 8 GPUs)
     if args.batch:
         cfg["batch"] = args.batch
     if args.control_steps:
@@ -156,7 +214,9 @@ def main():
     comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
     pending = []
 
-    def exchange(i, b, done):
+    gather_evs = []
+
+    def exchange(i, b, done, timed=False):
         # The collective is issued from a side stream that waits for `done` (the event recorded after
         # this tick's K1), so the solve stream itself carries nothing but K1 and its two timing events:
         # every extra event record between two launches costs ~4 us of barrier-packet latency.  No
@@ -165,7 +225,14 @@ def main():
         # for once, before the timed region closes.
         comm_stream.wait_event(done)
         with torch.cuda.stream(comm_stream):
+            if timed:   # (events on the side stream: they put nothing between two K1 launches)
+                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                g0.record(comm_stream)
             _, work = gather_commands(b.vel, gathered[i % ring], async_op=True)   # packed by K1, no copy
+            if timed:
+                work.wait()
+                g1.record(comm_stream)
+                gather_evs.append((g0, g1))
         pending.append(work)
 
     def drain():
@@ -202,7 +269,7 @@ def main():
         st_i = None if args.streams <= 1 or i % args.streams == 0 else extra_streams[i % args.streams - 1].cuda_stream
         solver.solve_device(base.problems, b.states, b.warm, b.commands, velocities=b.vel, events=evs[i], stream=st_i)
         if use_dist:
-            exchange(i, b, evs[i][1])
+            exchange(i, b, evs[i][1], timed=True)
     drain()
     torch.cuda.synchronize()
     if use_dist:
@@ -222,16 +289,26 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         algo_bytes = ALGO_BYTES.get(n, (17 + 3 * n) * 4 + (3 + 3 * n + 1) * 4 + 729)   # BASELINE.md's per-solve figure
         achieved = algo_bytes * cfg["batch"] / (k_ms * 1e-3) / 1e9
+        # HBM bytes / VALU instructions per launch from the committed PMC passes (profiles/hbm_traffic.json):
+        # reported only while the device sources are the ones the counters were collected on (source_sha)
+        # and the batch is the config's; null + the reason otherwise
         traffic = valu = None
+        traffic_note = "no PMC entry for this workload in profiles/hbm_traffic.json"
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
                 prof = json.load(open(tpath))
-                if cfg["batch"] == synthetic.CONFIGS[args.workload]["batch"]:   # the PMC passes ran at the config's batch
-                    traffic = prof.get(args.workload)
-                    valu = prof.get(args.workload + "_valu_insts")
-            except Exception:
-                traffic = valu = None
+                entry = prof.get(args.workload)
+                if isinstance(entry, dict):
+                    if entry.get("source_sha") != source_sha():
+                        traffic_note = "stale: PMC passes ran on source_sha %s, this build is %s" % (
+                            entry.get("source_sha"), source_sha())
+                    elif entry.get("batch") != cfg["batch"]:
+                        traffic_note = "PMC passes ran at batch %s" % entry.get("batch")
+                    else:
+                        traffic, valu, traffic_note = entry.get("hbm_bytes"), entry.get("valu_insts"), entry.get("note")
+            except Exception as e:
+                traffic_note = "profiles/hbm_traffic.json unreadable: %s" % e
         out = {
             "metric": "MPC solves/sec (control_steps=%d, %dx%d costmap)" % (n, cfg["map_size"], cfg["map_size"]),
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -243,7 +320,7 @@ def main():
                        "parallelism": "instances sharded x%d, 1 RCCL all-gather of (vx,vy,w)/step" % world
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": "k_solve", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_solve": algo_bytes},
             # what actually bounds K1: VALU issue.  SQ_INSTS_VALU of the committed PMC
@@ -253,8 +330,19 @@ def main():
                 "frac": valu * 4 / (1024 * k_ms * 1e-3 * SIMD_CLOCK_GHZ * 1e9)},
             **({"study_streams": args.streams} if args.streams > 1 else {}),
             "solver": {"mean_iterations": float(cmds["iterations"].mean()),
-                       "converged_frac": float((cmds["status"] == 0).mean())},
+                       "max_iterations_seen": int(cmds["iterations"].max()),
+                       "converged_frac": float((cmds["status"] == 0).mean()),
+                       # status 1 = iteration cap reached (the reference's x.success False, py:399-400)
+                       "status_max_iter": int((cmds["status"] == 1).sum())},
         }
+        if use_dist:
+            out["rccl"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                           "gather_ms": float(np.mean([a.elapsed_time(b) for a, b in gather_evs])) if gather_evs else None,
+                           "gather_bytes_per_rank": cfg["batch"] * 24,
+                           "what": "one all-gather of (vx, vy, w) per step on a side stream, overlapped with the next "
+                                   "step's solve; gather_ms = its own duration (events on the side stream)"}
+        if world == 1 and not args.no_pcie:
+            out["pcie_inclusive"] = pcie_inclusive(solver, probs, st, warm, n)
         if world == 1 and not args.no_cpu_baseline:
             rate, cnt, secs = cpu_baseline(params, cmap, probs)
             out["cpu_baseline"] = {"value": rate, "unit": "solves/s", "cores": 1, "kind": "port",

@@ -268,6 +268,11 @@ int neo_mpc_postprocess_batch(neo_mpc_handle* handle, const neo_mpc_batch* batch
 int neo_mpc_gradient_batch(neo_mpc_handle* handle, const neo_mpc_problem* problems, const double* u,
                            double* grad_out, size_t count);
 
+/* Test hook: the search direction of lanes 32-63 (Newton / L-BFGS) in solver iteration `iteration` (0-based) of a
+ * solve started from u (instances that stop earlier leave their row untouched).  Host pointers. */
+int neo_mpc_direction_batch(neo_mpc_handle* handle, const neo_mpc_problem* problems, const double* u,
+                            double* dir_out, size_t count, int iteration);
+
 /* `MpcOptimizationServer.objective` (py:204-269) evaluated on the device for
  * u[count][3*control_steps] (not projected); `footprint_cost` from problems[i].  Host pointers. */
 int neo_mpc_objective_batch(neo_mpc_handle* handle, const neo_mpc_problem* problems,

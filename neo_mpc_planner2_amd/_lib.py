@@ -20,7 +20,8 @@ EXPORTS = (
     "neo_mpc_destroy", "neo_mpc_set_params", "neo_mpc_get_params", "neo_mpc_set_costmap",
     "neo_mpc_set_costmap_device", "neo_mpc_set_costmap_pool", "neo_mpc_set_costmap_pool_device", "neo_mpc_solve_batch", "neo_mpc_solve_batch_device",
     "neo_mpc_solve_batch_device_timed",
-    "neo_mpc_postprocess_batch", "neo_mpc_objective_batch", "neo_mpc_gradient_batch", "neo_mpc_kernel_info",
+    "neo_mpc_postprocess_batch", "neo_mpc_objective_batch", "neo_mpc_gradient_batch", "neo_mpc_direction_batch",
+    "neo_mpc_kernel_info",
     "neo_mpc_select_carrots", "neo_mpc_select_carrots_device",
 )
 
@@ -74,6 +75,7 @@ def load():
     lib.neo_mpc_postprocess_batch.argtypes = [C.c_void_p, P(abi.NeoMpcBatch), C.c_void_p]
     lib.neo_mpc_objective_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     lib.neo_mpc_gradient_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.neo_mpc_direction_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     lib.neo_mpc_select_carrots.argtypes = [C.c_void_p, P(abi.NeoMpcLookaheadParams), P(abi.NeoMpcPlanBatch)]
     lib.neo_mpc_select_carrots_device.argtypes = [C.c_void_p, P(abi.NeoMpcLookaheadParams),
                                                   P(abi.NeoMpcPlanBatch), C.c_void_p]

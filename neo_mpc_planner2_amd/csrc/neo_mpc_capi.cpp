@@ -589,8 +589,19 @@ int neo_mpc_objective_batch(neo_mpc_handle* h, const neo_mpc_problem* problems, 
   return NEO_MPC_OK;
 }
 
+static int hook_batch(neo_mpc_handle* h, const neo_mpc_problem* problems, const double* u, double* out, size_t count,
+                      int max_it);
 int neo_mpc_gradient_batch(neo_mpc_handle* h, const neo_mpc_problem* problems, const double* u, double* grad_out,
                            size_t count) {
+  return hook_batch(h, problems, u, grad_out, count, kDumpGradient);
+}
+int neo_mpc_direction_batch(neo_mpc_handle* h, const neo_mpc_problem* problems, const double* u, double* dir_out,
+                            size_t count, int iteration) {
+  if (iteration < 0 || iteration > 1000) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "iteration %d", iteration);
+  return hook_batch(h, problems, u, dir_out, count, kDumpGradient + 1 + iteration);
+}
+static int hook_batch(neo_mpc_handle* h, const neo_mpc_problem* problems, const double* u, double* grad_out, size_t count,
+                      int max_it) {
   if (!h || !problems || !u || !grad_out) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "null argument");
   if (!h->has_map) return fail(NEO_MPC_ERR_NO_COSTMAP, "neo_mpc_set_costmap has not been called");
   if (count == 0) return NEO_MPC_OK;
@@ -625,7 +636,8 @@ int neo_mpc_gradient_batch(neo_mpc_handle* h, const neo_mpc_problem* problems, c
   d.solution = (double*)h->solution.ptr;
   SolveArgs a;
   if ((rc = fill_args(h, &d, a))) return rc;
-  a.p.max_it = kDumpGradient;
+  a.p.max_it = max_it;
+  HIP_TRY(hipMemset(h->solution.ptr, 0xFF, count * nv * 8));   // NaN rows for instances that stop before the dump
   if ((rc = map_acquire(h, nullptr))) return rc;
   launch_solve(a, nullptr);
   HIP_TRY(hipGetLastError());

@@ -62,7 +62,7 @@ struct LdsLayout {
   int32_t prob, state, tol, term, u, gs, gt, gr, d, u_prev, gt_prev, u_new, S, Y, rho;
   int32_t cs, sn, dxs, dys, rx, ry, rt, nx, ny, mode;  // per-step scratch
   int32_t hess;        // Newton: (3N)^2 Hessian, only when 3N <= 24
-  int32_t ric;         // Riccati: per-stage block curvature (6 N), gains (12 N), wall penalties (3 N), riccati.h
+  int32_t ric;         // Riccati: float32 stage records (16 N floats) then gains (12 N floats), riccati.h
   int32_t tile;        // byte tile starts here (double index)
   int32_t total_bytes;
   int32_t tile_w;      // row stride of the tile in bytes (power of two), 0: no tile
@@ -86,24 +86,39 @@ constexpr LdsLayout make_lds_layout(int n, int mem, bool riccati) {
   l.gt = off; off += nv;
   l.gr = off; off += nv;
   l.d = off; off += nv;
-  l.u_prev = off; off += nv;
-  l.gt_prev = off; off += nv;
-  l.u_new = off; off += nv;
-  l.S = off; off += mem * nv;
-  l.Y = off; off += mem * nv;
-  l.rho = off; off += NEO_MPC_MAX_LBFGS_MEMORY;
-  l.cs = off; off += n;
-  l.sn = off; off += n;
-  l.dxs = off; off += n;
-  l.dys = off; off += n;
-  l.rx = off; off += n;
-  l.ry = off; off += n;
-  l.rt = off; off += n;
-  l.nx = off; off += n;
-  l.ny = off; off += n;
-  l.mode = off; off += 2 * n;  // int[4n]: mode, omega-frozen, near-kink, near-kink at the previous iterate
-  l.hess = off; off += (nv <= 24 && !riccati) ? nv * nv : 0;
-  l.ric = off; off += riccati ? 21 * n : 0;
+  if (riccati) {
+    // the Riccati kernel keeps no previous iterate / gradient and no quasi-Newton pairs; the winner is
+    // staged where the reduced gradient lived (disjoint lifetimes inside an iteration); of the per-step
+    // float64 scratch it uses nx, ny and rt (disc curvature) only; its stage records and gains are float32
+    l.u_new = l.gr;
+    l.u_prev = l.u; l.gt_prev = l.u; l.S = off; l.Y = off; l.rho = off;
+    l.cs = off; l.sn = off; l.dxs = off; l.dys = off; l.rx = off; l.ry = off;
+    l.rt = off; off += n;
+    l.nx = off; off += n;
+    l.ny = off; off += n;
+    l.mode = off; off += 2 * n;
+    l.hess = off;
+    l.ric = off; off += 14 * n;             // (16 + 12) floats per stage, riccati.h
+  } else {
+    l.u_prev = off; off += nv;
+    l.gt_prev = off; off += nv;
+    l.u_new = off; off += nv;
+    l.S = off; off += mem * nv;
+    l.Y = off; off += mem * nv;
+    l.rho = off; off += NEO_MPC_MAX_LBFGS_MEMORY;
+    l.cs = off; off += n;
+    l.sn = off; off += n;
+    l.dxs = off; off += n;
+    l.dys = off; off += n;
+    l.rx = off; off += n;
+    l.ry = off; off += n;
+    l.rt = off; off += n;
+    l.nx = off; off += n;
+    l.ny = off; off += n;
+    l.mode = off; off += 2 * n;  // int[4n]: mode, omega-frozen, near-kink, near-kink at the previous iterate
+    l.hess = off; off += (nv <= 24) ? nv * nv : 0;
+    l.ric = off;
+  }
   off = (off + 1) & ~1;        // 16-byte align the tile
   l.tile = off;
   l.total_bytes = off * 8;

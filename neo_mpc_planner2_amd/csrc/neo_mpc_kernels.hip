@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   constexpr int kNewtonRecord = 13;
   static_assert(2 * 7 >= kNewtonRecord, "Newton records do not fit the step arrays");
   float* NB = reinterpret_cast<float*>(L + a.lds.cs);
-  double* RC = L + a.lds.ric;   // Riccati: block curvature records (then the gains, riccati.h)
+  float* RS = reinterpret_cast<float*>(L + a.lds.ric);   // Riccati: float32 stage records (then the gains, riccati.h)
 
   // x0 clipped to the feasible set (SciPy clips x0 to the bounds, _slsqp_py.py:268)
   for (int i = lane; i < n; i += kLanes) project_block<kTame>(p, u[3 * i], u[3 * i + 1], u[3 * i + 2]);
@@ -318,17 +318,13 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         gs[3 * lane + 1] = p.dt * (-sn * SX + cs * SY);
         gs[3 * lane + 2] = p.dt * ST;
         if (kRiccati) {
-          // stage record of the Riccati sweep: trigonometry, position increments and the second-order
-          // terms of this step weighted by the position costates (SX, SY) of its result:
-          // d2(lambda . p)/d(vx, vy, xi)^2 = [[0 0 ax] [0 0 ay] [ax ay kappa]], xi = theta_{i-1} + w dt
-          ACS[lane] = cs; ASN[lane] = sn; ADX[lane] = ddx; ADY[lane] = ddy;
-          ARX[lane] = p.dt * (-SX * sn + SY * cs);
-          ARY[lane] = p.dt * (-SX * cs - SY * sn);
-          ART[lane] = -(SX * ddx + SY * ddy);
+          // stage record of the Riccati sweep (float32): trigonometry, position increments and the
+          // wall-sliding penalty on the stage position (costmap.h)
+          float* rs = RS + kRicStage * lane;
+          rs[RS_CS] = (float)cs; rs[RS_SN] = (float)sn; rs[RS_PX] = (float)ddx; rs[RS_PY] = (float)ddy;
           double wxx, wxy, wyy;
           edge_stickiness(a, c, L, x, y, wxx, wxy, wyy);
-          double* wl = RC + (kRicCurv + kRicGain) * n + kRicWall * lane;
-          wl[0] = wxx; wl[1] = wxy; wl[2] = wyy;
+          rs[RS_WXX] = (float)wxx; rs[RS_WXY] = (float)wxy; rs[RS_WYY] = (float)wyy;
         }
       }
       WAVE_SYNC();
@@ -394,10 +390,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
 #pragma unroll
           for (int k = 0; k < kNewtonRecord; ++k) NB[kNewtonRecord * i + k] = 0.0f;  // P = 0: row/column of I
         }
-        if (kRiccati) {
-#pragma unroll
-          for (int k = 0; k < kRicCurv; ++k) RC[kRicCurv * i + k] = 0.0;
-        }
+        if (kRiccati) ART[i] = 0.0;
         continue;
       }
       gt[3 * i] = t0; gt[3 * i + 1] = t1; gt[3 * i + 2] = t2;
@@ -463,16 +456,8 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         nb[7] = c01; nb[8] = c11; nb[9] = c12;
         nb[10] = c02; nb[11] = c12; nb[12] = c22;
       }
-      if (kRiccati) {
-        // block curvature R_i of the stage model: the control norm's Hessian (w/|e|)(I - e e^T/|e|^2)
-        // plus lambda/r t t^T of a binding disc, t = (-ny, nx)
-        double* rc = RC + kRicCurv * i;
-        const double sN = p.wc_n * ine, h0 = e0 * ine, h1 = e1 * ine, h2 = e2 * ine;
-        const double k2 = (mode == 1 && mslot == 2) ? mlam * rcp_fast(p.r) : 0.0;
-        const double tx = -mny, ty = mnx;
-        rc[0] = sN * (1.0 - h0 * h0) + k2 * tx * tx; rc[1] = -sN * h0 * h1 + k2 * tx * ty; rc[2] = -sN * h0 * h2;
-        rc[3] = sN * (1.0 - h1 * h1) + k2 * ty * ty; rc[4] = -sN * h1 * h2; rc[5] = sN * (1.0 - h2 * h2);
-      }
+      // Riccati: curvature lambda/r of a binding disc (the rest of the block's record is made by riccati_prepare)
+      if (kRiccati) ART[i] = (mode == 1 && mslot == 2) ? mlam * rcp_fast(p.r) : 0.0;
     }
     WAVE_SYNC();
     NEO_PHASE(2);
@@ -490,7 +475,14 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       if (kRiccati) for (int i = lane; i < n; i += kLanes) AMODE[4 * i + 3] = 0;
       WAVE_SYNC();
     } else if (kRiccati) {
-      riccati_direction<kTame>(a, c, L, n, lane, v_feasible);
+      riccati_prepare(a, c, L, n, lane);
+      WAVE_SYNC();
+#ifdef NEO_MPC_RICCATI_F64   // (study build: the same recursion in float64 on the float32 records)
+      riccati_sweep<double>(a, L, n, lane, v_feasible);
+#else
+      riccati_sweep<float>(a, L, n, lane, v_feasible);
+#endif
+      riccati_finish(a, c, L, n, lane);
     } else if (kNewton) {
       // From here on the Newton system lives in float32: it only yields a search direction (the arc
       // search and the float64 objective decide), and single precision halves registers, readlanes
@@ -690,7 +682,12 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       float dm = 0.0f;
       int anynear = 0;
       if (kRiccati) {
-        for (int k = lane; k < nv; k += kLanes) { dm = fmaxf(dm, (float)fabs(d[k])); anynear |= AMODE[4 * (k / 3) + 2]; }
+        // (a non-finite direction must not read as "no step left": fmaxf drops NaN)
+        for (int k = lane; k < nv; k += kLanes) {
+          const float v = (float)fabs(d[k]);
+          dm = (v == v) ? fmaxf(dm, v) : INFINITY;
+          anynear |= AMODE[4 * (k / 3) + 2];
+        }
       } else if (lane < nvr) { dm = fabsf(newton_sol); anynear = AMODE[4 * (lane / 3) + 2]; }   // (d[lane], still in a register)
       dm = wave_max_f(dm);
       const bool near_any = __ballot(anynear != 0) != 0ull;
@@ -700,6 +697,11 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       if ((double)dm < TOL[T_FINAL] && !near_any) final_step = true;
     }
     NEO_PHASE(4);
+    if (p.max_it > kDumpGradient && it == p.max_it - kDumpGradient - 1) {
+      // test hook (neo_mpc_direction_batch): the search direction of lanes 32-63 in this iteration
+      for (int k = lane; k < nv; k += kLanes) a.solution[(size_t)b * nv + k] = d[k];
+      return;
+    }
     // ---- 64 candidates, one rollout per lane; lowest objective wins
     const double pstep = alpha * my_scale;
     const double step = lane < 32 ? pstep : my_scale;

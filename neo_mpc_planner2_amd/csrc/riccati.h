@@ -9,8 +9,25 @@
 // (W_i: Hessian of the stage cost, lambda_i = (SX_i, SY_i): position costates of the adjoint sweep,
 // J_i: sensitivity of z_i) and H d = -g is a linear-quadratic problem: one backward sweep with 3x3
 // value-function Hessians and one forward sweep, O(control_steps), no (3N)^2 matrix and no finite
-// differences.  The sweep is wave-uniform: every lane runs it on the same LDS records (written one
-// stage per lane by the passes in front of it), so nothing crosses lanes inside the recursion.
+// differences.
+//
+// The sweep keeps the GAUSS-NEWTON part of H (the lambda_i . d2F_i terms are left out): every stage system is
+// then positive definite by construction, the value function stays positive semi-definite, and the
+// recursion is safe in float32.  With the second-order terms the stage systems turn indefinite far from the
+// minimiser, pivots get replaced and the forward sweep can blow up (seen at control_steps 64: |d| ~ 1e53)
+// -- for 1-3 % fewer iterations (measured on the CPU mirror, which carries both variants: 12.07 against
+// 12.21 iterations at control_steps 32, 7.01 / 7.06 at 8).
+//
+// Three passes:
+//   riccati_prepare  lane = stage: rotates everything the sweep needs into the stage's DISPLACEMENT
+//                    coordinates w = B0 du, B0 = dt diag(Rot(theta_i), 1) -- the linearised step is then
+//                    dz_i = A_i (dz_{i-1} + w_i), A_i = [[1 0 -py] [0 1 px] [0 0 1]], and the Gauss-Newton part
+//                    of Quu, Quz and Qzz is ONE matrix M = A^T S A (derivation in DESIGN.md).
+//   riccati_sweep    wave-uniform: every lane runs the recursion on the same LDS records, in float32 (it
+//                    only yields a search direction; the float64 objective decides); each stage is solved
+//                    in the coordinates of its face (0-3 free directions) instead of through 3x3 projector
+//                    products.
+//   riccati_finish   lane = stage: back to control coordinates, du = B0^-1 w.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -23,162 +40,253 @@
 namespace neo_mpc {
 namespace {
 
-constexpr int kRicCurv = 6;    // doubles per stage: block curvature R_i (symmetric 3x3: 00 01 02 11 12 22)
-constexpr int kRicGain = 12;   // doubles per stage: feedback K_i (3x3, row-major) and feed-forward k_i
-constexpr int kRicWall = 3;    // doubles per stage: wall-sliding penalty on the stage position (xx xy yy), costmap.h
+// float32 record of one stage (LDS): rollout step, costates, wall penalty, face, block curvature
+enum : int {
+  RS_CS = 0, RS_SN, RS_PX, RS_PY, RS_TX, RS_TY, RS_WXX, RS_WXY, RS_WYY,
+  RS_C00, RS_C01, RS_C02, RS_C11, RS_C12, RS_C22, RS_PAD, kRicStage   // = 16 floats
+};
+constexpr int kRicGain = 12;   // floats per stage: feedback K_i (3x3, row-major) and feed-forward k_i
 
 // non-positive pivots are replaced (the exact Hessian is indefinite away from the minimiser): the
 // factorisation is then that of a positive definite matrix and the stage step a descent direction
-__device__ __forceinline__ double ric_pivot(double p, double delta) { return p > delta ? p : fmax(fabs(p), delta); }
+__device__ __forceinline__ float ric_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double ric_rcp(double x) { return rcp_fast(x); }
+template <typename T> __device__ __forceinline__ T ric_max(T a, T b) { return a > b ? a : b; }
+template <typename T> __device__ __forceinline__ T ric_abs(T a) { return a < (T)0 ? -a : a; }
+__device__ __forceinline__ float ric_fma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ double ric_fma(double a, double b, double c) { return fma(a, b, c); }
+template <typename T> __device__ __forceinline__ T ric_pivot(T p, T delta) { return p > delta ? p : ric_max(ric_abs(p), delta); }
 
-// Backward + forward sweep.  Inputs per stage i (LDS, doubles): cs/sn/px/py = rollout trigonometry and
-// position increments, ax/ay/kap = costate-weighted second-order terms of the step, curv = R_i, wall =
-// the wall-sliding penalty on the stage position,
-// gt = total gradient (0 on blocks next to the kink), gs = smooth gradient, u, and the tangent-cone
-// description (mode, wfroz, near | nx, ny).  Output: d (3N) and, per block, tokink (AMODE slot 3): the
-// stage model's minimiser is the kink u_i = v_cur itself, d_i = v_cur - u_i.
-template <bool kTame>
-__device__ __forceinline__ void riccati_direction(const SolveArgs& a, const Ctx& c, double* L, int n, int lane,
-                                                  bool v_feasible) {
+// lane = stage.  In: gt / gr(unused here) / gs / u / tangent-cone description (mode, wfroz, near | nx, ny, k2 =
+// lambda/r of a binding disc) and the stage's cs, sn.  Out: gt <- total gradient in displacement
+// coordinates, gr <- smooth gradient in displacement coordinates, d <- the step onto the kink in
+// displacement coordinates, record: tangent, block curvature.
+__device__ __forceinline__ void riccati_prepare(const SolveArgs& a, const Ctx& c, double* L, int n, int lane) {
+  if (lane >= n) return;
   const DevParams& p = a.p;
-  const double dt = p.dt;
-  const double* ACS = L + a.lds.cs;
-  const double* ASN = L + a.lds.sn;
-  const double* APX = L + a.lds.dxs;
-  const double* APY = L + a.lds.dys;
-  const double* AAX = L + a.lds.rx;
-  const double* AAY = L + a.lds.ry;
-  const double* AKP = L + a.lds.rt;
-  const double* ANX = L + a.lds.nx;
-  const double* ANY = L + a.lds.ny;
-  const double* CURV = L + a.lds.ric;
-  double* GAIN = L + a.lds.ric + kRicCurv * n;
-  const double* WALL = GAIN + kRicGain * n;
+  float* rs = reinterpret_cast<float*>(L + a.lds.ric) + kRicStage * lane;
+  const int* am = reinterpret_cast<const int*>(L + a.lds.mode) + 4 * lane;
+  double* gt = L + a.lds.gt + 3 * lane;
+  double* gsr = L + a.lds.gr + 3 * lane;
+  const double* gs = L + a.lds.gs + 3 * lane;
+  const double* u = L + a.lds.u + 3 * lane;
+  double* d = L + a.lds.d + 3 * lane;
+  const double cs = rs[RS_CS], sn = rs[RS_SN];   // (float32 copies: a direction's worth of accuracy)
+  const double idt = rcp_fast(p.dt);
+  // gradients: g~ = B0^-T g = (Rot g_xy, g_w) / dt
+  const double t0 = gt[0], t1 = gt[1], t2 = gt[2];
+  gt[0] = (cs * t0 - sn * t1) * idt; gt[1] = (sn * t0 + cs * t1) * idt; gt[2] = t2 * idt;
+  const double s0 = gs[0], s1 = gs[1], s2 = gs[2];
+  gsr[0] = (cs * s0 - sn * s1) * idt; gsr[1] = (sn * s0 + cs * s1) * idt; gsr[2] = s2 * idt;
+  // the step onto the kink u_i = v_cur: w = B0 (v - u_i)
+  const double e0 = u[0] - c.v0, e1 = u[1] - c.v1, e2 = u[2] - c.v2;
+  d[0] = -(cs * e0 - sn * e1) * p.dt; d[1] = -(sn * e0 + cs * e1) * p.dt; d[2] = -e2 * p.dt;
+  // face: tangent of a sliding block, rotated
+  const double nx = L[a.lds.nx + lane], ny = L[a.lds.ny + lane];
+  const double tx = -ny, ty = nx;
+  const float rtx = (float)(cs * tx - sn * ty), rty = (float)(sn * tx + cs * ty);
+  rs[RS_TX] = rtx; rs[RS_TY] = rty;
+  // block curvature R~ = B0^-T R B0^-1: the control norm's Hessian (w/|e|)(I - h h^T), h = e/|e| rotated, plus
+  // lambda/r t t^T of a binding disc -- both divided by dt^2
+  float c00 = 0.0f, c01 = 0.0f, c02 = 0.0f, c11 = 0.0f, c12 = 0.0f, c22 = 0.0f;
+  if (!am[2]) {
+    const float f0 = (float)(cs * e0 - sn * e1), f1 = (float)(sn * e0 + cs * e1), f2 = (float)e2;
+    const float fn2 = f0 * f0 + f1 * f1 + f2 * f2;
+    const float ine = fn2 > 0.0f ? __builtin_amdgcn_rsqf(fn2) : 0.0f;
+    const float i2 = (float)(idt * idt);
+    const float sN = (float)p.wc_n * ine * i2, h0 = f0 * ine, h1 = f1 * ine, h2 = f2 * ine;
+    const float k2 = (float)L[a.lds.rt + lane] * i2;
+    c00 = sN * (1.0f - h0 * h0) + k2 * rtx * rtx; c01 = -sN * h0 * h1 + k2 * rtx * rty; c02 = -sN * h0 * h2;
+    c11 = sN * (1.0f - h1 * h1) + k2 * rty * rty; c12 = -sN * h1 * h2; c22 = sN * (1.0f - h2 * h2);
+  }
+  rs[RS_C00] = c00; rs[RS_C01] = c01; rs[RS_C02] = c02; rs[RS_C11] = c11; rs[RS_C12] = c12; rs[RS_C22] = c22;
+}
+
+// Backward + forward sweep in displacement coordinates, wave-uniform.  Output: w_i in d (float64 slots), and
+// per block tokink (AMODE slot 3): the stage model's minimiser is the kink itself.
+template <typename T>
+__device__ __forceinline__ void riccati_sweep(const SolveArgs& a, double* L, int n, int lane, bool v_feasible) {
+  const DevParams& p = a.p;
+  const float* RS = reinterpret_cast<const float*>(L + a.lds.ric);
+  float* GAIN = reinterpret_cast<float*>(L + a.lds.ric) + kRicStage * n;
   int* AMODE = reinterpret_cast<int*>(L + a.lds.mode);
-  const double* u = L + a.lds.u;
-  const double* gs = L + a.lds.gs;
+  const double* gsr = L + a.lds.gr;
   const double* gt = L + a.lds.gt;
   double* d = L + a.lds.d;
-  const double w2 = 2.0 * p.wt_n, wo2 = 2.0 * p.wo_n;
-  const double wc2 = p.wc_n * p.wc_n;
+  const T w2 = (T)(2.0 * p.wt_n), wo2 = (T)(2.0 * p.wo_n), wterm2 = (T)(2.0 * p.wterm_o);
+  // kink test |B0^T r| <= w_control/N  <=>  |r| <= w_control / (N dt)
+  const T wc2 = (T)((p.wc_n * p.wc_n) / (p.dt * p.dt));
 
-  double V00 = 0.0, V01 = 0.0, V02 = 0.0, V11 = 0.0, V12 = 0.0, V22 = 0.0, v0 = 0.0, v1 = 0.0, v2 = 0.0;
+  T V00 = (T)0.0, V01 = (T)0.0, V02 = (T)0.0, V11 = (T)0.0, V12 = (T)0.0, V22 = (T)0.0, v0 = (T)0.0, v1 = (T)0.0, v2 = (T)0.0;
   for (int i = n - 1; i >= 0; --i) {
-    const double cs = ACS[i], sn = ASN[i], px = APX[i], py = APY[i];
-    // S = W_i + V; M = A^T S A with A = [[1 0 -py] [0 1 px] [0 0 1]]
-    const double* wl = WALL + kRicWall * i;
-    const double S00 = V00 + w2 + wl[0], S01 = V01 + wl[1], S02 = V02, S11 = V11 + w2 + wl[2], S12 = V12;
-    const double S22 = V22 + wo2 + (i == n - 1 ? 2.0 * p.wterm_o : 0.0);
-    const double M02 = fma(-py, S00, fma(px, S01, S02));
-    const double M12 = fma(-py, S01, fma(px, S11, S12));
-    const double M22 = fma(-py, M02, fma(px, M12, fma(-py, S02, fma(px, S12, S22))));
-    // B = A B0, B0 = dt [[cs -sn 0] [sn cs 0] [0 0 1]]:  G = B0^T M (= Quz before the second-order terms)
-    const double dc = dt * cs, ds = dt * sn;
-    const double G00 = dc * S00 + ds * S01, G01 = dc * S01 + ds * S11, G02 = dc * M02 + ds * M12;
-    const double G10 = dc * S01 - ds * S00, G11 = dc * S11 - ds * S01, G12 = dc * M12 - ds * M02;
-    const double G20 = dt * M02, G21 = dt * M12, G22 = dt * M22;
-    // Quu = G B0 (symmetric) + second-order terms + block curvature
-    const double ax = AAX[i], ay = AAY[i], kap = AKP[i];
-    double Q00 = dc * G00 + ds * G01, Q01 = dc * G01 - ds * G00, Q02 = dt * G02 + dt * ax;
-    double Q11 = dc * G11 - ds * G10, Q12 = dt * G12 + dt * ay, Q22 = dt * G22 + dt * dt * kap;
-    // Quz = G + second-order terms (column theta); Qzz = M + kappa e_theta e_theta^T
-    const double Z02 = G02 + ax, Z12 = G12 + ay, Z22 = G22 + dt * kap;
-    const double Y22 = M22 + kap;
-    // linear terms: Qz = A^T v, Qu = gt_i + B0^T Qz
-    const double z0 = v0, z1 = v1, z2 = fma(-py, v0, fma(px, v1, v2));
-    const double b0 = dc * z0 + ds * z1, b1 = dc * z1 - ds * z0, b2 = dt * z2;
-    const double u0 = u[3 * i], u1 = u[3 * i + 1], u2 = u[3 * i + 2];
-    const int mode = AMODE[4 * i], wfroz = AMODE[4 * i + 1], near = AMODE[4 * i + 2];
-    double k0, k1, k2, K00, K01, K02, K10, K11, K12, K20, K21, K22;
+    const float* rs = RS + kRicStage * i;
+    const T px = rs[RS_PX], py = rs[RS_PY];
+    // S = W_i + wall_i + V;  M = A^T S A
+    const T S00 = V00 + w2 + rs[RS_WXX], S01 = V01 + rs[RS_WXY], S11 = V11 + w2 + rs[RS_WYY];
+    const T S22 = V22 + wo2 + (i == n - 1 ? wterm2 : (T)0.0);
+    const T M02 = ric_fma(-py, S00, ric_fma(px, S01, V02));
+    const T M12 = ric_fma(-py, S01, ric_fma(px, S11, V12));
+    const T M22 = ric_fma(-py, M02, ric_fma(px, M12, ric_fma(-py, V02, ric_fma(px, V12, S22))));
+    // Gauss-Newton: Quu_s = Quz = Qzz = M (see the header: the second-order terms of the step are left out)
+    const T Z02 = M02, Z12 = M12, Z22 = M22;
+    // linear terms: Qz = A^T v, Qu = g~ + Qz
+    const T z0 = v0, z1 = v1, z2 = ric_fma(-py, v0, ric_fma(px, v1, v2));
+    // (wave-uniform by construction: tell the compiler, so that the case analysis below is scalar branches)
+    const int mode = __builtin_amdgcn_readfirstlane(AMODE[4 * i]), wfroz = __builtin_amdgcn_readfirstlane(AMODE[4 * i + 1]),
+              near = __builtin_amdgcn_readfirstlane(AMODE[4 * i + 2]);
+    T k0 = (T)0.0, k1 = (T)0.0, k2 = (T)0.0, K00 = (T)0.0, K01 = (T)0.0, K02 = (T)0.0, K10 = (T)0.0, K11 = (T)0.0, K12 = (T)0.0,
+          K20 = (T)0.0, K21 = (T)0.0, K22 = (T)0.0;
     bool tokink = false;
     if (!near && v_feasible) {
-      // does the stage model put this block ON the kink?  0 in Qu_s + Quu_s k + w d|u_i + k - v| at
-      // k = v - u_i  <=>  |Qu_s + Quu_s (v - u_i)| <= w  (smooth parts only)
-      const double e0 = c.v0 - u0, e1 = c.v1 - u1, e2 = c.v2 - u2;
-      const double r0 = gs[3 * i] + b0 + Q00 * e0 + Q01 * e1 + Q02 * e2;
-      const double r1 = gs[3 * i + 1] + b1 + Q01 * e0 + Q11 * e1 + Q12 * e2;
-      const double r2 = gs[3 * i + 2] + b2 + Q02 * e0 + Q12 * e1 + Q22 * e2;
-      tokink = r0 * r0 + r1 * r1 + r2 * r2 <= wc2;
-    }
-    if (tokink) {   // fixed step onto the kink, no feedback: v = Qz + Quz^T k, V = Qzz
-      k0 = c.v0 - u0; k1 = c.v1 - u1; k2 = c.v2 - u2;
-      K00 = K01 = K02 = K10 = K11 = K12 = K20 = K21 = K22 = 0.0;
-      v0 = z0 + G00 * k0 + G10 * k1 + G20 * k2;
-      v1 = z1 + G01 * k0 + G11 * k1 + G21 * k2;
-      v2 = z2 + Z02 * k0 + Z12 * k1 + Z22 * k2;
-      V00 = S00; V01 = S01; V02 = M02; V11 = S11; V12 = M12; V22 = Y22;
-    } else {
-      const double* cv = CURV + kRicCurv * i;
-      Q00 += cv[0]; Q01 += cv[1]; Q02 += cv[2]; Q11 += cv[3]; Q12 += cv[4]; Q22 += cv[5];
-      // face projector P = [[p00 p01 0] [p01 p11 0] [0 0 pw]]
-      double p00, p01, p11;
-      if (near || mode == 2) { p00 = 0.0; p01 = 0.0; p11 = 0.0; }
-      else if (mode == 1) { const double nx = ANX[i], ny = ANY[i]; p00 = 1.0 - nx * nx; p01 = -nx * ny; p11 = 1.0 - ny * ny; }
-      else { p00 = 1.0; p01 = 0.0; p11 = 1.0; }
-      const double pw = (near || wfroz) ? 0.0 : 1.0;
-      // rhs and Quz on the face
-      const double q0 = gt[3 * i] + b0, q1 = gt[3 * i + 1] + b1, q2 = gt[3 * i + 2] + b2;
-      const double g0 = p00 * q0 + p01 * q1, g1 = p01 * q0 + p11 * q1, g2 = pw * q2;
-      const double R00 = p00 * G00 + p01 * G10, R01 = p00 * G01 + p01 * G11, R02 = p00 * Z02 + p01 * Z12;
-      const double R10 = p01 * G00 + p11 * G10, R11 = p01 * G01 + p11 * G11, R12 = p01 * Z02 + p11 * Z12;
-      const double R20 = pw * G20, R21 = pw * G21, R22 = pw * Z22;
-      // P Quu P + (I - P)
-      const double T00 = p00 * Q00 + p01 * Q01, T01 = p00 * Q01 + p01 * Q11, T02 = p00 * Q02 + p01 * Q12;
-      const double T10 = p01 * Q00 + p11 * Q01, T11 = p01 * Q01 + p11 * Q11, T12 = p01 * Q02 + p11 * Q12;
-      const double H00 = T00 * p00 + T01 * p01 + (1.0 - p00), H01 = T00 * p01 + T01 * p11 - p01, H02 = T02 * pw;
-      const double H11 = T10 * p01 + T11 * p11 + (1.0 - p11), H12 = T12 * pw;
-      const double H22 = pw * Q22 * pw + (1.0 - pw);
-      // L D L^T without pivoting, pivots made positive
-      const double delta = fmax(1e-6 * fmax(fabs(H00), fmax(fabs(H11), fabs(H22))), 1e-30);
-      const double d0 = ric_pivot(H00, delta), i0 = rcp_fast(d0);
-      const double l10 = H01 * i0, l20 = H02 * i0;
-      const double d1 = ric_pivot(H11 - l10 * H01, delta), i1 = rcp_fast(d1);
-      const double h12 = H12 - l20 * H01;
-      const double l21 = h12 * i1;
-      const double d2 = ric_pivot(H22 - l20 * H02 - l21 * h12, delta), i2 = rcp_fast(d2);
-      // solve (L D L^T) x = -r for r = g and the three columns of Quz on the face
-#define NEO_RIC_SOLVE(r0_, r1_, r2_, x0_, x1_, x2_)                     \
-      {                                                                  \
-        const double y0 = -(r0_), y1 = -(r1_) - l10 * y0, y2 = -(r2_) - l20 * y0 - l21 * y1; \
-        x2_ = y2 * i2;                                                   \
-        x1_ = y1 * i1 - l21 * x2_;                                       \
-        x0_ = y0 * i0 - l10 * x1_ - l20 * x2_;                           \
+      // does the stage model put this block ON the kink?  0 in Qu_s + Quu_s k + w d|.| at k = step onto the kink
+      // <=> |Qu_s + Quu_s k| <= w  (smooth parts only: Quu_s = M + T)
+      const T e0 = (T)d[3 * i], e1 = (T)d[3 * i + 1], e2 = (T)d[3 * i + 2];
+      const T r0 = (T)gsr[3 * i] + z0 + S00 * e0 + S01 * e1 + Z02 * e2;
+      const T r1 = (T)gsr[3 * i + 1] + z1 + S01 * e0 + S11 * e1 + Z12 * e2;
+      const T r2 = (T)gsr[3 * i + 2] + z2 + Z02 * e0 + Z12 * e1 + Z22 * e2;
+      if (__builtin_amdgcn_readfirstlane((int)(r0 * r0 + r1 * r1 + r2 * r2 <= wc2))) {   // fixed step onto the kink, no feedback: v = Qz + Quz^T k, V = Qzz
+        tokink = true;
+        k0 = e0; k1 = e1; k2 = e2;
+        v0 = z0 + S00 * k0 + S01 * k1 + M02 * k2;
+        v1 = z1 + S01 * k0 + S11 * k1 + M12 * k2;
+        v2 = z2 + Z02 * k0 + Z12 * k1 + Z22 * k2;
+        V00 = S00; V01 = S01; V02 = M02; V11 = S11; V12 = M12; V22 = Z22;
       }
-      NEO_RIC_SOLVE(g0, g1, g2, k0, k1, k2)
-      NEO_RIC_SOLVE(R00, R10, R20, K00, K10, K20)
-      NEO_RIC_SOLVE(R01, R11, R21, K01, K11, K21)
-      NEO_RIC_SOLVE(R02, R12, R22, K02, K12, K22)
-#undef NEO_RIC_SOLVE
-      // v = Qz + Quz_r^T k, V = Qzz + Quz_r^T K (symmetrised)
-      v0 = z0 + R00 * k0 + R10 * k1 + R20 * k2;
-      v1 = z1 + R01 * k0 + R11 * k1 + R21 * k2;
-      v2 = z2 + R02 * k0 + R12 * k1 + R22 * k2;
-      V00 = S00 + R00 * K00 + R10 * K10 + R20 * K20;
-      V11 = S11 + R01 * K01 + R11 * K11 + R21 * K21;
-      V22 = Y22 + R02 * K02 + R12 * K12 + R22 * K22;
-      V01 = S01 + 0.5 * ((R00 * K01 + R10 * K11 + R20 * K21) + (R01 * K00 + R11 * K10 + R21 * K20));
-      V02 = M02 + 0.5 * ((R00 * K02 + R10 * K12 + R20 * K22) + (R02 * K00 + R12 * K10 + R22 * K20));
-      V12 = M12 + 0.5 * ((R01 * K02 + R11 * K12 + R21 * K22) + (R02 * K01 + R12 * K11 + R22 * K21));
+    }
+    if (!tokink) {
+      // Quu = M + T + R~, gradient on the stage
+      const T Q00 = S00 + rs[RS_C00], Q01 = S01 + rs[RS_C01], Q02 = Z02 + rs[RS_C02];
+      const T Q11 = S11 + rs[RS_C11], Q12 = Z12 + rs[RS_C12], Q22 = Z22 + rs[RS_C22];
+      const T q0 = (T)gt[3 * i] + z0, q1 = (T)gt[3 * i + 1] + z1, q2 = (T)gt[3 * i + 2] + z2;
+      const bool wfree = !(near || wfroz);
+      const int xy = near ? 2 : mode;   // 0: both directions free, 1: sliding along the tangent, 2: pinned
+      // reduced coordinates of the face: up to three unit directions; Quz rows are (S00 S01 Z02), (S01 S11 Z12),
+      // (M02 M12 Z22)
+      if (xy == 0 && wfree) {
+        // ---- three free directions: L D L^T of Quu without pivoting, pivots made positive
+        const T delta = ric_max((T)1e-6 * ric_max(ric_abs(Q00), ric_max(ric_abs(Q11), ric_abs(Q22))), (T)1e-30);
+        const T d0 = ric_pivot(Q00, delta), i0 = ric_rcp(d0);
+        const T l10 = Q01 * i0, l20 = Q02 * i0;
+        const T d1 = ric_pivot(Q11 - l10 * Q01, delta), i1 = ric_rcp(d1);
+        const T h12 = Q12 - l20 * Q01;
+        const T l21 = h12 * i1;
+        const T d2 = ric_pivot(Q22 - l20 * Q02 - l21 * h12, delta), i2 = ric_rcp(d2);
+#define NEO_RIC_SOLVE3(r0_, r1_, r2_, x0_, x1_, x2_)                                           \
+        {                                                                                        \
+          const T y0 = -(r0_), y1 = -(r1_) - l10 * y0, y2 = -(r2_) - l20 * y0 - l21 * y1;    \
+          x2_ = y2 * i2;                                                                         \
+          x1_ = y1 * i1 - l21 * x2_;                                                             \
+          x0_ = y0 * i0 - l10 * x1_ - l20 * x2_;                                                 \
+        }
+        NEO_RIC_SOLVE3(q0, q1, q2, k0, k1, k2)
+        NEO_RIC_SOLVE3(S00, S01, M02, K00, K10, K20)
+        NEO_RIC_SOLVE3(S01, S11, M12, K01, K11, K21)
+        NEO_RIC_SOLVE3(Z02, Z12, Z22, K02, K12, K22)
+#undef NEO_RIC_SOLVE3
+      } else {
+        // ---- at most two free directions a, b: unit vectors ea, eb (eb = the omega axis, or the y axis)
+        // a: tangent (sliding), x axis (xy free, omega frozen) or -- xy pinned -- none; b: omega or y
+        T ax = (T)0.0, ay = (T)0.0;          // direction a = (ax, ay, 0)
+        bool has_a = false, has_b = false, b_is_w = false;
+        if (xy == 1) { ax = rs[RS_TX]; ay = rs[RS_TY]; has_a = true; has_b = wfree; b_is_w = true; }
+        else if (xy == 0) { ax = (T)1.0; has_a = true; has_b = true; b_is_w = false; }   // (omega frozen: b = y axis)
+        else { has_b = wfree; b_is_w = true; }
+        // rows of Quu and Quz along a and b
+        const T Qa0 = ax * Q00 + ay * Q01, Qa1 = ax * Q01 + ay * Q11, Qa2 = ax * Q02 + ay * Q12;
+        const T haa = Qa0 * ax + Qa1 * ay;
+        const T hab = b_is_w ? Qa2 : Qa1;
+        const T hbb = b_is_w ? Q22 : Q11;
+        const T ga = ax * q0 + ay * q1, gb = b_is_w ? q2 : q1;
+        const T Za0 = ax * S00 + ay * S01, Za1 = ax * S01 + ay * S11, Za2 = ax * Z02 + ay * Z12;
+        const T Zb0 = b_is_w ? M02 : S01, Zb1 = b_is_w ? M12 : S11, Zb2 = b_is_w ? Z22 : Z12;
+        T ka = (T)0.0, kb = (T)0.0, Ka0 = (T)0.0, Ka1 = (T)0.0, Ka2 = (T)0.0, Kb0 = (T)0.0, Kb1 = (T)0.0, Kb2 = (T)0.0;
+        if (has_a && has_b) {
+          const T delta = ric_max((T)1e-6 * ric_max(ric_abs(haa), ric_abs(hbb)), (T)1e-30);
+          const T d0 = ric_pivot(haa, delta), i0 = ric_rcp(d0);
+          const T l = hab * i0;
+          const T d1 = ric_pivot(hbb - l * hab, delta), i1 = ric_rcp(d1);
+#define NEO_RIC_SOLVE2(ra_, rb_, xa_, xb_)                       \
+          {                                                        \
+            const T y0 = -(ra_), y1 = -(rb_) - l * y0;         \
+            xb_ = y1 * i1;                                         \
+            xa_ = y0 * i0 - l * xb_;                               \
+          }
+          NEO_RIC_SOLVE2(ga, gb, ka, kb)
+          NEO_RIC_SOLVE2(Za0, Zb0, Ka0, Kb0)
+          NEO_RIC_SOLVE2(Za1, Zb1, Ka1, Kb1)
+          NEO_RIC_SOLVE2(Za2, Zb2, Ka2, Kb2)
+#undef NEO_RIC_SOLVE2
+        } else if (has_a) {
+          const T i0 = -ric_rcp(ric_pivot(haa, ric_max((T)1e-6 * ric_abs(haa), (T)1e-30)));
+          ka = ga * i0; Ka0 = Za0 * i0; Ka1 = Za1 * i0; Ka2 = Za2 * i0;
+        } else if (has_b) {
+          const T i0 = -ric_rcp(ric_pivot(hbb, ric_max((T)1e-6 * ric_abs(hbb), (T)1e-30)));
+          kb = gb * i0; Kb0 = Zb0 * i0; Kb1 = Zb1 * i0; Kb2 = Zb2 * i0;
+        }
+        // back to the stage's three coordinates: k = ea ka + eb kb, K likewise
+        k0 = ax * ka; k1 = ay * ka; K00 = ax * Ka0; K01 = ax * Ka1; K02 = ax * Ka2; K10 = ay * Ka0; K11 = ay * Ka1; K12 = ay * Ka2;
+        if (b_is_w) { k2 = kb; K20 = Kb0; K21 = Kb1; K22 = Kb2; }
+        else { k1 += kb; K10 += Kb0; K11 += Kb1; K12 += Kb2; }
+      }
+      // v = Qz + Quz^T k, V = Qzz + Quz^T K (K spans the face only; upper triangle, symmetric in exact arithmetic)
+      v0 = z0 + S00 * k0 + S01 * k1 + M02 * k2;
+      v1 = z1 + S01 * k0 + S11 * k1 + M12 * k2;
+      v2 = z2 + Z02 * k0 + Z12 * k1 + Z22 * k2;
+      V00 = S00 + S00 * K00 + S01 * K10 + M02 * K20;
+      V01 = S01 + S00 * K01 + S01 * K11 + M02 * K21;
+      V02 = M02 + S00 * K02 + S01 * K12 + M02 * K22;
+      V11 = S11 + S01 * K01 + S11 * K11 + M12 * K21;
+      V12 = M12 + S01 * K02 + S11 * K12 + M12 * K22;
+      V22 = Z22 + Z02 * K02 + Z12 * K12 + Z22 * K22;
     }
     if (lane == 0) {
-      double* gn = GAIN + kRicGain * i;
-      gn[0] = K00; gn[1] = K01; gn[2] = K02; gn[3] = K10; gn[4] = K11; gn[5] = K12;
-      gn[6] = K20; gn[7] = K21; gn[8] = K22; gn[9] = k0; gn[10] = k1; gn[11] = k2;
+      float* gn = GAIN + kRicGain * i;
+      gn[0] = (float)K00; gn[1] = (float)K01; gn[2] = (float)K02; gn[3] = (float)K10; gn[4] = (float)K11;
+      gn[5] = (float)K12; gn[6] = (float)K20; gn[7] = (float)K21; gn[8] = (float)K22; gn[9] = (float)k0;
+      gn[10] = (float)k1; gn[11] = (float)k2;
       AMODE[4 * i + 3] = tokink ? 1 : 0;
     }
   }
   WAVE_SYNC();
-  // forward sweep of the linearised chain: du_i = k_i + K_i dz_{i-1}, dz_i = A_i (dz_{i-1} + B0_i du_i)
-  double z0 = 0.0, z1 = 0.0, z2 = 0.0;
+  // forward sweep: w_i = k_i + K_i dz_{i-1}, dz_i = A_i (dz_{i-1} + w_i)
+  T z0 = (T)0.0, z1 = (T)0.0, z2 = (T)0.0;
   for (int i = 0; i < n; ++i) {
-    const double* gn = GAIN + kRicGain * i;
-    const double du0 = gn[9] + gn[0] * z0 + gn[1] * z1 + gn[2] * z2;
-    const double du1 = gn[10] + gn[3] * z0 + gn[4] * z1 + gn[5] * z2;
-    const double du2 = gn[11] + gn[6] * z0 + gn[7] * z1 + gn[8] * z2;
-    if (lane == 0) { d[3 * i] = du0; d[3 * i + 1] = du1; d[3 * i + 2] = du2; }
-    const double cs = ACS[i], sn = ASN[i], px = APX[i], py = APY[i];
-    const double e0 = z0 + dt * (cs * du0 - sn * du1), e1 = z1 + dt * (sn * du0 + cs * du1), e2 = z2 + dt * du2;
-    z0 = fma(-py, e2, e0); z1 = fma(px, e2, e1); z2 = e2;
+    const float* gn = GAIN + kRicGain * i;
+    const T w0 = gn[9] + gn[0] * z0 + gn[1] * z1 + gn[2] * z2;
+    const T w1 = gn[10] + gn[3] * z0 + gn[4] * z1 + gn[5] * z2;
+    const T w2f = gn[11] + gn[6] * z0 + gn[7] * z1 + gn[8] * z2;
+    if (lane == 0) { d[3 * i] = (double)w0; d[3 * i + 1] = (double)w1; d[3 * i + 2] = (double)w2f; }
+    const float* rs = RS + kRicStage * i;
+    const T e0 = z0 + w0, e1 = z1 + w1, e2 = z2 + w2f;
+    z0 = ric_fma(-(T)rs[RS_PY], e2, e0); z1 = ric_fma((T)rs[RS_PX], e2, e1); z2 = e2;
+  }
+  WAVE_SYNC();
+}
+
+// lane = stage: du = B0^-1 w = (Rot^T w_xy, w_w) / dt; the step of a block sent onto the kink is exact
+__device__ __forceinline__ void riccati_finish(const SolveArgs& a, const Ctx& c, double* L, int n, int lane) {
+  if (lane < n) {
+    const float* rs = reinterpret_cast<const float*>(L + a.lds.ric) + kRicStage * lane;
+    const int* am = reinterpret_cast<const int*>(L + a.lds.mode) + 4 * lane;
+    double* d = L + a.lds.d + 3 * lane;
+    if (am[3]) {
+      const double* u = L + a.lds.u + 3 * lane;
+      d[0] = c.v0 - u[0]; d[1] = c.v1 - u[1]; d[2] = c.v2 - u[2];
+    } else {
+      const double cs = rs[RS_CS], sn = rs[RS_SN], idt = rcp_fast(a.p.dt);
+      const double w0 = d[0], w1 = d[1], w2 = d[2];
+      double d0 = (cs * w0 + sn * w1) * idt, d1 = (-sn * w0 + cs * w1) * idt;
+      // back on the face EXACTLY: the rotation round trip leaves ~1e-10 of a sliding block's step along the
+      // constraint normal; an inward residue would take the block off its bound, the next tangent-cone pass
+      // would find it free, and the Newton step would run straight back into the bound
+      const int mode = am[2] ? 2 : am[0];
+      if (mode == 1) {
+        const double nx = L[a.lds.nx + lane], ny = L[a.lds.ny + lane];
+        const double dot = d0 * nx + d1 * ny;
+        d0 -= dot * nx; d1 -= dot * ny;
+      } else if (mode == 2) { d0 = 0.0; d1 = 0.0; }
+      d[0] = d0; d[1] = d1; d[2] = (am[2] || am[1]) ? 0.0 : w2 * idt;
+    }
   }
   WAVE_SYNC();
 }

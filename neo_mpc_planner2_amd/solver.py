@@ -159,6 +159,17 @@ class BatchSolver:
             C.c_void_p(out.ctypes.data), len(problems)))
         return out
 
+    def direction(self, problems, u, iteration):
+        """Test hook: the search direction of lanes 32-63 in solver iteration `iteration` (0-based) of a
+        solve started from `u`; rows of instances that stopped earlier stay NaN."""
+        problems = np.ascontiguousarray(problems, dtype=abi.PROBLEM_DTYPE)
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        out = np.full_like(u, np.nan)
+        _lib.check(self._lib.neo_mpc_direction_batch(
+            self._handle, C.c_void_p(problems.ctypes.data), C.c_void_p(u.ctypes.data),
+            C.c_void_p(out.ctypes.data), len(problems), int(iteration)))
+        return out
+
     # -- carrot selection (the step before the solver) ------------------------------------
     def select_carrots(self, plan_poses, plan_offsets, robot_poses, slow_down, footprint_costs=None,
                        problems=None, lookahead_dist_min=0.5, lookahead_dist_max=0.5,

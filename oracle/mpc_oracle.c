@@ -554,13 +554,14 @@ static void orc_newton_direction(const orc_ctx* c, const double* u, const double
  * W_i the stage cost's Hessian, lambda_i = (SX_i, SY_i) the costate of the adjoint sweep, J_i the
  * sensitivity of z_i.  One backward sweep over the stages with 3x3 value-function Hessians and one
  * forward sweep give d in O(control_steps) -- no (3N)^2 matrix, no finite differences. */
+static int orc_piv_replaced;
 static void orc_sym3_solve_prepare(double Q[3][3], double L[3][3], double delta) {
   /* LDL^T-free Cholesky-like elimination without pivoting, non-positive pivots replaced:
    * L holds the eliminated upper triangle rows (as orc_newton_direction does for the dense system) */
   for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) L[r][q] = Q[r][q];
   for (int p = 0; p < 3; ++p) {
     double piv = L[p][p];
-    if (!(piv > delta)) piv = fmax(fabs(piv), delta);
+    if (!(piv > delta)) { piv = fmax(fabs(piv), delta); ++orc_piv_replaced; }
     L[p][p] = piv;
     for (int j = p + 1; j < 3; ++j) {
       const double fac = L[j][p] / piv;
@@ -763,10 +764,182 @@ static void orc_riccati_direction(const orc_ctx* c, const double* u, const doubl
   }
 }
 
+/* The same direction computed the way the device does (riccati.h): in the DISPLACEMENT coordinates of every
+ * stage, w = B0 du with B0 = dt diag(Rot(theta_i), 1).  The linearised step is then dz_i = A_i (dz_{i-1} + w_i),
+ * the Gauss-Newton part of Quu, Quz and Qzz is one matrix M = A^T S A, the second-order terms of the step are
+ * T = [[0 0 SY] [0 0 -SX] [SY -SX kappa]], and every stage is solved in the coordinates of its face (0-3 free
+ * directions) instead of through projector products.  float64 here, float32 on the device. */
+static int orc_disp = 1;
+void orc_set_disp(int on) { orc_disp = on; }
+static int orc_piv_replaced = 0;
+static double orc_piv(double p, double delta) { if (!(p > delta)) ++orc_piv_replaced; return p > delta ? p : fmax(fabs(p), delta); }
+int orc_get_piv_replaced(void) { int r = orc_piv_replaced; orc_piv_replaced = 0; return r; }
+static void orc_riccati_direction_disp_tau(const orc_ctx* c, const double* u, const double* gs, const double* gt,
+                                       orc_active* a, double* d, double tau);
+/* What the solver uses: the GAUSS-NEWTON part of the Hessian (tau = 0: the lambda . d2F terms of the rollout
+ * step are left out).  Every stage system is then positive definite by construction and the recursion is
+ * safe in float32 (the device's precision); with the second-order terms (tau = 1, kept for the equivalence
+ * test against the dense Newton direction) stage systems turn indefinite far from the minimiser, pivots
+ * get replaced and the forward sweep can blow up (control_steps 64: |d| ~ 1e53) -- for 1-3 % fewer
+ * iterations (12.07 against 12.21 at control_steps 32, 7.01 / 7.06 at 8). */
+static void orc_riccati_direction_disp(const orc_ctx* c, const double* u, const double* gs, const double* gt,
+                                       orc_active* a, double* d) {
+  orc_riccati_direction_disp_tau(c, u, gs, gt, a, d, 0.0);
+}
+static void orc_riccati_direction_disp_tau(const orc_ctx* c, const double* u, const double* gs, const double* gt,
+                                       orc_active* a, double* d, double tau) {
+  const int n = c->n;
+  const double dt = c->dt;
+  double cs[ORC_MAXN], sn[ORC_MAXN], px[ORC_MAXN], py[ORC_MAXN], SX[ORC_MAXN], SY[ORC_MAXN], xs_[ORC_MAXN], ys_[ORC_MAXN];
+  {
+    double x = 0.0, y = 0.0, th = 0.0, rx[ORC_MAXN], ry[ORC_MAXN];
+    for (int i = 0; i < n; ++i) {
+      th += u[3 * i + 2] * dt;
+      cs[i] = cos(th); sn[i] = sin(th);
+      px[i] = (u[3 * i] * cs[i] - u[3 * i + 1] * sn[i]) * dt;
+      py[i] = (u[3 * i] * sn[i] + u[3 * i + 1] * cs[i]) * dt;
+      x += px[i]; y += py[i];
+      xs_[i] = x; ys_[i] = y;
+      rx[i] = -2.0 * c->wt_n * (c->cx - x);
+      ry[i] = -2.0 * c->wt_n * (c->cy - y);
+    }
+    double ax = 0.0, ay = 0.0;
+    for (int i = n - 1; i >= 0; --i) { ax += rx[i]; ay += ry[i]; SX[i] = ax; SY[i] = ay; }
+  }
+  double vv[3] = {c->v[0], c->v[1], c->v[2]}, vp[3] = {c->v[0], c->v[1], c->v[2]};
+  orc_project(c, vp);
+  const int v_feasible = vp[0] == vv[0] && vp[1] == vv[1] && vp[2] == vv[2];
+  static _Thread_local double Kf[ORC_MAXN][3][3], kf[ORC_MAXN][3];
+  double V00 = 0, V01 = 0, V02 = 0, V11 = 0, V12 = 0, V22 = 0, v0 = 0, v1 = 0, v2 = 0;
+  const double w2 = 2.0 * c->wt_n, wc2 = (c->wc_n * c->wc_n) / (dt * dt), idt = 1.0 / dt;
+  for (int i = n - 1; i >= 0; --i) {
+    /* wall sliding (see orc_riccati_direction) */
+    double wxx = 0.0, wxy = 0.0, wyy = 0.0;
+    {
+      const double X = c->X0 + (c->c0 * xs_[i] - c->s0 * ys_[i]), Y = c->Y0 + (c->s0 * xs_[i] + c->c0 * ys_[i]);
+      const orc_map* m = c->map;
+      int64_t mx, my;
+      orc_world_to_map(m, X, Y, &mx, &my);
+      const double fx = (X - m->origin_x) / m->resolution - (double)mx, fy = (Y - m->origin_y) / m->resolution - (double)my;
+      const double here = orc_term_at(c, mx, my), rho = ORC_STICKY * 2.0 * c->wt_n;
+      if ((fx < ORC_STICKY_DIST && orc_term_at(c, mx - 1, my) > here) || (1.0 - fx < ORC_STICKY_DIST && orc_term_at(c, mx + 1, my) > here)) {
+        wxx += rho * c->c0 * c->c0; wxy += rho * c->c0 * -c->s0; wyy += rho * c->s0 * c->s0;
+      }
+      if ((fy < ORC_STICKY_DIST && orc_term_at(c, mx, my - 1) > here) || (1.0 - fy < ORC_STICKY_DIST && orc_term_at(c, mx, my + 1) > here)) {
+        wxx += rho * c->s0 * c->s0; wxy += rho * c->s0 * c->c0; wyy += rho * c->c0 * c->c0;
+      }
+    }
+    const double S00 = V00 + w2 + wxx, S01 = V01 + wxy, S11 = V11 + w2 + wyy;
+    const double S22 = V22 + 2.0 * c->wo_n + (i == n - 1 ? 2.0 * c->wterm_o : 0.0);
+    const double M02 = -py[i] * S00 + px[i] * S01 + V02, M12 = -py[i] * S01 + px[i] * S11 + V12;
+    const double M22 = -py[i] * M02 + px[i] * M12 + (-py[i] * V02 + px[i] * V12 + S22);
+    const double kap = -tau * (SX[i] * px[i] + SY[i] * py[i]);
+    const double Z02 = M02 + tau * SY[i], Z12 = M12 - tau * SX[i], Z22 = M22 + kap;
+    const double z0 = v0, z1 = v1, z2 = -py[i] * v0 + px[i] * v1 + v2;
+    /* gradients and the step onto the kink in displacement coordinates */
+    const double* ui = u + 3 * i;
+    const double gt0 = (cs[i] * gt[3 * i] - sn[i] * gt[3 * i + 1]) * idt, gt1 = (sn[i] * gt[3 * i] + cs[i] * gt[3 * i + 1]) * idt,
+                 gt2 = gt[3 * i + 2] * idt;
+    const double gs0 = (cs[i] * gs[3 * i] - sn[i] * gs[3 * i + 1]) * idt, gs1 = (sn[i] * gs[3 * i] + cs[i] * gs[3 * i + 1]) * idt,
+                 gs2 = gs[3 * i + 2] * idt;
+    const double e0 = ui[0] - c->v[0], e1 = ui[1] - c->v[1], e2 = ui[2] - c->v[2];
+    const double f0 = cs[i] * e0 - sn[i] * e1, f1 = sn[i] * e0 + cs[i] * e1, f2 = e2;
+    double k[3] = {0, 0, 0}, K[3][3] = {{0}};
+    a->tokink[i] = 0;
+    if (!a->near[i] && v_feasible && orc_kink_predict) {
+      const double w0 = -f0 * dt, w1 = -f1 * dt, w2k = -f2 * dt;
+      const double r0 = gs0 + z0 + S00 * w0 + S01 * w1 + Z02 * w2k, r1 = gs1 + z1 + S01 * w0 + S11 * w1 + Z12 * w2k,
+                   r2 = gs2 + z2 + Z02 * w0 + Z12 * w1 + Z22 * w2k;
+      if (r0 * r0 + r1 * r1 + r2 * r2 <= wc2) { a->tokink[i] = 1; k[0] = w0; k[1] = w1; k[2] = w2k; }
+    }
+    if (!a->tokink[i]) {
+      double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0, tx = 0, ty = 0;
+      if (!a->near[i]) {
+        const double fn = sqrt(f0 * f0 + f1 * f1 + f2 * f2), ine = fn > 0.0 ? 1.0 / fn : 0.0;
+        const double sN = c->wc_n * ine * idt * idt, h0 = f0 * ine, h1 = f1 * ine, h2 = f2 * ine;
+        const double utx = -a->ny[i], uty = a->nx[i];
+        tx = cs[i] * utx - sn[i] * uty; ty = sn[i] * utx + cs[i] * uty;
+        const double k2 = (a->mode[i] == 1 && a->disc[i]) ? a->lambda[i] / c->r * idt * idt : 0.0;
+        c00 = sN * (1 - h0 * h0) + k2 * tx * tx; c01 = -sN * h0 * h1 + k2 * tx * ty; c02 = -sN * h0 * h2;
+        c11 = sN * (1 - h1 * h1) + k2 * ty * ty; c12 = -sN * h1 * h2; c22 = sN * (1 - h2 * h2);
+      }
+      const double Q00 = S00 + c00, Q01 = S01 + c01, Q02 = Z02 + c02, Q11 = S11 + c11, Q12 = Z12 + c12, Q22 = Z22 + c22;
+      const double q0 = gt0 + z0, q1 = gt1 + z1, q2 = gt2 + z2;
+      const int wfree = !(a->near[i] || a->wfroz[i]);
+      const int xy = a->near[i] ? 2 : a->mode[i];
+      /* Quz rows: (S00 S01 Z02), (S01 S11 Z12), (M02 M12 Z22) */
+      const double Zr[3][3] = {{S00, S01, Z02}, {S01, S11, Z12}, {M02, M12, Z22}};
+      if (xy == 0 && wfree) {
+        double Q[3][3] = {{Q00, Q01, Q02}, {Q01, Q11, Q12}, {Q02, Q12, Q22}}, Lm[3][3];
+        orc_sym3_solve_prepare(Q, Lm, fmax(1e-6 * fmax(fabs(Q00), fmax(fabs(Q11), fabs(Q22))), 1e-30));
+        double rhs[3] = {-q0, -q1, -q2};
+        orc_sym3_solve(Lm, rhs, k);
+        for (int q = 0; q < 3; ++q) {
+          double col[3] = {-Zr[0][q], -Zr[1][q], -Zr[2][q]}, sol[3];
+          orc_sym3_solve(Lm, col, sol);
+          for (int r = 0; r < 3; ++r) K[r][q] = sol[r];
+        }
+      } else {
+        double ax = 0, ay = 0;
+        int has_a = 0, has_b = 0, b_is_w = 0;
+        if (xy == 1) { ax = tx; ay = ty; has_a = 1; has_b = wfree; b_is_w = 1; }
+        else if (xy == 0) { ax = 1.0; has_a = 1; has_b = 1; b_is_w = 0; }
+        else { has_b = wfree; b_is_w = 1; }
+        const double Qa0 = ax * Q00 + ay * Q01, Qa1 = ax * Q01 + ay * Q11, Qa2 = ax * Q02 + ay * Q12;
+        const double haa = Qa0 * ax + Qa1 * ay, hab = b_is_w ? Qa2 : Qa1, hbb = b_is_w ? Q22 : Q11;
+        const double ga = ax * q0 + ay * q1, gb = b_is_w ? q2 : q1;
+        double Za[3], Zb[3], ka = 0, kb = 0, Ka[3] = {0, 0, 0}, Kb[3] = {0, 0, 0};
+        for (int q = 0; q < 3; ++q) { Za[q] = ax * Zr[0][q] + ay * Zr[1][q]; Zb[q] = b_is_w ? Zr[2][q] : Zr[1][q]; }
+        if (has_a && has_b) {
+          const double delta = fmax(1e-6 * fmax(fabs(haa), fabs(hbb)), 1e-30);
+          const double d0 = orc_piv(haa, delta), l = hab / d0, d1 = orc_piv(hbb - l * hab, delta);
+          { const double y0 = -ga, y1 = -gb - l * y0; kb = y1 / d1; ka = y0 / d0 - l * kb; }
+          for (int q = 0; q < 3; ++q) { const double y0 = -Za[q], y1 = -Zb[q] - l * y0; Kb[q] = y1 / d1; Ka[q] = y0 / d0 - l * Kb[q]; }
+        } else if (has_a) {
+          const double i0 = -1.0 / orc_piv(haa, fmax(1e-6 * fabs(haa), 1e-30));
+          ka = ga * i0; for (int q = 0; q < 3; ++q) Ka[q] = Za[q] * i0;
+        } else if (has_b) {
+          const double i0 = -1.0 / orc_piv(hbb, fmax(1e-6 * fabs(hbb), 1e-30));
+          kb = gb * i0; for (int q = 0; q < 3; ++q) Kb[q] = Zb[q] * i0;
+        }
+        k[0] = ax * ka; k[1] = ay * ka;
+        for (int q = 0; q < 3; ++q) { K[0][q] = ax * Ka[q]; K[1][q] = ay * Ka[q]; }
+        if (b_is_w) { k[2] = kb; for (int q = 0; q < 3; ++q) K[2][q] = Kb[q]; }
+        else { k[1] += kb; for (int q = 0; q < 3; ++q) K[1][q] += Kb[q]; }
+      }
+      v0 = z0 + S00 * k[0] + S01 * k[1] + M02 * k[2];
+      v1 = z1 + S01 * k[0] + S11 * k[1] + M12 * k[2];
+      v2 = z2 + Z02 * k[0] + Z12 * k[1] + Z22 * k[2];
+      V00 = S00 + S00 * K[0][0] + S01 * K[1][0] + M02 * K[2][0];
+      V01 = S01 + S00 * K[0][1] + S01 * K[1][1] + M02 * K[2][1];
+      V02 = M02 + S00 * K[0][2] + S01 * K[1][2] + M02 * K[2][2];
+      V11 = S11 + S01 * K[0][1] + S11 * K[1][1] + M12 * K[2][1];
+      V12 = M12 + S01 * K[0][2] + S11 * K[1][2] + M12 * K[2][2];
+      V22 = Z22 + Z02 * K[0][2] + Z12 * K[1][2] + Z22 * K[2][2];
+    } else {
+      v0 = z0 + S00 * k[0] + S01 * k[1] + M02 * k[2];
+      v1 = z1 + S01 * k[0] + S11 * k[1] + M12 * k[2];
+      v2 = z2 + Z02 * k[0] + Z12 * k[1] + Z22 * k[2];
+      V00 = S00; V01 = S01; V02 = M02; V11 = S11; V12 = M12; V22 = Z22;
+    }
+    for (int r = 0; r < 3; ++r) { kf[i][r] = k[r]; for (int q = 0; q < 3; ++q) Kf[i][r][q] = K[r][q]; }
+  }
+  double z0 = 0, z1 = 0, z2 = 0;
+  for (int i = 0; i < n; ++i) {
+    const double w0 = kf[i][0] + Kf[i][0][0] * z0 + Kf[i][0][1] * z1 + Kf[i][0][2] * z2;
+    const double w1 = kf[i][1] + Kf[i][1][0] * z0 + Kf[i][1][1] * z1 + Kf[i][1][2] * z2;
+    const double w2f = kf[i][2] + Kf[i][2][0] * z0 + Kf[i][2][1] * z1 + Kf[i][2][2] * z2;
+    if (a->tokink[i]) { for (int r = 0; r < 3; ++r) d[3 * i + r] = c->v[r] - u[3 * i + r]; }
+    else { d[3 * i] = (cs[i] * w0 + sn[i] * w1) * idt; d[3 * i + 1] = (-sn[i] * w0 + cs[i] * w1) * idt; d[3 * i + 2] = w2f * idt; }
+    const double e0 = z0 + w0, e1 = z1 + w1, e2 = z2 + w2f;
+    z0 = e0 - py[i] * e2; z1 = e1 + px[i] * e2; z2 = e2;
+  }
+}
+
 /* debug/test hook: both Newton directions at a feasible point u (the dense one in float64) */
 void orc_debug_newton_directions(const neo_mpc_params* p, const uint8_t* cells, int32_t sx, int32_t sy, double res,
                                  double ox, double oy, const neo_mpc_problem* q, const double* u, double* d_dense,
-                                 double* d_stage, double* grad_total);
+                                 double* d_stage, double* d_disp);
 
 static double orc_dot(const double* a, const double* b, int n) {
   double s = 0.0;
@@ -811,6 +984,10 @@ static void orc_candidate(const orc_ctx* c, const orc_active* act, int lane, dou
   }
 }
 
+/* test hook: the direction of one iteration of the next orc_pg_solve call (single-threaded use) */
+static int orc_capture_it = -1;
+static double* orc_capture_d = NULL;
+void orc_capture_direction(int it, double* d_out) { orc_capture_it = it; orc_capture_d = d_out; }
 static int orc_trace = 0;
 void orc_set_trace(int on) { orc_trace = on; }
 
@@ -872,6 +1049,7 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
        * Newton step almost never wins there (9 % of the cases): lanes 32-63 walk the reduced
        * steepest-descent direction in that first iteration instead */
       if (it == 0 && cold) for (int k = 0; k < nv; ++k) d[k] = -gr[k];
+      else if (riccati && orc_disp) orc_riccati_direction_disp(&c, u, gs, gt, &act, d);
       else if (riccati) orc_riccati_direction(&c, u, gs, gt, &act, d);
       else orc_newton_direction(&c, u, gs, gr, &act, d);
       orc_apply_active(&c, &act, d);
@@ -926,6 +1104,7 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
       for (int k = 0; k < nv; ++k) d[k] = -d[k];
       orc_apply_active(&c, &act, d);
     }
+    if (orc_capture_it == it && orc_capture_d) memcpy(orc_capture_d, d, sizeof(double) * nv);
     /* 64 candidates, lowest objective wins (ties: lowest lane) */
     double fb = INFINITY, fb_qn = INFINITY;
     int best = -1, best_qn = -1;
@@ -1076,7 +1255,7 @@ void orc_gradient_batch(const neo_mpc_params* p, const uint8_t* cells, int32_t s
 
 void orc_debug_newton_directions(const neo_mpc_params* p, const uint8_t* cells, int32_t sx, int32_t sy, double res,
                                  double ox, double oy, const neo_mpc_problem* q, const double* u, double* d_dense,
-                                 double* d_stage, double* grad_total) {
+                                 double* d_stage, double* d_disp) {
   orc_map m = orc_make_map(cells, sx, sy, res, ox, oy);
   orc_ctx c;
   orc_ctx_init(&c, p, &m, q, q->footprint_cost);
@@ -1085,7 +1264,6 @@ void orc_debug_newton_directions(const neo_mpc_params* p, const uint8_t* cells, 
   orc_grad_smooth(&c, u, gs);
   orc_reduce(&c, u, gs, gt, gr, &act);
   const int nv = 3 * c.n;
-  if (grad_total) memcpy(grad_total, gt, sizeof(double) * nv);
   if (d_dense && nv <= ORC_NEWTON_MAXV) {
     orc_newton_f64 = 1;
     orc_newton_direction(&c, u, gs, gr, &act, d_dense);
@@ -1097,6 +1275,12 @@ void orc_debug_newton_directions(const neo_mpc_params* p, const uint8_t* cells, 
     orc_riccati_direction(&c, u, gs, gt, &act, d_stage);
     orc_kink_predict = 1;
     orc_apply_active(&c, &act, d_stage);
+  }
+  if (d_disp) {   /* the device's formulation: displacement coordinates, face-reduced stage solves */
+    orc_kink_predict = 0;
+    orc_riccati_direction_disp_tau(&c, u, gs, gt, &act, d_disp, 1.0);
+    orc_kink_predict = 1;
+    orc_apply_active(&c, &act, d_disp);
   }
 }
 

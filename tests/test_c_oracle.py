@@ -142,11 +142,13 @@ def test_riccati_direction_equals_the_dense_newton_direction():
             b = u.reshape(n, 3)
             b[:, :2] *= np.minimum(1, 0.7 / np.hypot(b[:, 0], b[:, 1]))[:, None]
             b[:, 2] = np.clip(b[:, 2], -0.7, 0.7)
-            dd, ds = np.zeros(3 * n), np.zeros(3 * n)
+            dd, ds, dw = np.zeros(3 * n), np.zeros(3 * n), np.zeros(3 * n)
             lib.orc_debug_newton_directions(C.byref(ps), *margs, C.c_void_p(probs[j:j + 1].ctypes.data),
                                             C.c_void_p(u.ctypes.data), C.c_void_p(dd.ctypes.data),
-                                            C.c_void_p(ds.ctypes.data), None)
+                                            C.c_void_p(ds.ctypes.data), C.c_void_p(dw.ctypes.data))
             assert np.abs(dd - ds).max() <= 1e-5 * max(1e-9, np.abs(dd).max()), (n, j)
+            # the device's formulation (displacement coordinates, stage solved in the coordinates of its face)
+            assert np.abs(dw - ds).max() <= 1e-9 * max(1e-9, np.abs(ds).max()), (n, j)
 
 
 def test_projection_box_cuts_disc():

@@ -1,0 +1,18 @@
+#!/bin/bash
+# one gpurun call: GPU tests, the default bench line, rocprofv3 evidence for C2 / C3 / C5 and K3
+# usage: bash tools/r2_profile.sh <tag>
+TAG=${1:-r02a}
+O=gpurun_out/final_$TAG
+mkdir -p $O
+timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -15 > $O/gpu_tests.log
+timeout 600 python bench.py > $O/bench_c2.log 2>&1; tail -1 $O/bench_c2.log > $O/bench_c2.json
+timeout 900 bash tools/profile_all.sh $TAG C2 50 > $O/profile_c2.txt 2>&1
+timeout 900 bash tools/profile_all.sh $TAG C3 4 > $O/profile_c3.txt 2>&1
+timeout 900 bash tools/profile_all.sh $TAG C5 4 > $O/profile_c5.txt 2>&1
+timeout 600 bash tools/profile_k3.sh $TAG > $O/profile_k3.txt 2>&1
+{
+  timeout 300 python bench.py --workload C3 --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1
+  timeout 300 python bench.py --workload C4 --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1
+  timeout 300 python bench.py --workload C5 --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1
+} > $O/other_configs.jsonl
+cat $O/gpu_tests.log; cat $O/bench_c2.json; tail -30 $O/profile_c2.txt; tail -8 $O/profile_c3.txt; tail -8 $O/profile_c5.txt; cat gpurun_out/prof_${TAG}_k3/k3.txt; cat $O/other_configs.jsonl

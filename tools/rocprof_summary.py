@@ -15,12 +15,14 @@ import sys
 def kernels(db):
     c = sqlite3.connect(db)
     print("# rocprofv3 --kernel-trace --stats summary of %s" % db)
-    print("%-90s %6s %12s %10s %10s %10s %8s %8s %6s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us",
-                                                          "lds_B", "scratch", "vgpr"))
+    print("# (vgpr_rp = vgpr_count + accum_vgpr_count as rocprofv3 records them -- on gfx950 half of what the compiler\n"
+          "#  reports, `make -C neo_mpc_planner2_amd/csrc resource-usage` is the authoritative figure)")
+    print("%-90s %6s %12s %10s %10s %10s %8s %8s %7s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us",
+                                                          "lds_B", "scratch", "vgpr_rp"))
     q = ("select name, count(*), sum(duration), avg(duration), min(duration), max(duration), avg(lds_size), "
          "avg(scratch_size), avg(vgpr_count + accum_vgpr_count) from kernels group by name order by sum(duration) desc")
     for r in c.execute(q):
-        print("%-90s %6d %12.1f %10.2f %10.2f %10.2f %8d %8d %6d" % (r[0][:90], r[1], r[2] / 1e3, r[3] / 1e3,
+        print("%-90s %6d %12.1f %10.2f %10.2f %10.2f %8d %8d %7d" % (r[0][:90], r[1], r[2] / 1e3, r[3] / 1e3,
                                                                    r[4] / 1e3, r[5] / 1e3, r[6], r[7], r[8]))
 
 
@@ -36,5 +38,31 @@ def pmc(directory, match="k_solve"):
             print("%-28s %18.1f   (n=%d, pass %s)" % (k, sum(v) / len(v), len(v), f.split("/")[-1]))
 
 
+def traffic(directory, workload, match="k_solve"):
+    """One entry of profiles/hbm_traffic.json from the PMC passes in `directory`: HBM bytes (FETCH_SIZE +
+    WRITE_SIZE, KB units; raw counters -- K1's loads are 8-byte and dword accesses, so the gfx950 x2
+    FETCH_SIZE correction for 16 B/lane streams is not applied) and VALU instructions per launch, stamped
+    with the sha of the device sources they were measured on (bench.py reports them only while it matches)."""
+    import json
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    vals, name = {}, None
+    for f in sorted(glob.glob(directory + "/*_counter_collection.csv")):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if match in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                name = r["Kernel_Name"]
+        for k, v in agg.items():
+            vals[k] = sum(v) / len(v)
+    waves = int(vals.get("SQ_WAVES", 0))
+    print(json.dumps({workload: {
+        "hbm_bytes": (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024, "valu_insts": vals.get("SQ_INSTS_VALU"),
+        "batch": waves, "source_sha": bench.source_sha(),
+        "note": "(FETCH_SIZE %.1f KB + WRITE_SIZE %.1f KB) * 1024 per %s launch (%d instances), rocprofv3 --pmc in "
+                "separate passes (tools/profile_all.sh), raw counters" % (vals["FETCH_SIZE"], vals["WRITE_SIZE"], name, waves)}}))
+
+
 if __name__ == "__main__":
-    {"kernels": kernels, "pmc": pmc}[sys.argv[1]](*sys.argv[2:])
+    {"kernels": kernels, "pmc": pmc, "traffic": traffic}[sys.argv[1]](*sys.argv[2:])
