@@ -62,7 +62,7 @@ struct LdsLayout {
   int32_t prob, state, tol, term, u, gs, gt, gr, d, u_prev, gt_prev, u_new, S, Y, rho;
   int32_t cs, sn, dxs, dys, rx, ry, rt, nx, ny, mode;  // per-step scratch
   int32_t hess;        // Newton: (3N)^2 Hessian, only when 3N <= 24
-  int32_t ric;         // Riccati: float32 stage records (16 N floats) then gains (12 N floats), riccati.h
+  int32_t ric;         // Riccati: float32 stage records (28 N floats; the gains overwrite part of them), riccati.h
   int32_t tile;        // byte tile starts here (double index)
   int32_t total_bytes;
   int32_t tile_w;      // row stride of the tile in bytes (power of two), 0: no tile
@@ -98,7 +98,8 @@ constexpr LdsLayout make_lds_layout(int n, int mem, bool riccati) {
     l.ny = off; off += n;
     l.mode = off; off += 2 * n;
     l.hess = off;
-    l.ric = off; off += 14 * n;             // (16 + 12) floats per stage, riccati.h
+    off = (off + 1) & ~1;                   // (16-byte aligned: the records are read as 16-byte words)
+    l.ric = off; off += 14 * n;             // 28 floats per stage, riccati.h
   } else {
     l.u_prev = off; off += nv;
     l.gt_prev = off; off += nv;

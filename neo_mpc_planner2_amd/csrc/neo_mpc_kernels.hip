@@ -475,12 +475,12 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       if (kRiccati) for (int i = lane; i < n; i += kLanes) AMODE[4 * i + 3] = 0;
       WAVE_SYNC();
     } else if (kRiccati) {
-      riccati_prepare(a, c, L, n, lane);
+      riccati_prepare(a, c, L, n, lane, v_feasible);
       WAVE_SYNC();
 #ifdef NEO_MPC_RICCATI_F64   // (study build: the same recursion in float64 on the float32 records)
-      riccati_sweep<double>(a, L, n, lane, v_feasible);
+      riccati_sweep<double>(a, L, n, lane);
 #else
-      riccati_sweep<float>(a, L, n, lane, v_feasible);
+      riccati_sweep<float>(a, L, n, lane);
 #endif
       riccati_finish(a, c, L, n, lane);
     } else if (kNewton) {

@@ -40,56 +40,71 @@
 namespace neo_mpc {
 namespace {
 
-// float32 record of one stage (LDS): rollout step, costates, wall penalty, face, block curvature
+// float32 record of one stage (LDS, 28 floats = seven 16-byte words): rollout step, face, wall penalty, flags,
+// block curvature, trigonometry; then the stage's linear terms, which the backward sweep replaces IN PLACE by
+// the stage's gains once it has consumed them
 enum : int {
-  RS_CS = 0, RS_SN, RS_PX, RS_PY, RS_TX, RS_TY, RS_WXX, RS_WXY, RS_WYY,
-  RS_C00, RS_C01, RS_C02, RS_C11, RS_C12, RS_C22, RS_PAD, kRicStage   // = 16 floats
+  RS_PX = 0, RS_PY, RS_TX, RS_TY,
+  RS_WXX, RS_WXY, RS_WYY, RS_FLAGS,
+  RS_C00, RS_C01, RS_C02, RS_C11,
+  RS_C12, RS_C22, RS_CS, RS_SN,
+  RS_GT = 16,          // [3] total gradient, displacement coordinates   -> K row 0, K[1][0]
+  RS_GS = 19,          // [3] smooth gradient                             -> K[1][1..2], K[2][0]
+  RS_WK = 22,          // [3] the step onto the kink                      -> K[2][1..2], k[0]
+  RS_PAD = 25,         // [3]                                             -> k[1], k[2], -
+  RS_GAIN = 16,        // K (row-major 3x3) then k: 12 floats from here
+  kRicStage = 28
 };
-constexpr int kRicGain = 12;   // floats per stage: feedback K_i (3x3, row-major) and feed-forward k_i
+// RS_FLAGS bits
+enum : int { RF_XY = 3 /* 0 free, 1 sliding along (tx, ty), 2 pinned */, RF_WFREE = 4, RF_KINK_OK = 8 };
 
-// non-positive pivots are replaced (the exact Hessian is indefinite away from the minimiser): the
-// factorisation is then that of a positive definite matrix and the stage step a descent direction
+typedef float ric_f4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ float ric_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ double ric_rcp(double x) { return rcp_fast(x); }
 template <typename T> __device__ __forceinline__ T ric_max(T a, T b) { return a > b ? a : b; }
 template <typename T> __device__ __forceinline__ T ric_abs(T a) { return a < (T)0 ? -a : a; }
 __device__ __forceinline__ float ric_fma(float a, float b, float c) { return fmaf(a, b, c); }
 __device__ __forceinline__ double ric_fma(double a, double b, double c) { return fma(a, b, c); }
+// non-positive pivots are replaced: the factorisation is then that of a positive definite matrix and the stage
+// step a descent direction (Gauss-Newton stage systems are positive definite; this guards rounding)
 template <typename T> __device__ __forceinline__ T ric_pivot(T p, T delta) { return p > delta ? p : ric_max(ric_abs(p), delta); }
 
-// lane = stage.  In: gt / gr(unused here) / gs / u / tangent-cone description (mode, wfroz, near | nx, ny, k2 =
-// lambda/r of a binding disc) and the stage's cs, sn.  Out: gt <- total gradient in displacement
-// coordinates, gr <- smooth gradient in displacement coordinates, d <- the step onto the kink in
-// displacement coordinates, record: tangent, block curvature.
-__device__ __forceinline__ void riccati_prepare(const SolveArgs& a, const Ctx& c, double* L, int n, int lane) {
+// lane = stage.  In: gt / gs / u / tangent-cone description (mode, wfroz, near | nx, ny, k2 = lambda/r of a
+// binding disc) and the stage's cs, sn (record).  Out (record): gradients and the step onto the kink in
+// displacement coordinates, tangent, flags, block curvature.
+__device__ __forceinline__ void riccati_prepare(const SolveArgs& a, const Ctx& c, double* L, int n, int lane,
+                                                bool v_feasible) {
   if (lane >= n) return;
   const DevParams& p = a.p;
   float* rs = reinterpret_cast<float*>(L + a.lds.ric) + kRicStage * lane;
   const int* am = reinterpret_cast<const int*>(L + a.lds.mode) + 4 * lane;
-  double* gt = L + a.lds.gt + 3 * lane;
-  double* gsr = L + a.lds.gr + 3 * lane;
+  const double* gt = L + a.lds.gt + 3 * lane;
   const double* gs = L + a.lds.gs + 3 * lane;
   const double* u = L + a.lds.u + 3 * lane;
-  double* d = L + a.lds.d + 3 * lane;
   const double cs = rs[RS_CS], sn = rs[RS_SN];   // (float32 copies: a direction's worth of accuracy)
   const double idt = rcp_fast(p.dt);
   // gradients: g~ = B0^-T g = (Rot g_xy, g_w) / dt
-  const double t0 = gt[0], t1 = gt[1], t2 = gt[2];
-  gt[0] = (cs * t0 - sn * t1) * idt; gt[1] = (sn * t0 + cs * t1) * idt; gt[2] = t2 * idt;
-  const double s0 = gs[0], s1 = gs[1], s2 = gs[2];
-  gsr[0] = (cs * s0 - sn * s1) * idt; gsr[1] = (sn * s0 + cs * s1) * idt; gsr[2] = s2 * idt;
+  rs[RS_GT] = (float)((cs * gt[0] - sn * gt[1]) * idt); rs[RS_GT + 1] = (float)((sn * gt[0] + cs * gt[1]) * idt);
+  rs[RS_GT + 2] = (float)(gt[2] * idt);
+  rs[RS_GS] = (float)((cs * gs[0] - sn * gs[1]) * idt); rs[RS_GS + 1] = (float)((sn * gs[0] + cs * gs[1]) * idt);
+  rs[RS_GS + 2] = (float)(gs[2] * idt);
   // the step onto the kink u_i = v_cur: w = B0 (v - u_i)
   const double e0 = u[0] - c.v0, e1 = u[1] - c.v1, e2 = u[2] - c.v2;
-  d[0] = -(cs * e0 - sn * e1) * p.dt; d[1] = -(sn * e0 + cs * e1) * p.dt; d[2] = -e2 * p.dt;
-  // face: tangent of a sliding block, rotated
+  rs[RS_WK] = (float)(-(cs * e0 - sn * e1) * p.dt); rs[RS_WK + 1] = (float)(-(sn * e0 + cs * e1) * p.dt);
+  rs[RS_WK + 2] = (float)(-e2 * p.dt);
+  // face: tangent of a sliding block, rotated; flags
   const double nx = L[a.lds.nx + lane], ny = L[a.lds.ny + lane];
   const double tx = -ny, ty = nx;
   const float rtx = (float)(cs * tx - sn * ty), rty = (float)(sn * tx + cs * ty);
   rs[RS_TX] = rtx; rs[RS_TY] = rty;
+  const int near = am[2];
+  const int flags = (near ? 2 : am[0]) | ((near || am[1]) ? 0 : RF_WFREE) | ((!near && v_feasible) ? RF_KINK_OK : 0);
+  rs[RS_FLAGS] = (float)flags;   // (a small integer as a float VALUE: its bit pattern would be a denormal)
   // block curvature R~ = B0^-T R B0^-1: the control norm's Hessian (w/|e|)(I - h h^T), h = e/|e| rotated, plus
   // lambda/r t t^T of a binding disc -- both divided by dt^2
   float c00 = 0.0f, c01 = 0.0f, c02 = 0.0f, c11 = 0.0f, c12 = 0.0f, c22 = 0.0f;
-  if (!am[2]) {
+  if (!near) {
     const float f0 = (float)(cs * e0 - sn * e1), f1 = (float)(sn * e0 + cs * e1), f2 = (float)e2;
     const float fn2 = f0 * f0 + f1 * f1 + f2 * f2;
     const float ine = fn2 > 0.0f ? __builtin_amdgcn_rsqf(fn2) : 0.0f;
@@ -102,66 +117,66 @@ __device__ __forceinline__ void riccati_prepare(const SolveArgs& a, const Ctx& c
   rs[RS_C00] = c00; rs[RS_C01] = c01; rs[RS_C02] = c02; rs[RS_C11] = c11; rs[RS_C12] = c12; rs[RS_C22] = c22;
 }
 
-// Backward + forward sweep in displacement coordinates, wave-uniform.  Output: w_i in d (float64 slots), and
-// per block tokink (AMODE slot 3): the stage model's minimiser is the kink itself.
+// Backward + forward sweep in displacement coordinates, wave-uniform.  The record of stage i - 1 is fetched
+// (seven 16-byte LDS reads) while stage i is worked on: nothing in it depends on the recursion.  Output: w_i
+// in d (float64 slots), and per block tokink (AMODE slot 3): the stage model's minimiser is the kink itself.
 template <typename T>
-__device__ __forceinline__ void riccati_sweep(const SolveArgs& a, double* L, int n, int lane, bool v_feasible) {
+__device__ __forceinline__ void riccati_sweep(const SolveArgs& a, double* L, int n, int lane) {
   const DevParams& p = a.p;
-  const float* RS = reinterpret_cast<const float*>(L + a.lds.ric);
-  float* GAIN = reinterpret_cast<float*>(L + a.lds.ric) + kRicStage * n;
+  float* RS = static_cast<float*>(__builtin_assume_aligned(reinterpret_cast<float*>(L + a.lds.ric), 16));
   int* AMODE = reinterpret_cast<int*>(L + a.lds.mode);
-  const double* gsr = L + a.lds.gr;
-  const double* gt = L + a.lds.gt;
   double* d = L + a.lds.d;
   const T w2 = (T)(2.0 * p.wt_n), wo2 = (T)(2.0 * p.wo_n), wterm2 = (T)(2.0 * p.wterm_o);
   // kink test |B0^T r| <= w_control/N  <=>  |r| <= w_control / (N dt)
   const T wc2 = (T)((p.wc_n * p.wc_n) / (p.dt * p.dt));
 
   T V00 = (T)0.0, V01 = (T)0.0, V02 = (T)0.0, V11 = (T)0.0, V12 = (T)0.0, V22 = (T)0.0, v0 = (T)0.0, v1 = (T)0.0, v2 = (T)0.0;
+  ric_f4 r0, r1, r2, r3, r4, r5, r6;
+  {
+    const ric_f4* R4 = reinterpret_cast<const ric_f4*>(RS + kRicStage * (n - 1));
+    r0 = R4[0]; r1 = R4[1]; r2 = R4[2]; r3 = R4[3]; r4 = R4[4]; r5 = R4[5]; r6 = R4[6];
+  }
   for (int i = n - 1; i >= 0; --i) {
-    const float* rs = RS + kRicStage * i;
-    const T px = rs[RS_PX], py = rs[RS_PY];
-    // S = W_i + wall_i + V;  M = A^T S A
-    const T S00 = V00 + w2 + rs[RS_WXX], S01 = V01 + rs[RS_WXY], S11 = V11 + w2 + rs[RS_WYY];
+    // this stage's record (registers), the next one on its way
+    const T px = r0.x, py = r0.y, rtx = r0.z, rty = r0.w;
+    const T wxx = r1.x, wxy = r1.y, wyy = r1.z;
+    const int flags = __builtin_amdgcn_readfirstlane((int)r1.w);   // (wave-uniform: scalar branches below)
+    const T c00 = r2.x, c01 = r2.y, c02 = r2.z, c11 = r2.w, c12 = r3.x, c22 = r3.y;
+    const T gt0 = r4.x, gt1 = r4.y, gt2 = r4.z, gs0 = r4.w, gs1 = r5.x, gs2 = r5.y, e0 = r5.z, e1 = r5.w, e2 = r6.x;
+    if (i > 0) {
+      const ric_f4* R4 = reinterpret_cast<const ric_f4*>(RS + kRicStage * (i - 1));
+      r0 = R4[0]; r1 = R4[1]; r2 = R4[2]; r3 = R4[3]; r4 = R4[4]; r5 = R4[5]; r6 = R4[6];
+    }
+    // S = W_i + wall_i + V;  M = A^T S A  (Gauss-Newton: Quu_s = Quz = Qzz = M)
+    const T S00 = V00 + w2 + wxx, S01 = V01 + wxy, S11 = V11 + w2 + wyy;
     const T S22 = V22 + wo2 + (i == n - 1 ? wterm2 : (T)0.0);
     const T M02 = ric_fma(-py, S00, ric_fma(px, S01, V02));
     const T M12 = ric_fma(-py, S01, ric_fma(px, S11, V12));
     const T M22 = ric_fma(-py, M02, ric_fma(px, M12, ric_fma(-py, V02, ric_fma(px, V12, S22))));
-    // Gauss-Newton: Quu_s = Quz = Qzz = M (see the header: the second-order terms of the step are left out)
-    const T Z02 = M02, Z12 = M12, Z22 = M22;
     // linear terms: Qz = A^T v, Qu = g~ + Qz
     const T z0 = v0, z1 = v1, z2 = ric_fma(-py, v0, ric_fma(px, v1, v2));
-    // (wave-uniform by construction: tell the compiler, so that the case analysis below is scalar branches)
-    const int mode = __builtin_amdgcn_readfirstlane(AMODE[4 * i]), wfroz = __builtin_amdgcn_readfirstlane(AMODE[4 * i + 1]),
-              near = __builtin_amdgcn_readfirstlane(AMODE[4 * i + 2]);
     T k0 = (T)0.0, k1 = (T)0.0, k2 = (T)0.0, K00 = (T)0.0, K01 = (T)0.0, K02 = (T)0.0, K10 = (T)0.0, K11 = (T)0.0, K12 = (T)0.0,
           K20 = (T)0.0, K21 = (T)0.0, K22 = (T)0.0;
     bool tokink = false;
-    if (!near && v_feasible) {
-      // does the stage model put this block ON the kink?  0 in Qu_s + Quu_s k + w d|.| at k = step onto the kink
-      // <=> |Qu_s + Quu_s k| <= w  (smooth parts only: Quu_s = M + T)
-      const T e0 = (T)d[3 * i], e1 = (T)d[3 * i + 1], e2 = (T)d[3 * i + 2];
-      const T r0 = (T)gsr[3 * i] + z0 + S00 * e0 + S01 * e1 + Z02 * e2;
-      const T r1 = (T)gsr[3 * i + 1] + z1 + S01 * e0 + S11 * e1 + Z12 * e2;
-      const T r2 = (T)gsr[3 * i + 2] + z2 + Z02 * e0 + Z12 * e1 + Z22 * e2;
-      if (__builtin_amdgcn_readfirstlane((int)(r0 * r0 + r1 * r1 + r2 * r2 <= wc2))) {   // fixed step onto the kink, no feedback: v = Qz + Quz^T k, V = Qzz
+    if (flags & RF_KINK_OK) {
+      // does the stage model put this block ON the kink?  0 in Qu_s + M k + w d|.| at k = the step onto the kink
+      // <=> |Qu_s + M k| <= w  (smooth parts only)
+      const T q0 = gs0 + z0 + S00 * e0 + S01 * e1 + M02 * e2;
+      const T q1 = gs1 + z1 + S01 * e0 + S11 * e1 + M12 * e2;
+      const T q2 = gs2 + z2 + M02 * e0 + M12 * e1 + M22 * e2;
+      if (__builtin_amdgcn_readfirstlane((int)(q0 * q0 + q1 * q1 + q2 * q2 <= wc2))) {   // fixed step, no feedback
         tokink = true;
         k0 = e0; k1 = e1; k2 = e2;
-        v0 = z0 + S00 * k0 + S01 * k1 + M02 * k2;
-        v1 = z1 + S01 * k0 + S11 * k1 + M12 * k2;
-        v2 = z2 + Z02 * k0 + Z12 * k1 + Z22 * k2;
-        V00 = S00; V01 = S01; V02 = M02; V11 = S11; V12 = M12; V22 = Z22;
       }
     }
     if (!tokink) {
-      // Quu = M + T + R~, gradient on the stage
-      const T Q00 = S00 + rs[RS_C00], Q01 = S01 + rs[RS_C01], Q02 = Z02 + rs[RS_C02];
-      const T Q11 = S11 + rs[RS_C11], Q12 = Z12 + rs[RS_C12], Q22 = Z22 + rs[RS_C22];
-      const T q0 = (T)gt[3 * i] + z0, q1 = (T)gt[3 * i + 1] + z1, q2 = (T)gt[3 * i + 2] + z2;
-      const bool wfree = !(near || wfroz);
-      const int xy = near ? 2 : mode;   // 0: both directions free, 1: sliding along the tangent, 2: pinned
-      // reduced coordinates of the face: up to three unit directions; Quz rows are (S00 S01 Z02), (S01 S11 Z12),
-      // (M02 M12 Z22)
+      // Quu = M + R~, gradient on the stage
+      const T Q00 = S00 + c00, Q01 = S01 + c01, Q02 = M02 + c02;
+      const T Q11 = S11 + c11, Q12 = M12 + c12, Q22 = M22 + c22;
+      const T q0 = gt0 + z0, q1 = gt1 + z1, q2 = gt2 + z2;
+      const bool wfree = (flags & RF_WFREE) != 0;
+      const int xy = flags & RF_XY;   // 0: both directions free, 1: sliding along the tangent, 2: pinned
+      // rows of Quz (= M): (S00 S01 M02), (S01 S11 M12), (M02 M12 M22)
       if (xy == 0 && wfree) {
         // ---- three free directions: L D L^T of Quu without pivoting, pivots made positive
         const T delta = ric_max((T)1e-6 * ric_max(ric_abs(Q00), ric_max(ric_abs(Q11), ric_abs(Q22))), (T)1e-30);
@@ -173,7 +188,7 @@ __device__ __forceinline__ void riccati_sweep(const SolveArgs& a, double* L, int
         const T d2 = ric_pivot(Q22 - l20 * Q02 - l21 * h12, delta), i2 = ric_rcp(d2);
 #define NEO_RIC_SOLVE3(r0_, r1_, r2_, x0_, x1_, x2_)                                           \
         {                                                                                        \
-          const T y0 = -(r0_), y1 = -(r1_) - l10 * y0, y2 = -(r2_) - l20 * y0 - l21 * y1;    \
+          const T y0 = -(r0_), y1 = -(r1_) - l10 * y0, y2 = -(r2_) - l20 * y0 - l21 * y1;        \
           x2_ = y2 * i2;                                                                         \
           x1_ = y1 * i1 - l21 * x2_;                                                             \
           x0_ = y0 * i0 - l10 * x1_ - l20 * x2_;                                                 \
@@ -181,24 +196,22 @@ __device__ __forceinline__ void riccati_sweep(const SolveArgs& a, double* L, int
         NEO_RIC_SOLVE3(q0, q1, q2, k0, k1, k2)
         NEO_RIC_SOLVE3(S00, S01, M02, K00, K10, K20)
         NEO_RIC_SOLVE3(S01, S11, M12, K01, K11, K21)
-        NEO_RIC_SOLVE3(Z02, Z12, Z22, K02, K12, K22)
+        NEO_RIC_SOLVE3(M02, M12, M22, K02, K12, K22)
 #undef NEO_RIC_SOLVE3
       } else {
         // ---- at most two free directions a, b: unit vectors ea, eb (eb = the omega axis, or the y axis)
-        // a: tangent (sliding), x axis (xy free, omega frozen) or -- xy pinned -- none; b: omega or y
         T ax = (T)0.0, ay = (T)0.0;          // direction a = (ax, ay, 0)
         bool has_a = false, has_b = false, b_is_w = false;
-        if (xy == 1) { ax = rs[RS_TX]; ay = rs[RS_TY]; has_a = true; has_b = wfree; b_is_w = true; }
+        if (xy == 1) { ax = rtx; ay = rty; has_a = true; has_b = wfree; b_is_w = true; }
         else if (xy == 0) { ax = (T)1.0; has_a = true; has_b = true; b_is_w = false; }   // (omega frozen: b = y axis)
         else { has_b = wfree; b_is_w = true; }
-        // rows of Quu and Quz along a and b
         const T Qa0 = ax * Q00 + ay * Q01, Qa1 = ax * Q01 + ay * Q11, Qa2 = ax * Q02 + ay * Q12;
         const T haa = Qa0 * ax + Qa1 * ay;
         const T hab = b_is_w ? Qa2 : Qa1;
         const T hbb = b_is_w ? Q22 : Q11;
         const T ga = ax * q0 + ay * q1, gb = b_is_w ? q2 : q1;
-        const T Za0 = ax * S00 + ay * S01, Za1 = ax * S01 + ay * S11, Za2 = ax * Z02 + ay * Z12;
-        const T Zb0 = b_is_w ? M02 : S01, Zb1 = b_is_w ? M12 : S11, Zb2 = b_is_w ? Z22 : Z12;
+        const T Za0 = ax * S00 + ay * S01, Za1 = ax * S01 + ay * S11, Za2 = ax * M02 + ay * M12;
+        const T Zb0 = b_is_w ? M02 : S01, Zb1 = b_is_w ? M12 : S11, Zb2 = b_is_w ? M22 : M12;
         T ka = (T)0.0, kb = (T)0.0, Ka0 = (T)0.0, Ka1 = (T)0.0, Ka2 = (T)0.0, Kb0 = (T)0.0, Kb1 = (T)0.0, Kb2 = (T)0.0;
         if (has_a && has_b) {
           const T delta = ric_max((T)1e-6 * ric_max(ric_abs(haa), ric_abs(hbb)), (T)1e-30);
@@ -207,7 +220,7 @@ __device__ __forceinline__ void riccati_sweep(const SolveArgs& a, double* L, int
           const T d1 = ric_pivot(hbb - l * hab, delta), i1 = ric_rcp(d1);
 #define NEO_RIC_SOLVE2(ra_, rb_, xa_, xb_)                       \
           {                                                        \
-            const T y0 = -(ra_), y1 = -(rb_) - l * y0;         \
+            const T y0 = -(ra_), y1 = -(rb_) - l * y0;             \
             xb_ = y1 * i1;                                         \
             xa_ = y0 * i0 - l * xb_;                               \
           }
@@ -228,22 +241,23 @@ __device__ __forceinline__ void riccati_sweep(const SolveArgs& a, double* L, int
         if (b_is_w) { k2 = kb; K20 = Kb0; K21 = Kb1; K22 = Kb2; }
         else { k1 += kb; K10 += Kb0; K11 += Kb1; K12 += Kb2; }
       }
-      // v = Qz + Quz^T k, V = Qzz + Quz^T K (K spans the face only; upper triangle, symmetric in exact arithmetic)
-      v0 = z0 + S00 * k0 + S01 * k1 + M02 * k2;
-      v1 = z1 + S01 * k0 + S11 * k1 + M12 * k2;
-      v2 = z2 + Z02 * k0 + Z12 * k1 + Z22 * k2;
-      V00 = S00 + S00 * K00 + S01 * K10 + M02 * K20;
-      V01 = S01 + S00 * K01 + S01 * K11 + M02 * K21;
-      V02 = M02 + S00 * K02 + S01 * K12 + M02 * K22;
-      V11 = S11 + S01 * K01 + S11 * K11 + M12 * K21;
-      V12 = M12 + S01 * K02 + S11 * K12 + M12 * K22;
-      V22 = Z22 + Z02 * K02 + Z12 * K12 + Z22 * K22;
     }
-    if (lane == 0) {
-      float* gn = GAIN + kRicGain * i;
-      gn[0] = (float)K00; gn[1] = (float)K01; gn[2] = (float)K02; gn[3] = (float)K10; gn[4] = (float)K11;
-      gn[5] = (float)K12; gn[6] = (float)K20; gn[7] = (float)K21; gn[8] = (float)K22; gn[9] = (float)k0;
-      gn[10] = (float)k1; gn[11] = (float)k2;
+    // v = Qz + Quz^T k, V = Qzz + Quz^T K (K spans the face only -- all zero for a block sent onto the kink;
+    // upper triangle, symmetric in exact arithmetic)
+    v0 = z0 + S00 * k0 + S01 * k1 + M02 * k2;
+    v1 = z1 + S01 * k0 + S11 * k1 + M12 * k2;
+    v2 = z2 + M02 * k0 + M12 * k1 + M22 * k2;
+    V00 = S00 + S00 * K00 + S01 * K10 + M02 * K20;
+    V01 = S01 + S00 * K01 + S01 * K11 + M02 * K21;
+    V02 = M02 + S00 * K02 + S01 * K12 + M02 * K22;
+    V11 = S11 + S01 * K01 + S11 * K11 + M12 * K21;
+    V12 = M12 + S01 * K02 + S11 * K12 + M12 * K22;
+    V22 = M22 + M02 * K02 + M12 * K12 + M22 * K22;
+    if (lane == 0) {   // the gains take the place of the stage's linear terms
+      ric_f4* G4 = reinterpret_cast<ric_f4*>(RS + kRicStage * i + RS_GAIN);
+      G4[0] = ric_f4{(float)K00, (float)K01, (float)K02, (float)K10};
+      G4[1] = ric_f4{(float)K11, (float)K12, (float)K20, (float)K21};
+      G4[2] = ric_f4{(float)K22, (float)k0, (float)k1, (float)k2};
       AMODE[4 * i + 3] = tokink ? 1 : 0;
     }
   }
@@ -251,14 +265,14 @@ __device__ __forceinline__ void riccati_sweep(const SolveArgs& a, double* L, int
   // forward sweep: w_i = k_i + K_i dz_{i-1}, dz_i = A_i (dz_{i-1} + w_i)
   T z0 = (T)0.0, z1 = (T)0.0, z2 = (T)0.0;
   for (int i = 0; i < n; ++i) {
-    const float* gn = GAIN + kRicGain * i;
-    const T w0 = gn[9] + gn[0] * z0 + gn[1] * z1 + gn[2] * z2;
-    const T w1 = gn[10] + gn[3] * z0 + gn[4] * z1 + gn[5] * z2;
-    const T w2f = gn[11] + gn[6] * z0 + gn[7] * z1 + gn[8] * z2;
+    const ric_f4* R4 = reinterpret_cast<const ric_f4*>(RS + kRicStage * i);
+    const ric_f4 s0 = R4[0], g0 = R4[4], g1 = R4[5], g2 = R4[6];
+    const T w0 = (T)g2.y + (T)g0.x * z0 + (T)g0.y * z1 + (T)g0.z * z2;
+    const T w1 = (T)g2.z + (T)g0.w * z0 + (T)g1.x * z1 + (T)g1.y * z2;
+    const T w2f = (T)g2.w + (T)g1.z * z0 + (T)g1.w * z1 + (T)g2.x * z2;
     if (lane == 0) { d[3 * i] = (double)w0; d[3 * i + 1] = (double)w1; d[3 * i + 2] = (double)w2f; }
-    const float* rs = RS + kRicStage * i;
     const T e0 = z0 + w0, e1 = z1 + w1, e2 = z2 + w2f;
-    z0 = ric_fma(-(T)rs[RS_PY], e2, e0); z1 = ric_fma((T)rs[RS_PX], e2, e1); z2 = e2;
+    z0 = ric_fma(-(T)s0.y, e2, e0); z1 = ric_fma((T)s0.x, e2, e1); z2 = e2;
   }
   WAVE_SYNC();
 }

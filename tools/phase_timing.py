@@ -8,14 +8,16 @@ import torch
 from neo_mpc_planner2_amd import synthetic
 from neo_mpc_planner2_amd.solver import BatchSolver
 from neo_mpc_planner2_amd.mpc_optimization_server import README_PARAMS
-params = dict(README_PARAMS); params.update(control_steps=3)
-names = ["FD sweep", "cone", "newton", "restrict/early", "candidates", "accept"]
+workload = sys.argv[1] if len(sys.argv) > 1 else "C2"
+n = synthetic.CONFIGS[workload]["control_steps"]
+params = dict(README_PARAMS); params.update(control_steps=n)
+names = ["adjoint sweep", "cone", "direction (Newton system / Riccati sweep)", "restrict/early", "candidates", "accept"]
 for count in (1, 4096, 65536):
-    cfg, cmap, probs, st, warm = synthetic.make_workload("C2", seed=0, batch=count)
+    cfg, cmap, probs, st, warm = synthetic.make_workload(workload, seed=0, batch=count)
     with BatchSolver(params) as s:
         s.set_costmap(*cmap)
         for rep in range(2):
-            st, warm = synthetic.make_states(probs, 3)
+            st, warm = synthetic.make_states(probs, n)
             cmds, x = s.solve(probs, st, warm)
     ok = cmds["iterations"] >= 3
     t = x[ok][:, :6]
