@@ -55,8 +55,8 @@ enum : int {
   RS_GAIN = 16,        // K (row-major 3x3) then k: 12 floats from here
   kRicStage = 28
 };
-// RS_FLAGS bits
-enum : int { RF_XY = 3 /* 0 free, 1 sliding along (tx, ty), 2 pinned */, RF_WFREE = 4, RF_KINK_OK = 8 };
+// RS_FLAGS: the stage's case (what is free) + whether it may be sent onto the kink
+enum : int { RC_FREE3 = 0, RC_SLIDE_W, RC_XY, RC_SLIDE, RC_W, RC_NONE, RC_KINK, RF_CASE = 7, RF_KINK_OK = 8 };
 
 typedef float ric_f4 __attribute__((ext_vector_type(4)));
 
@@ -99,7 +99,10 @@ __device__ __forceinline__ void riccati_prepare(const SolveArgs& a, const Ctx& c
   const float rtx = (float)(cs * tx - sn * ty), rty = (float)(sn * tx + cs * ty);
   rs[RS_TX] = rtx; rs[RS_TY] = rty;
   const int near = am[2];
-  const int flags = (near ? 2 : am[0]) | ((near || am[1]) ? 0 : RF_WFREE) | ((!near && v_feasible) ? RF_KINK_OK : 0);
+  const int xy = near ? 2 : am[0];          // 0: both velocity directions free, 1: sliding along the tangent, 2: pinned
+  const bool wfree = !(near || am[1]);
+  const int kase = xy == 0 ? (wfree ? RC_FREE3 : RC_XY) : xy == 1 ? (wfree ? RC_SLIDE_W : RC_SLIDE) : (wfree ? RC_W : RC_NONE);
+  const int flags = kase | ((!near && v_feasible) ? RF_KINK_OK : 0);
   rs[RS_FLAGS] = (float)flags;   // (a small integer as a float VALUE: its bit pattern would be a denormal)
   // block curvature R~ = B0^-T R B0^-1: the control norm's Hessian (w/|e|)(I - h h^T), h = e/|e| rotated, plus
   // lambda/r t t^T of a binding disc -- both divided by dt^2
@@ -155,30 +158,27 @@ __device__ __forceinline__ void riccati_sweep(const SolveArgs& a, double* L, int
     const T M22 = ric_fma(-py, M02, ric_fma(px, M12, ric_fma(-py, V02, ric_fma(px, V12, S22))));
     // linear terms: Qz = A^T v, Qu = g~ + Qz
     const T z0 = v0, z1 = v1, z2 = ric_fma(-py, v0, ric_fma(px, v1, v2));
+    // ---- the stage system in the coordinates of its face.  Six straight-line cases (wave-uniform switch):
+    //      what is free -- both velocity directions or one (the tangent a of a sliding block) or none, and omega.
+    //      Rows of Quz (= M): (S00 S01 M02), (S01 S11 M12), (M02 M12 M22).  v = Qz + Quz^T k, V = Qzz + Quz^T K,
+    //      upper triangle (symmetric in exact arithmetic), written as rank-one updates per free direction.
     T k0 = (T)0.0, k1 = (T)0.0, k2 = (T)0.0, K00 = (T)0.0, K01 = (T)0.0, K02 = (T)0.0, K10 = (T)0.0, K11 = (T)0.0, K12 = (T)0.0,
-          K20 = (T)0.0, K21 = (T)0.0, K22 = (T)0.0;
+      K20 = (T)0.0, K21 = (T)0.0, K22 = (T)0.0;
     bool tokink = false;
+    int kase = flags & RF_CASE;
     if (flags & RF_KINK_OK) {
       // does the stage model put this block ON the kink?  0 in Qu_s + M k + w d|.| at k = the step onto the kink
       // <=> |Qu_s + M k| <= w  (smooth parts only)
       const T q0 = gs0 + z0 + S00 * e0 + S01 * e1 + M02 * e2;
       const T q1 = gs1 + z1 + S01 * e0 + S11 * e1 + M12 * e2;
       const T q2 = gs2 + z2 + M02 * e0 + M12 * e1 + M22 * e2;
-      if (__builtin_amdgcn_readfirstlane((int)(q0 * q0 + q1 * q1 + q2 * q2 <= wc2))) {   // fixed step, no feedback
-        tokink = true;
-        k0 = e0; k1 = e1; k2 = e2;
-      }
+      if (__builtin_amdgcn_readfirstlane((int)(q0 * q0 + q1 * q1 + q2 * q2 <= wc2))) { tokink = true; kase = RC_KINK; }
     }
-    if (!tokink) {
-      // Quu = M + R~, gradient on the stage
-      const T Q00 = S00 + c00, Q01 = S01 + c01, Q02 = M02 + c02;
-      const T Q11 = S11 + c11, Q12 = M12 + c12, Q22 = M22 + c22;
-      const T q0 = gt0 + z0, q1 = gt1 + z1, q2 = gt2 + z2;
-      const bool wfree = (flags & RF_WFREE) != 0;
-      const int xy = flags & RF_XY;   // 0: both directions free, 1: sliding along the tangent, 2: pinned
-      // rows of Quz (= M): (S00 S01 M02), (S01 S11 M12), (M02 M12 M22)
-      if (xy == 0 && wfree) {
-        // ---- three free directions: L D L^T of Quu without pivoting, pivots made positive
+    const T q0 = gt0 + z0, q1 = gt1 + z1, q2 = gt2 + z2;   // gradient on the stage
+    switch (kase) {
+      case RC_FREE3: {
+        // L D L^T of Quu = M + R~ without pivoting, pivots made positive
+        const T Q00 = S00 + c00, Q01 = S01 + c01, Q02 = M02 + c02, Q11 = S11 + c11, Q12 = M12 + c12, Q22 = M22 + c22;
         const T delta = ric_max((T)1e-6 * ric_max(ric_abs(Q00), ric_max(ric_abs(Q11), ric_abs(Q22))), (T)1e-30);
         const T d0 = ric_pivot(Q00, delta), i0 = ric_rcp(d0);
         const T l10 = Q01 * i0, l20 = Q02 * i0;
@@ -198,61 +198,86 @@ __device__ __forceinline__ void riccati_sweep(const SolveArgs& a, double* L, int
         NEO_RIC_SOLVE3(S01, S11, M12, K01, K11, K21)
         NEO_RIC_SOLVE3(M02, M12, M22, K02, K12, K22)
 #undef NEO_RIC_SOLVE3
-      } else {
-        // ---- at most two free directions a, b: unit vectors ea, eb (eb = the omega axis, or the y axis)
-        T ax = (T)0.0, ay = (T)0.0;          // direction a = (ax, ay, 0)
-        bool has_a = false, has_b = false, b_is_w = false;
-        if (xy == 1) { ax = rtx; ay = rty; has_a = true; has_b = wfree; b_is_w = true; }
-        else if (xy == 0) { ax = (T)1.0; has_a = true; has_b = true; b_is_w = false; }   // (omega frozen: b = y axis)
-        else { has_b = wfree; b_is_w = true; }
-        const T Qa0 = ax * Q00 + ay * Q01, Qa1 = ax * Q01 + ay * Q11, Qa2 = ax * Q02 + ay * Q12;
-        const T haa = Qa0 * ax + Qa1 * ay;
-        const T hab = b_is_w ? Qa2 : Qa1;
-        const T hbb = b_is_w ? Q22 : Q11;
-        const T ga = ax * q0 + ay * q1, gb = b_is_w ? q2 : q1;
-        const T Za0 = ax * S00 + ay * S01, Za1 = ax * S01 + ay * S11, Za2 = ax * M02 + ay * M12;
-        const T Zb0 = b_is_w ? M02 : S01, Zb1 = b_is_w ? M12 : S11, Zb2 = b_is_w ? M22 : M12;
-        T ka = (T)0.0, kb = (T)0.0, Ka0 = (T)0.0, Ka1 = (T)0.0, Ka2 = (T)0.0, Kb0 = (T)0.0, Kb1 = (T)0.0, Kb2 = (T)0.0;
-        if (has_a && has_b) {
-          const T delta = ric_max((T)1e-6 * ric_max(ric_abs(haa), ric_abs(hbb)), (T)1e-30);
-          const T d0 = ric_pivot(haa, delta), i0 = ric_rcp(d0);
-          const T l = hab * i0;
-          const T d1 = ric_pivot(hbb - l * hab, delta), i1 = ric_rcp(d1);
-#define NEO_RIC_SOLVE2(ra_, rb_, xa_, xb_)                       \
-          {                                                        \
-            const T y0 = -(ra_), y1 = -(rb_) - l * y0;             \
-            xb_ = y1 * i1;                                         \
-            xa_ = y0 * i0 - l * xb_;                               \
-          }
-          NEO_RIC_SOLVE2(ga, gb, ka, kb)
-          NEO_RIC_SOLVE2(Za0, Zb0, Ka0, Kb0)
-          NEO_RIC_SOLVE2(Za1, Zb1, Ka1, Kb1)
-          NEO_RIC_SOLVE2(Za2, Zb2, Ka2, Kb2)
-#undef NEO_RIC_SOLVE2
-        } else if (has_a) {
-          const T i0 = -ric_rcp(ric_pivot(haa, ric_max((T)1e-6 * ric_abs(haa), (T)1e-30)));
-          ka = ga * i0; Ka0 = Za0 * i0; Ka1 = Za1 * i0; Ka2 = Za2 * i0;
-        } else if (has_b) {
-          const T i0 = -ric_rcp(ric_pivot(hbb, ric_max((T)1e-6 * ric_abs(hbb), (T)1e-30)));
-          kb = gb * i0; Kb0 = Zb0 * i0; Kb1 = Zb1 * i0; Kb2 = Zb2 * i0;
-        }
-        // back to the stage's three coordinates: k = ea ka + eb kb, K likewise
-        k0 = ax * ka; k1 = ay * ka; K00 = ax * Ka0; K01 = ax * Ka1; K02 = ax * Ka2; K10 = ay * Ka0; K11 = ay * Ka1; K12 = ay * Ka2;
-        if (b_is_w) { k2 = kb; K20 = Kb0; K21 = Kb1; K22 = Kb2; }
-        else { k1 += kb; K10 += Kb0; K11 += Kb1; K12 += Kb2; }
+        v0 = z0 + S00 * k0 + S01 * k1 + M02 * k2;
+        v1 = z1 + S01 * k0 + S11 * k1 + M12 * k2;
+        v2 = z2 + M02 * k0 + M12 * k1 + M22 * k2;
+        V00 = S00 + S00 * K00 + S01 * K10 + M02 * K20;
+        V01 = S01 + S00 * K01 + S01 * K11 + M02 * K21;
+        V02 = M02 + S00 * K02 + S01 * K12 + M02 * K22;
+        V11 = S11 + S01 * K01 + S11 * K11 + M12 * K21;
+        V12 = M12 + S01 * K02 + S11 * K12 + M12 * K22;
+        V22 = M22 + M02 * K02 + M12 * K12 + M22 * K22;
+        break;
       }
+      case RC_SLIDE_W:     // a = tangent (rtx, rty, 0), b = omega
+      case RC_XY: {        // a = x axis, b = y axis (omega frozen)
+        const bool bw = kase == RC_SLIDE_W;
+        const T ax = bw ? rtx : (T)1.0, ay = bw ? rty : (T)0.0;
+        const T Q00 = S00 + c00, Q01 = S01 + c01, Q11 = S11 + c11;
+        const T Qa0 = ax * Q00 + ay * Q01, Qa1 = ax * Q01 + ay * Q11;
+        const T haa = Qa0 * ax + Qa1 * ay;
+        const T hab = bw ? ax * (M02 + c02) + ay * (M12 + c12) : Qa1;
+        const T hbb = bw ? M22 + c22 : Q11;
+        const T ga = ax * q0 + ay * q1, gb = bw ? q2 : q1;
+        const T Za0 = ax * S00 + ay * S01, Za1 = ax * S01 + ay * S11, Za2 = ax * M02 + ay * M12;
+        const T Zb0 = bw ? M02 : S01, Zb1 = bw ? M12 : S11, Zb2 = bw ? M22 : M12;
+        const T delta = ric_max((T)1e-6 * ric_max(ric_abs(haa), ric_abs(hbb)), (T)1e-30);
+        const T d0 = ric_pivot(haa, delta), i0 = ric_rcp(d0);
+        const T l = hab * i0;
+        const T d1 = ric_pivot(hbb - l * hab, delta), i1 = ric_rcp(d1);
+        T ka, kb, Ka0, Ka1, Ka2, Kb0, Kb1, Kb2;
+#define NEO_RIC_SOLVE2(ra_, rb_, xa_, xb_)                       \
+        {                                                          \
+          const T y0 = -(ra_), y1 = -(rb_) - l * y0;               \
+          xb_ = y1 * i1;                                           \
+          xa_ = y0 * i0 - l * xb_;                                 \
+        }
+        NEO_RIC_SOLVE2(ga, gb, ka, kb)
+        NEO_RIC_SOLVE2(Za0, Zb0, Ka0, Kb0)
+        NEO_RIC_SOLVE2(Za1, Zb1, Ka1, Kb1)
+        NEO_RIC_SOLVE2(Za2, Zb2, Ka2, Kb2)
+#undef NEO_RIC_SOLVE2
+        v0 = z0 + Za0 * ka + Zb0 * kb; v1 = z1 + Za1 * ka + Zb1 * kb; v2 = z2 + Za2 * ka + Zb2 * kb;
+        V00 = S00 + Za0 * Ka0 + Zb0 * Kb0; V01 = S01 + Za0 * Ka1 + Zb0 * Kb1; V02 = M02 + Za0 * Ka2 + Zb0 * Kb2;
+        V11 = S11 + Za1 * Ka1 + Zb1 * Kb1; V12 = M12 + Za1 * Ka2 + Zb1 * Kb2; V22 = M22 + Za2 * Ka2 + Zb2 * Kb2;
+        k0 = ax * ka; k1 = ay * ka; K00 = ax * Ka0; K01 = ax * Ka1; K02 = ax * Ka2; K10 = ay * Ka0; K11 = ay * Ka1; K12 = ay * Ka2;
+        if (bw) { k2 = kb; K20 = Kb0; K21 = Kb1; K22 = Kb2; }
+        else { k1 = kb; K10 = Kb0; K11 = Kb1; K12 = Kb2; }
+        break;
+      }
+      case RC_SLIDE: {     // the tangent only (omega frozen)
+        const T Q00 = S00 + c00, Q01 = S01 + c01, Q11 = S11 + c11;
+        const T haa = (rtx * Q00 + rty * Q01) * rtx + (rtx * Q01 + rty * Q11) * rty;
+        const T i0 = -ric_rcp(ric_pivot(haa, ric_max((T)1e-6 * ric_abs(haa), (T)1e-30)));
+        const T Za0 = rtx * S00 + rty * S01, Za1 = rtx * S01 + rty * S11, Za2 = rtx * M02 + rty * M12;
+        const T ka = (rtx * q0 + rty * q1) * i0, Ka0 = Za0 * i0, Ka1 = Za1 * i0, Ka2 = Za2 * i0;
+        v0 = z0 + Za0 * ka; v1 = z1 + Za1 * ka; v2 = z2 + Za2 * ka;
+        V00 = S00 + Za0 * Ka0; V01 = S01 + Za0 * Ka1; V02 = M02 + Za0 * Ka2;
+        V11 = S11 + Za1 * Ka1; V12 = M12 + Za1 * Ka2; V22 = M22 + Za2 * Ka2;
+        k0 = rtx * ka; k1 = rty * ka; K00 = rtx * Ka0; K01 = rtx * Ka1; K02 = rtx * Ka2; K10 = rty * Ka0; K11 = rty * Ka1; K12 = rty * Ka2;
+        break;
+      }
+      case RC_W: {         // omega only (velocity pinned)
+        const T hbb = M22 + c22;
+        const T i0 = -ric_rcp(ric_pivot(hbb, ric_max((T)1e-6 * ric_abs(hbb), (T)1e-30)));
+        k2 = q2 * i0; K20 = M02 * i0; K21 = M12 * i0; K22 = M22 * i0;
+        v0 = z0 + M02 * k2; v1 = z1 + M12 * k2; v2 = z2 + M22 * k2;
+        V00 = S00 + M02 * K20; V01 = S01 + M02 * K21; V02 = M02 + M02 * K22;
+        V11 = S11 + M12 * K21; V12 = M12 + M12 * K22; V22 = M22 + M22 * K22;
+        break;
+      }
+      case RC_KINK:        // fixed step onto the kink, no feedback
+        k0 = e0; k1 = e1; k2 = e2;
+        v0 = z0 + S00 * k0 + S01 * k1 + M02 * k2;
+        v1 = z1 + S01 * k0 + S11 * k1 + M12 * k2;
+        v2 = z2 + M02 * k0 + M12 * k1 + M22 * k2;
+        V00 = S00; V01 = S01; V02 = M02; V11 = S11; V12 = M12; V22 = M22;
+        break;
+      default:             // RC_NONE: nothing moves
+        v0 = z0; v1 = z1; v2 = z2;
+        V00 = S00; V01 = S01; V02 = M02; V11 = S11; V12 = M12; V22 = M22;
+        break;
     }
-    // v = Qz + Quz^T k, V = Qzz + Quz^T K (K spans the face only -- all zero for a block sent onto the kink;
-    // upper triangle, symmetric in exact arithmetic)
-    v0 = z0 + S00 * k0 + S01 * k1 + M02 * k2;
-    v1 = z1 + S01 * k0 + S11 * k1 + M12 * k2;
-    v2 = z2 + M02 * k0 + M12 * k1 + M22 * k2;
-    V00 = S00 + S00 * K00 + S01 * K10 + M02 * K20;
-    V01 = S01 + S00 * K01 + S01 * K11 + M02 * K21;
-    V02 = M02 + S00 * K02 + S01 * K12 + M02 * K22;
-    V11 = S11 + S01 * K01 + S11 * K11 + M12 * K21;
-    V12 = M12 + S01 * K02 + S11 * K12 + M12 * K22;
-    V22 = M22 + M02 * K02 + M12 * K12 + M22 * K22;
     if (lane == 0) {   // the gains take the place of the stage's linear terms
       ric_f4* G4 = reinterpret_cast<ric_f4*>(RS + kRicStage * i + RS_GAIN);
       G4[0] = ric_f4{(float)K00, (float)K01, (float)K02, (float)K10};

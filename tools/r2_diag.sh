@@ -1,6 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out
 {
-timeout 300 python tools/diag_direction.py --steps 8 --iteration 1 --count 32
-} > gpurun_out/r2_diag10.log 2>&1
-cat gpurun_out/r2_diag10.log
+for w in C5 C3; do echo "== phase timing $w"; NEO_MPC_LIB=$PWD/neo_mpc_planner2_amd/libneo_mpc_timing.so timeout 300 python tools/phase_timing.py $w; done
+} > gpurun_out/r2_phase2.log 2>&1
+cat gpurun_out/r2_phase2.log
