@@ -287,6 +287,23 @@ int neo_mpc_select_carrots(neo_mpc_handle* handle, const neo_mpc_lookahead_param
 int neo_mpc_select_carrots_device(neo_mpc_handle* handle, const neo_mpc_lookahead_params* params,
                                   const neo_mpc_plan_batch* batch, void* stream);
 
+/* ---- multi-GPU fleets: the one exchange step ------------------------------------------------
+ * Instances of one tick shard embarrassingly over the GPUs of a node (one handle per GPU, costmap and parameters
+ * replicated, per-instance state resident on its GPU); what `computeVelocityCommands` returns for every robot
+ * (cpp:251-254) is collected with ONE all-gather of the packed `neo_mpc_batch.velocities` over RCCL (xGMI).
+ * `comm` is an ncclComm_t of the caller's, or one made by neo_mpc_comm_init_all (a single process driving all
+ * devices: bracket the per-device calls with neo_mpc_group_start / neo_mpc_group_end).  RCCL is bound at run time;
+ * without librccl.so these return NEO_MPC_ERR_UNSUPPORTED and everything else keeps working.  No torch types. */
+int neo_mpc_rccl_available(void);
+int neo_mpc_comm_init_all(int ndev, const int* devices, void** comms_out);   /* ncclCommInitAll */
+int neo_mpc_comm_destroy(void* comm);
+int neo_mpc_group_start(void);
+int neo_mpc_group_end(void);
+/* d_local[count][3] of this rank -> d_all[world][count][3] on every rank, enqueued on `stream` (hipStream_t). */
+int neo_mpc_allgather_velocities(const double* d_local, double* d_all, size_t count, void* comm, void* stream);
+/* One-off: rank `root`'s raw costmap cells to every rank (in place), then neo_mpc_set_costmap_device per rank. */
+int neo_mpc_broadcast_costmap(uint8_t* d_cells, size_t bytes, int root, void* comm, void* stream);
+
 /* Bytes of LDS and costmap reach (cells) the solve kernel uses with the current params/map. */
 int neo_mpc_kernel_info(const neo_mpc_handle* handle, uint32_t* lds_bytes, uint32_t* reach_cells,
                         uint32_t* tile_in_lds);

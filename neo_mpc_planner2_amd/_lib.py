@@ -23,6 +23,8 @@ EXPORTS = (
     "neo_mpc_postprocess_batch", "neo_mpc_objective_batch", "neo_mpc_gradient_batch", "neo_mpc_direction_batch",
     "neo_mpc_kernel_info",
     "neo_mpc_select_carrots", "neo_mpc_select_carrots_device",
+    "neo_mpc_rccl_available", "neo_mpc_comm_init_all", "neo_mpc_comm_destroy", "neo_mpc_group_start",
+    "neo_mpc_group_end", "neo_mpc_allgather_velocities", "neo_mpc_broadcast_costmap",
 )
 
 _lib = None

@@ -33,6 +33,19 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+}  // namespace
+// (shared with neo_mpc_rccl.cpp)
+int neo_mpc_set_error(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_error = buf;
+  return code;
+}
+namespace {
+
 #define HIP_TRY(expr)                                                                   \
   do {                                                                                  \
     hipError_t e_ = (expr);                                                             \

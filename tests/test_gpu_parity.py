@@ -523,3 +523,23 @@ def test_c3_c5_full_size_properties(solver_mod, name):
     moving = (cmds["flags"] & abi.FLAG_STOPPED) == 0
     dv = np.abs(cmds["vel"] - probs["cur_vel"])[moving]
     assert (dv <= np.array([2.5, 2.5, 3.0]) / 30.0 + 1e-12).all()
+
+
+def test_fleet_allgather_example_through_the_c_abi(tmp_path):
+    """examples/fleet_allgather.cpp: the multi-GPU tick of SURVEY 8e from C++ through the C-ABI alone -- one handle,
+    stream and RCCL communicator per visible GPU, block-partitioned instances, ONE all-gather of the packed
+    commands (neo_mpc_allgather_velocities, RCCL bound at run time) -- verified against the per-GPU results."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "fleet"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "fleet_allgather.cpp"),
+                           "-L", os.path.join(root, "neo_mpc_planner2_amd"), "-lneo_mpc",
+                           "-Wl,-rpath," + os.path.join(root, "neo_mpc_planner2_amd"), "-o", str(exe)])
+    out = subprocess.run([str(exe), "2048"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.returncode, out.stdout[-500:], out.stderr[-800:])
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["gathered_equals_local"] is True and rec["n_gpus"] >= 1 and rec["max_speed"] <= 0.7 + 1e-9
+    print(rec)

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""Parity report of the HIP solver against the reference's SciPy path (SURVEY.md §8c tiers
-P2-P4), printed as text.  Runs on the GPU box; uses tests/golden/g3_solves.npz (SLSQP solves of
-the REFERENCE's objective at ftol 1e-3 and 1e-12, cold start).
+"""Parity report of the HIP solver against the reference's SciPy path (SURVEY.md §8c tiers P2-P4), printed as
+text.  Runs on the GPU box; uses tests/golden/g3_solves.npz (SLSQP solves of the REFERENCE's objective at
+ftol 1e-3 and 1e-12, cold start, control_steps 3 / 8 / 32) and the G4 episodes (the reference's own warm
+starts on real costmaps).  Every distribution is given twice: on the raw first control u0 and on the COMMAND
+the robot receives (after the low-pass and the acceleration clamp of py:366-367, 383-391, with last_control =
+the current velocity) -- K2 applied to the build's x and, through the oracle's wrapper, to SLSQP's x.
 
     python tools/parity_report.py > profiles/rNN_parity_report.txt
 """
@@ -13,8 +16,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from neo_mpc_planner2_amd import synthetic  # noqa: E402
+from neo_mpc_planner2_amd import abi, synthetic  # noqa: E402
 from neo_mpc_planner2_amd.solver import BatchSolver  # noqa: E402
+from oracle import c_oracle  # noqa: E402
 from tests import util  # noqa: E402
 
 
@@ -22,33 +26,85 @@ def pct(a):
     return "median %.2e  p90 %.2e  p99 %.2e  max %.2e" % (np.median(a), np.percentile(a, 90), np.percentile(a, 99), a.max())
 
 
-def main():
+def command_of(params, cmap, pr, x):
+    """the reference's post-filter (py:365-403) applied to a raw solver output, mid-episode state"""
+    st, warm = synthetic.make_states(pr, params["control_steps"])
+    cmds, _, _ = c_oracle.postprocess_batch(params, cmap, pr, st, warm, x.copy())
+    return cmds["vel"]
+
+
+def cold_starts():
     g = util.load("g3_solves.npz")
-    params = util.params_from(g["param_keys"], g["params"])
-    probs = util.problems_from(g["problems"])
-    hm = g["has_map"].astype(bool)
     print("# HIP solver vs SciPy SLSQP on the reference objective (%s)" % str(g["versions"]))
-    for name, mask, cells in (("zero costmap (unique minimiser)", ~hm, np.zeros_like(g["cells"])),
-                              ("synthetic costmap (local minima)", hm, g["cells"])):
-        cmap = (cells,) + tuple(g["map_meta"])
-        pr = probs[mask]
-        st, warm = synthetic.make_states(pr, 3)
+    for n in (3, 8, 32):
+        k = "" if n == 3 else "n%d_" % n
+        params = util.params_from(g["param_keys"], g[k + "params"])
+        probs = util.problems_from(g[k + "problems"])
+        hm = g[k + "has_map"].astype(bool)
+        for name, mask, cells in (("zero costmap (unique minimiser)", ~hm, np.zeros_like(g[k + "cells"])),
+                                  ("synthetic costmap (local minima)", hm, g[k + "cells"])):
+            cmap = (cells,) + tuple(g[k + "map_meta"])
+            pr = probs[mask]
+            st, warm = synthetic.make_states(pr, n)
+            with BatchSolver(params) as s:
+                s.set_costmap(*cmap)
+                cmds, x = s.solve(pr, st, warm)
+            xt, xl = g[k + "x_tight"][mask], g[k + "x_loose"][mask]
+            ok = g[k + "status_tight"][mask] == 0
+            du_t = np.abs(x[:, :3] - xt[:, :3]).max(axis=1)
+            du_l = np.abs(x[:, :3] - xl[:, :3]).max(axis=1)
+            ref_ll = np.abs(xl[:, :3] - xt[:, :3]).max(axis=1)
+            c_b, c_t, c_l = cmds["vel"], command_of(params, cmap, pr, xt), command_of(params, cmap, pr, xl)
+            dc_t, dc_l, dc_ref = (np.abs(c_b - c_t).max(axis=1), np.abs(c_b - c_l).max(axis=1), np.abs(c_l - c_t).max(axis=1))
+            print("\n## control_steps %d, %s, %d cold-start problems (SLSQP ftol=1e-12 reached status 0 on %d)"
+                  % (n, name, mask.sum(), ok.sum()))
+            print("P2  |u0 - u0(SLSQP ftol=1e-12)|_inf      : %s" % pct(du_t))
+            print("    ... on the command                   : %s" % pct(dc_t))
+            print("P3  f - f(SLSQP ftol=1e-3)               : max %.3e  (bar: <= 1e-3)   f - f(SLSQP 1e-12): max %.3e min %.3e"
+                  % ((cmds["cost"] - g[k + "f_loose"][mask]).max(), (cmds["cost"] - g[k + "f_tight"][mask]).max(),
+                     (cmds["cost"] - g[k + "f_tight"][mask]).min()))
+            print("P4  |u0 - u0(SLSQP ftol=1e-3)|_inf       : %s" % pct(du_l))
+            print("    ... on the command                   : %s" % pct(dc_l))
+            print("    reference vs itself, |u0(SLSQP 1e-3) - u0(SLSQP 1e-12)|_inf : %s" % pct(ref_ll))
+            print("    ... on the command                   : %s" % pct(dc_ref))
+            print("    iterations: mean %.1f max %d; converged %d/%d (status 1 = iteration cap: %d); SLSQP@1e-3: nit mean %.1f"
+                  % (cmds["iterations"].mean(), cmds["iterations"].max(), (cmds["status"] == 0).sum(), len(cmds),
+                     (cmds["status"] == 1).sum(), g[k + "nit_loose"][mask].mean()))
+
+
+def warm_starts():
+    print("\n# warm starts: every call of the reference's recorded episodes (G4) solved from the reference's own state")
+    for fixture in ("g4_episodes.npz", "g4_episodes_n8.npz"):
+        g = util.load(fixture)
+        params = util.params_from(g["param_keys"], g["params"])
+        n = params["control_steps"]
+        cmap = (g["cells"],) + tuple(g["map_meta"])
+        probs = util.problems_from(g["problems"])
+        n_ep, n_calls = probs.shape
+        states, warm = abi.new_states(n_ep, n)
+        df, dcmd, its = [], [], []
         with BatchSolver(params) as s:
             s.set_costmap(*cmap)
-            cmds, x = s.solve(pr, st, warm)
-        du_t = np.abs(x[:, :3] - g["x_tight"][mask][:, :3]).max(axis=1)
-        du_l = np.abs(x[:, :3] - g["x_loose"][mask][:, :3]).max(axis=1)
-        ref_ll = np.abs(g["x_loose"][mask][:, :3] - g["x_tight"][mask][:, :3]).max(axis=1)
-        print("\n## %s, %d cold-start problems" % (name, mask.sum()))
-        print("P2  |u0 - u0(SLSQP ftol=1e-12)|_inf : %s" % pct(du_t))
-        print("P3  f - f(SLSQP ftol=1e-3)          : max %.3e  (bar: <= 1e-3)   f - f(SLSQP 1e-12): max %.3e min %.3e"
-              % ((cmds["cost"] - g["f_loose"][mask]).max(), (cmds["cost"] - g["f_tight"][mask]).max(),
-                 (cmds["cost"] - g["f_tight"][mask]).min()))
-        print("P4  |u0 - u0(SLSQP ftol=1e-3)|_inf  : %s" % pct(du_l))
-        print("    reference vs itself, |u0(SLSQP 1e-3) - u0(SLSQP 1e-12)|_inf : %s" % pct(ref_ll))
-        print("    iterations: mean %.1f max %d; converged %d/%d" % (cmds["iterations"].mean(), cmds["iterations"].max(),
-                                                                   (cmds["status"] == 0).sum(), len(cmds)))
+            for k in range(n_calls):
+                fp = g["footprint"][:, k]
+                rows = probs[:, k].copy()
+                has = ~np.isnan(fp).any(axis=(1, 2))
+                rows["footprint_cost"] = 0.0
+                if has.any():
+                    rows["footprint_cost"][has] = c_oracle.footprint_cost_batch(cmap, fp[has])
+                cmds, x = s.solve(rows, states.copy(), warm.copy())
+                df.append(cmds["cost"] - s.objective(rows, g["raw_x"][:, k]))
+                moving = ~(g["collision"][:, k] | g["collision_footprint"][:, k])
+                dcmd.append(np.where(moving, np.abs(cmds["vel"] - g["out"][:, k]).max(axis=1), 0.0))
+                its.append(cmds["iterations"])
+                s.postprocess(rows, states, warm, g["raw_x"][:, k], g["success"][:, k])
+        df, dcmd, its = np.array(df), np.array(dcmd), np.array(its)
+        print("\n## control_steps %d: %d calls" % (n, df.size))
+        print("P3  f(build) - f(reference raw x.x)      : max %.3e  median %.3e  (bar: <= 1e-3)" % (df.max(), np.median(df)))
+        print("P4  |command - reference command|_inf    : %s   (calls not stopped by the collision latch)" % pct(dcmd.ravel()))
+        print("    iterations: mean %.1f max %d" % (its.mean(), its.max()))
 
 
 if __name__ == "__main__":
-    main()
+    cold_starts()
+    warm_starts()

@@ -1,5 +1,5 @@
 #!/bin/bash
-# one gpurun call: GPU tests, the default bench line, rocprofv3 evidence for C2 / C3 / C5 and K3
+# one gpurun call: GPU tests, the default bench line, rocprofv3 evidence for C2 / C3 / C5 and K3, parity report
 # usage: bash tools/r2_profile.sh <tag>
 TAG=${1:-r02a}
 O=gpurun_out/final_$TAG
@@ -10,9 +10,19 @@ timeout 900 bash tools/profile_all.sh $TAG C2 50 > $O/profile_c2.txt 2>&1
 timeout 900 bash tools/profile_all.sh $TAG C3 4 > $O/profile_c3.txt 2>&1
 timeout 900 bash tools/profile_all.sh $TAG C5 4 > $O/profile_c5.txt 2>&1
 timeout 600 bash tools/profile_k3.sh $TAG > $O/profile_k3.txt 2>&1
+timeout 900 python tools/parity_report.py > $O/parity_report.txt 2>&1
 {
   timeout 300 python bench.py --workload C3 --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1
   timeout 300 python bench.py --workload C4 --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1
   timeout 300 python bench.py --workload C5 --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1
+  timeout 120 python tools/bench_tick_latency.py 2>/dev/null | tail -1
 } > $O/other_configs.jsonl
-cat $O/gpu_tests.log; cat $O/bench_c2.json; tail -30 $O/profile_c2.txt; tail -8 $O/profile_c3.txt; tail -8 $O/profile_c5.txt; cat gpurun_out/prof_${TAG}_k3/k3.txt; cat $O/other_configs.jsonl
+cat $O/gpu_tests.log; cat $O/bench_c2.json; grep -v amdgpu $O/parity_report.txt
+python - <<PY
+import json
+for l in open("$O/other_configs.jsonl"):
+    try: d=json.loads(l)
+    except Exception: continue
+    if "config" in d: print(d["config"]["workload"][:40], "| %.4g solves/s | kernel %.3f ms | iters %.2f" % (d["value"], d["roofline"]["kernel_ms"], d["solver"]["mean_iterations"]))
+    else: print(l.strip()[:300])
+PY
