@@ -85,7 +85,10 @@ constexpr LdsLayout make_lds_layout(int n, int mem, bool riccati) {
   l.gs = off; off += nv;
   l.gt = off; off += nv;
   l.gr = off; off += nv;
-  l.d = off; off += nv;
+  // (Riccati: the direction takes the place of the total gradient -- the sweep has consumed it before the
+  // forward pass writes d, and the next tangent-cone pass rewrites it after the candidates have read d)
+  if (riccati) l.d = l.gt;
+  else { l.d = off; off += nv; }
   if (riccati) {
     // the Riccati kernel keeps no previous iterate / gradient and no quasi-Newton pairs; the winner is
     // staged where the reduced gradient lived (disjoint lifetimes inside an iteration); of the per-step

@@ -480,7 +480,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
 #ifdef NEO_MPC_RICCATI_F64   // (study build: the same recursion in float64 on the float32 records)
       riccati_sweep<double>(a, L, n, lane);
 #else
-      riccati_sweep<float>(a, L, n, lane);
+      riccati_sweep<float, (kMinWavesPerSimd < 4)>(a, L, n, lane);
 #endif
       riccati_finish(a, c, L, n, lane);
     } else if (kNewton) {
@@ -1020,7 +1020,9 @@ void launch_solve(const SolveArgs& a, void* stream, void* ev_start, void* ev_sto
   } else if (a.p.n == 3 && a.p.newton == 0 && !generic) {
     NEO_LAUNCH_W(solve_variant(3), 3);
   } else if (a.p.newton == 2) {  // any control_steps: Newton direction by the Riccati sweep (riccati.h)
-    const int w = solve_variant(3);   // (167 VGPRs: spill-free at 3 waves/SIMD)
+    // 4 waves/SIMD where LDS allows 16 workgroups per CU (control_steps <= ~20), else 3 (measured at
+    // control_steps 8: +7 % with 4; at 32, where LDS caps the CU at 12 workgroups, 3 is the faster build)
+    const int w = solve_variant(lds <= 10 * 1024 ? 4 : 3);
     if (disc) NEO_LAUNCH_W(w, 0, 2, true);
     else NEO_LAUNCH_W(w, 0, 2);
   } else if (a.p.newton == 1) {  // control_steps <= kNewtonMaxSteps, dense system with run-time size

@@ -123,7 +123,9 @@ __device__ __forceinline__ void riccati_prepare(const SolveArgs& a, const Ctx& c
 // Backward + forward sweep in displacement coordinates, wave-uniform.  The record of stage i - 1 is fetched
 // (seven 16-byte LDS reads) while stage i is worked on: nothing in it depends on the recursion.  Output: w_i
 // in d (float64 slots), and per block tokink (AMODE slot 3): the stage model's minimiser is the kink itself.
-template <typename T>
+// kPrefetch: fetch the next stage's record one stage ahead (28 more live registers: the 4-waves/SIMD build
+// reads each record when it needs it instead)
+template <typename T, bool kPrefetch = true>
 __device__ __forceinline__ void riccati_sweep(const SolveArgs& a, double* L, int n, int lane) {
   const DevParams& p = a.p;
   float* RS = static_cast<float*>(__builtin_assume_aligned(reinterpret_cast<float*>(L + a.lds.ric), 16));
@@ -135,18 +137,22 @@ __device__ __forceinline__ void riccati_sweep(const SolveArgs& a, double* L, int
 
   T V00 = (T)0.0, V01 = (T)0.0, V02 = (T)0.0, V11 = (T)0.0, V12 = (T)0.0, V22 = (T)0.0, v0 = (T)0.0, v1 = (T)0.0, v2 = (T)0.0;
   ric_f4 r0, r1, r2, r3, r4, r5, r6;
-  {
+  if (kPrefetch) {
     const ric_f4* R4 = reinterpret_cast<const ric_f4*>(RS + kRicStage * (n - 1));
     r0 = R4[0]; r1 = R4[1]; r2 = R4[2]; r3 = R4[3]; r4 = R4[4]; r5 = R4[5]; r6 = R4[6];
   }
   for (int i = n - 1; i >= 0; --i) {
+    if (!kPrefetch) {
+      const ric_f4* R4 = reinterpret_cast<const ric_f4*>(RS + kRicStage * i);
+      r0 = R4[0]; r1 = R4[1]; r2 = R4[2]; r3 = R4[3]; r4 = R4[4]; r5 = R4[5]; r6 = R4[6];
+    }
     // this stage's record (registers), the next one on its way
     const T px = r0.x, py = r0.y, rtx = r0.z, rty = r0.w;
     const T wxx = r1.x, wxy = r1.y, wyy = r1.z;
     const int flags = __builtin_amdgcn_readfirstlane((int)r1.w);   // (wave-uniform: scalar branches below)
     const T c00 = r2.x, c01 = r2.y, c02 = r2.z, c11 = r2.w, c12 = r3.x, c22 = r3.y;
     const T gt0 = r4.x, gt1 = r4.y, gt2 = r4.z, gs0 = r4.w, gs1 = r5.x, gs2 = r5.y, e0 = r5.z, e1 = r5.w, e2 = r6.x;
-    if (i > 0) {
+    if (kPrefetch && i > 0) {
       const ric_f4* R4 = reinterpret_cast<const ric_f4*>(RS + kRicStage * (i - 1));
       r0 = R4[0]; r1 = R4[1]; r2 = R4[2]; r3 = R4[3]; r4 = R4[4]; r5 = R4[5]; r6 = R4[6];
     }
