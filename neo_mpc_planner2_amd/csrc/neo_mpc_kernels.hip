@@ -1020,9 +1020,10 @@ void launch_solve(const SolveArgs& a, void* stream, void* ev_start, void* ev_sto
   } else if (a.p.n == 3 && a.p.newton == 0 && !generic) {
     NEO_LAUNCH_W(solve_variant(3), 3);
   } else if (a.p.newton == 2) {  // any control_steps: Newton direction by the Riccati sweep (riccati.h)
-    // 4 waves/SIMD where LDS allows 16 workgroups per CU (control_steps <= ~20), else 3 (measured at
-    // control_steps 8: +7 % with 4; at 32, where LDS caps the CU at 12 workgroups, 3 is the faster build)
-    const int w = solve_variant(lds <= 10 * 1024 ? 4 : 3);
+    // the 128-VGPR build (4 waves/SIMD) wherever LDS lets a CU hold more than 12 workgroups -- 13 need <= 12.3 KB
+    // each -- else the 168-VGPR build (measured: control_steps 8, 16 workgroups/CU: +17 %; control_steps 32 at
+    // 11.3 KB = 14 workgroups/CU: +9 %; with 12 workgroups/CU the 4-wave build's spills make it 4 % slower)
+    const int w = solve_variant(lds <= 12600 ? 4 : 3);
     if (disc) NEO_LAUNCH_W(w, 0, 2, true);
     else NEO_LAUNCH_W(w, 0, 2);
   } else if (a.p.newton == 1) {  // control_steps <= kNewtonMaxSteps, dense system with run-time size

@@ -23,6 +23,7 @@ import json
 for l in open("$O/other_configs.jsonl"):
     try: d=json.loads(l)
     except Exception: continue
-    if "config" in d: print(d["config"]["workload"][:40], "| %.4g solves/s | kernel %.3f ms | iters %.2f" % (d["value"], d["roofline"]["kernel_ms"], d["solver"]["mean_iterations"]))
+    if isinstance(d, dict) and isinstance(d.get("config"), dict) and "workload" in d["config"]:
+        print(d["config"]["workload"][:40], "| %.4g solves/s | kernel %.3f ms | iters %.2f" % (d["value"], d["roofline"]["kernel_ms"], d["solver"]["mean_iterations"]))
     else: print(l.strip()[:300])
 PY
