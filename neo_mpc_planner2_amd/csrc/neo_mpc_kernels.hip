@@ -213,7 +213,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   // this lane's step multiplier: the one lane-derived constant worth two registers for the whole loop
   // (half of the table sits in constant memory: re-reading it would put a global load on every
   // iteration's critical path)
-  const double my_scale = lane_scale(lane);
+  const double my_scale = kRiccati ? 0.0 : lane_scale(lane);
   for (it = 0; it < p.max_it; ++it) {
     // The lane index is re-read opaquely every iteration: otherwise the compiler hoists two dozen
     // lane-derived constants (step multipliers, compare masks, LDS addresses) out of the loop and,
@@ -703,8 +703,11 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       return;
     }
     // ---- 64 candidates, one rollout per lane; lowest objective wins
-    const double pstep = alpha * my_scale;
-    const double step = lane < 32 ? pstep : my_scale;
+    // (run-time-sized Riccati kernel: the multiplier is re-read here -- one constant-memory load per iteration
+    // against 2 x control_steps stages of work, and two registers fewer across the sweep)
+    const double lscale = kRiccati ? lane_scale(lane) : my_scale;
+    const double pstep = alpha * lscale;
+    const double step = lane < 32 ? pstep : lscale;
     double fc = rollout_cost<kSteps, kTame>(
         a, c, L,
         [&](int i, double& b0, double& b1, double& b2) {
