@@ -385,7 +385,10 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       if (ne < TOL[T_KINK]) {  // next to the kink: prox-only block, outside the quasi-Newton model
         gt[3 * i] = 0.0; gt[3 * i + 1] = 0.0; gt[3 * i + 2] = 0.0;
         gr[3 * i] = 0.0; gr[3 * i + 1] = 0.0; gr[3 * i + 2] = 0.0;
-        ANX[i] = 0.0; ANY[i] = 0.0; AMODE[4 * i] = 0; AMODE[4 * i + 1] = 0; AMODE[4 * i + 2] = 1;
+        // (2: exactly ON the kink with a smooth gradient inside the norm's subdifferential, |g_s| <= w_control/N --
+        // the block stays there under every proximal step: at rest, it does not hold up the Newton stop tests)
+        const int at_rest = (ne2 == 0.0 && g0 * g0 + g1 * g1 + g2 * g2 <= p.wc_n * p.wc_n) ? 2 : 1;
+        ANX[i] = 0.0; ANY[i] = 0.0; AMODE[4 * i] = 0; AMODE[4 * i + 1] = 0; AMODE[4 * i + 2] = at_rest;
         if (kNewton) {
 #pragma unroll
           for (int k = 0; k < kNewtonRecord; ++k) NB[kNewtonRecord * i + k] = 0.0f;  // P = 0: row/column of I
@@ -686,9 +689,9 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         for (int k = lane; k < nv; k += kLanes) {
           const float v = (float)fabs(d[k]);
           dm = (v == v) ? fmaxf(dm, v) : INFINITY;
-          anynear |= AMODE[4 * (k / 3) + 2];
+          anynear |= (AMODE[4 * (k / 3) + 2] == 1);
         }
-      } else if (lane < nvr) { dm = fabsf(newton_sol); anynear = AMODE[4 * (lane / 3) + 2]; }   // (d[lane], still in a register)
+      } else if (lane < nvr) { dm = fabsf(newton_sol); anynear = (AMODE[4 * (lane / 3) + 2] == 1); }   // (d[lane], still in a register)
       dm = wave_max_f(dm);
       const bool near_any = __ballot(anynear != 0) != 0ull;
       if ((double)dm < TOL[T_EARLY] && !near_any) { status = NEO_MPC_STATUS_CONVERGED; break; }

@@ -356,6 +356,7 @@ typedef struct orc_active {
   double lambda[ORC_MAXN]; /* mode 1: n . (-g) > 0, the multiplier estimate of the binding constraint */
   uint8_t tokink[ORC_MAXN]; /* Riccati direction: the stage model's minimiser is the kink itself (d_i = v - u_i) */
   int riccati;              /* the Riccati kernel's candidate rules apply (per-block prox step) */
+  uint8_t rest[ORC_MAXN];   /* near block exactly on the kink whose smooth gradient keeps it there */
 } orc_active;
 
 
@@ -377,6 +378,10 @@ static void orc_reduce(const orc_ctx* c, const double* u, const double* gs, doub
     }
     for (int k = 0; k < 3; ++k) { gt[3 * i + k] = gi[k]; gr[3 * i + k] = gi[k]; }
     a->near[i] = ne < c->kink_radius;
+    /* a block sitting exactly ON the kink with a smooth gradient inside the norm's subdifferential
+     * (|g_s| <= w_control/N) stays there under every proximal step: it is at rest */
+    a->rest[i] = a->near[i] && ne == 0.0 &&
+                 gsi[0] * gsi[0] + gsi[1] * gsi[1] + gsi[2] * gsi[2] <= c->wc_n * c->wc_n;
     if (a->near[i]) {
       for (int k = 0; k < 3; ++k) { gt[3 * i + k] = 0.0; gr[3 * i + k] = 0.0; }
       a->wfroz[i] = 0; a->mode[i] = 0; a->nx[i] = 0.0; a->ny[i] = 0.0; a->disc[i] = 0; a->lambda[i] = 0.0;
@@ -988,6 +993,8 @@ static void orc_candidate(const orc_ctx* c, const orc_active* act, int lane, dou
 static int orc_capture_it = -1;
 static double* orc_capture_d = NULL;
 void orc_capture_direction(int it, double* d_out) { orc_capture_it = it; orc_capture_d = d_out; }
+static int orc_rest_rule = 1;
+void orc_set_rest_rule(int on) { orc_rest_rule = on; }
 static int orc_trace = 0;
 void orc_set_trace(int on) { orc_trace = on; }
 
@@ -1058,7 +1065,9 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
         double dm = 0.0;
         int anynear = 0;
         for (int k = 0; k < nv; ++k) dm = fmax(dm, fabs(d[k]));
-        for (int i = 0; i < n; ++i) anynear |= act.near[i];
+        /* (blocks next to the kink are moved by the prox step, which d does not describe -- unless they are at
+         * rest on it) */
+        for (int i = 0; i < n; ++i) anynear |= act.near[i] && !(orc_rest_rule && act.rest[i]);
         if (dm < xtol && !anynear) { status = NEO_MPC_STATUS_CONVERGED; break; }
         /* a full Newton step below opt_tolerance (SLSQP's own step test) is the last one: it is
          * searched and taken like any other, but nothing re-checks the point it lands on (the

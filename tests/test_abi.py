@@ -135,3 +135,39 @@ def test_plugin_seam_example_compiles_and_links(tmp_path):
                            "-Wl,-rpath," + os.path.join(ROOT, "neo_mpc_planner2_amd"),
                            "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
     assert subprocess.call([str(exe)]) == 0
+
+
+def test_bench_refuses_to_run_more_ranks_than_devices():
+    """`python bench.py --gpus N` without a launcher spawns its own N ranks -- and says so loudly when the node has
+    fewer devices (here: none) instead of quietly running on one."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode != 0 and "HIP device(s) visible" in (out.stderr + out.stdout)
+
+
+def test_cb_params_accepts_rclpy_style_enum_types():
+    """rclpy's Parameter.Type is a plain Enum (DOUBLE.value == 3), not an int: such parameters must be applied
+    (py:407 compares against the enum member), integers and other types skipped."""
+    import enum
+    from types import SimpleNamespace as NS
+    from neo_mpc_planner2_amd import mpc_optimization_server as srv
+
+    class Type(enum.Enum):
+        INTEGER = 2
+        DOUBLE = 3
+
+    node = object.__new__(srv.MpcOptimizationServer)      # no GPU needed: only cb_params' bookkeeping
+    node.reference_quirks = True
+    node._params = dict(srv.README_PARAMS)
+    applied = {}
+    node._solver = NS(set_params=lambda **kw: applied.update(kw))
+    node.cb_params([NS(name="w_trans", value=0.4, type_=Type.DOUBLE), NS(name="w_orient", value=7, type_=Type.INTEGER),
+                    NS(name="w_control", value=0.2, type_=3)])
+    assert node.w_trans == 0.4 and node.w_control == 0.2 and not hasattr(node, "w_orient")
+    assert applied == {"w_trans": 0.4, "w_control": 0.2}

@@ -416,3 +416,32 @@ def test_device_entry_point_can_be_captured_in_a_hip_graph():
             a, b = graphed.commands_host(), direct.commands_host()
             assert (a["iterations"] == b["iterations"]).all() and (a["vel"] == b["vel"]).all(), tick
         assert (graphed.states_host()["has_old_goal"] == 1).all()
+
+
+def test_pool_larger_than_one_ingest_launch_and_bad_footprints_are_refused():
+    """K3 takes the map index from the grid's y coordinate: a pool of more than 65 535 maps is refused with
+    NEO_MPC_ERR_UNSUPPORTED (not a generic launch failure); a non-finite footprint vertex is refused on the host
+    (its rasterisation would walk billions of cells)."""
+    import ctypes as C
+    from neo_mpc_planner2_amd import _lib
+    from neo_mpc_planner2_amd.solver import BatchSolver
+    lib = _lib.load()
+    with BatchSolver(util.orc.make_params()) as s:
+        cells = np.zeros((2, 8, 8), dtype=np.uint8)
+        orig = np.zeros((70000, 2))
+        rc = lib.neo_mpc_set_costmap_pool(s._handle, C.c_void_p(cells.ctypes.data), 70000, 8, 8, 0.05,
+                                          C.c_void_p(orig.ctypes.data))
+        assert rc == -5 and b"65535" in lib.neo_mpc_last_error()
+        cmap = synthetic.make_costmap(200, seed=1)
+        s.set_costmap(*cmap)
+        probs = synthetic.make_problems(100, 200, seed=2)
+        st, warm = synthetic.make_states(probs, 3)
+        fps = np.array([synthetic.footprint_world(r) for r in probs])
+        fps[57, 2, 1] = np.inf
+        with pytest.raises(_lib.NeoMpcError) as e:
+            s.solve(probs, st, warm, footprints=fps)
+        assert e.value.code == -1 and "not finite" in str(e.value)
+        # a vertex far outside the map is fine: the outline's cost is decided (lethal) without walking to it
+        fps[57, 2, 1] = 1e12
+        cmds, _ = s.solve(probs, st, warm, footprints=fps)
+        assert st["collision_footprint"][57] == 1 and (cmds["vel"][57] == 0.0).all()
