@@ -167,12 +167,15 @@ void derive(neo_mpc_handle* h) {
              : (n == 3 ? 1 : 2);
   d.early_tol = getenv("NEO_MPC_NO_EARLY") ? 0.0 : d.xtol;
   d.final_tol = getenv("NEO_MPC_NO_EARLY") ? 0.0 : (p.step_tolerance > 0.0 ? p.step_tolerance : p.opt_tolerance);
-  d.ftol = p.cost_tolerance > 0.0 ? p.cost_tolerance : (d.newton ? 3e-4 : 3e-6) * p.opt_tolerance;
-  // (beyond 8 control steps the objective is flatter per block -- the weights are divided by N: the
-  // window shrinks with (8/N)^2, measured on the control_steps 32 reference solves)
-  const double wscale = n > 8 ? (8.0 / n) * (8.0 / n) : 1.0;
+  // Beyond 3 control steps the objective is flatter per block (the weights are divided by N, and two neighbouring
+  // blocks of a long horizon can trade displacement at almost no cost): the gain thresholds of the Newton
+  // directions shrink with (3/N)^2 (the three-iteration window with (3/N)^3) -- measured on 1024 zero-costmap problems against solves run to the end
+  // (tools/parity_report.py): with the control_steps-3 thresholds 59 first controls at N = 32 (7 at 16, 2 at 8) end
+  // more than 1e-3 away (max 0.09, objective within 1e-4), with the scaled ones none, for 8 % more iterations at 32.
+  const double flat = (d.newton && n > 3) ? (3.0 / n) * (3.0 / n) : 1.0;
+  d.ftol = p.cost_tolerance > 0.0 ? p.cost_tolerance : (d.newton ? 3e-4 * flat : 3e-6) * p.opt_tolerance;
   d.wtol = p.window_tolerance > 0.0 ? p.window_tolerance
-           : (p.window_tolerance == 0.0 && d.newton) ? 3e-3 * p.opt_tolerance * wscale : 0.0;
+           : (p.window_tolerance == 0.0 && d.newton) ? 3e-3 * p.opt_tolerance * flat * fmin(1.0, 3.0 / n) : 0.0;
 
   // LDS carve-up (shared with the kernel specialisations) + reach tile geometry
   LdsLayout& l = h->lds;

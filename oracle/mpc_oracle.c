@@ -1016,7 +1016,13 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
   const int newton = riccati || (p->method != NEO_MPC_METHOD_LBFGS && 3 * p->control_steps <= ORC_NEWTON_MAXV);
   /* Newton converges quadratically, so a run of tiny gains means creeping along a costmap cell
    * edge much earlier than with L-BFGS: looser default */
-  const double ftol = p->cost_tolerance > 0.0 ? p->cost_tolerance : (newton ? 3e-4 : 3e-6) * p->opt_tolerance;
+  /* Beyond 3 control steps the objective is flatter per block (the weights are divided by N, and two
+   * neighbouring blocks of a long horizon can trade displacement at almost no cost): the gain thresholds of the
+   * Newton directions shrink with (3/N)^2 (the three-iteration window with (3/N)^3) -- measured on 1024 zero-costmap problems against solves run to the end:
+   * with the control_steps-3 thresholds 59 first controls at N = 32 (7 at 16, 2 at 8) end more than 1e-3 away
+   * (max 0.09, objective within 1e-4), with the scaled ones none (max 4e-4), for 8 % more iterations at 32. */
+  const double flat = (newton && p->control_steps > 3) ? (3.0 / p->control_steps) * (3.0 / p->control_steps) : 1.0;
+  const double ftol = p->cost_tolerance > 0.0 ? p->cost_tolerance : (newton ? 3e-4 * flat : 3e-6) * p->opt_tolerance;
 
   double u[ORC_MAXV], gs[ORC_MAXV], gt[ORC_MAXV], gr[ORC_MAXV], d[ORC_MAXV];
   double u_prev[ORC_MAXV], gt_prev[ORC_MAXV], cand[ORC_MAXV], best_c[ORC_MAXV];
@@ -1040,11 +1046,8 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
   double alpha = 1.0;
   int nfev = 1, it = 0, status = NEO_MPC_STATUS_MAX_ITER, stall = 0;
   /* three iterations in a row that together gain less than wtol end the search (Newton only by default) */
-  /* (beyond 8 control steps the objective is flatter per block -- weights are divided by N: the window
-   * shrinks with (8/N)^2, measured on the control_steps 32 reference solves) */
-  const double wscale = n > 8 ? (8.0 / n) * (8.0 / n) : 1.0;
   const double wtol = p->window_tolerance > 0.0 ? p->window_tolerance
-                      : (p->window_tolerance == 0.0 && newton) ? 3e-3 * p->opt_tolerance * wscale : 0.0;
+                      : (p->window_tolerance == 0.0 && newton) ? 3e-3 * p->opt_tolerance * flat * fmin(1.0, 3.0 / p->control_steps) : 0.0;
   double gain1 = INFINITY, gain2 = INFINITY;
   const double final_tol = p->step_tolerance > 0.0 ? p->step_tolerance : p->opt_tolerance;
   int final = 0;

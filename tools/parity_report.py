@@ -105,6 +105,31 @@ def warm_starts():
         print("    iterations: mean %.1f max %d" % (its.mean(), its.max()))
 
 
+def flat_problem_drift():
+    """How far the default stop rules leave the first control from a solve of the same kernel run to the end
+    (window off, step tolerance 1e-9, cost tolerance 1e-12, 300 iterations) on 1024 zero-costmap problems --
+    a broader sample than the reference fixtures can give (SLSQP to 1e-12 at control_steps 32 takes 20 s a
+    solve).  The long-horizon problems have valleys: two neighbouring blocks can trade displacement at almost
+    no cost, so u0 may sit 1e-2 away at an objective within 1e-4 of the minimum."""
+    print("\n# default stop rules vs the same kernel run to the end, 1024 zero-costmap cold starts")
+    for n in (3, 8, 32):
+        cmap = synthetic.make_costmap(500, seed=0)
+        zero = (np.zeros_like(cmap[0]),) + cmap[1:]
+        pr = synthetic.make_problems(1024, 500, seed=77)
+        res = []
+        for over in ({}, dict(window_tolerance=-1.0, step_tolerance=1e-9, cost_tolerance=1e-12, max_iterations=300)):
+            st, warm = synthetic.make_states(pr, n)
+            with BatchSolver(dict(util.orc.make_params(control_steps=n), **over)) as s:
+                s.set_costmap(*zero)
+                res.append(s.solve(pr, st, warm))
+        (c0, x0), (c1, x1) = res
+        du = np.abs(x0[:, :3] - x1[:, :3]).max(axis=1)
+        print("control_steps %2d: |u0 - u0(run to the end)|_inf : %s ; above 1e-3: %d of 1024; f - f(end): max %.2e; "
+              "iterations %.1f vs %.1f" % (n, pct(du), (du > 1e-3).sum(), (c0["cost"] - c1["cost"]).max(),
+                                         c0["iterations"].mean(), c1["iterations"].mean()))
+
+
 if __name__ == "__main__":
     cold_starts()
     warm_starts()
+    flat_problem_drift()
