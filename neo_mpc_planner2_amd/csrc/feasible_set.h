@@ -53,7 +53,11 @@ __constant__ double kQnSteps[32] = {
     0.125, 0.088, 0.0625, 0.044, 0.03125, 0.0156, 0.0078, 0.0039, 0.00195, 0.00098, 4.9e-4, 2.4e-4,
     1.2e-4, 6e-5, 3e-5, 1.5e-5};
 
+// kLongShots (Newton directions): lanes 61-63 trade the three shortest step lengths (L-BFGS's last resort)
+// for 8, 16 and 32 -- long shots that find the way out of a lethal cell
+template <bool kLongShots>
 __device__ __forceinline__ double lane_scale(int lane) {
+  if (kLongShots && lane >= 61) return ldexp(1.0, lane - 58);
   if (lane >= 32) return kQnSteps[lane - 32];
   double s = ldexp(1.0, -12 + (lane >> 1));
   return (lane & 1) ? s * 1.4142135623730951 : s;

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   // spilled from) scalar registers all through the loop.
   // So do two per-instance constants the loop has no use for: the request's true yaw (K2 only) and
   // the part of the objective that does not depend on u -- inside the loop f excludes it.
-  enum { T_XTOL, T_EARLY, T_FINAL, T_FTOL, T_STALL, T_WTOL, T_KINK, T_KONST, T_TRUE_YAW };
+  enum { T_XTOL, T_EARLY, T_FINAL, T_FTOL, T_STALL, T_WTOL, T_KINK, T_KONST, T_TRUE_YAW, T_MU };
   if (lane == 0) {
     double* t = L + a.lds.tol;
     t[T_XTOL] = p.xtol; t[T_EARLY] = p.early_tol; t[T_FINAL] = p.final_tol; t[T_FTOL] = p.ftol;
@@ -198,7 +198,14 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   for (int k = 0; k < nv; ++k) cold = cold && (u[k] == 0.0);
 
   for (int i = lane; i < n; i += kLanes) { AMODE[4 * i + 2] = 0; AMODE[4 * i + 3] = 0; }
-  double alpha = 1.0;
+  // Long horizons (Riccati direction): the curvature of a block falls with 1/N^2, so the proximal step starts
+  // longer; and the Newton step is long along the valleys in which neighbouring blocks trade displacement and
+  // leaves the region where the model holds -- Levenberg-Marquardt damping mu (in units of one stage's tracking
+  // weights, riccati_prepare), relaxed x1/4 after an iteration won by the (nearly) full Newton step, tightened
+  // x4 after one won by a proximal step or a short Newton step.  Nothing of it at control_steps <= 8.
+  double alpha = kRiccati ? fmax(1.0, n * 0.125) : 1.0;
+  // (mu lives in the tolerance block of LDS: two scalar registers fewer across the loop)
+  if (kRiccati && lane == 0) L[a.lds.tol + T_MU] = n > 8 ? (double)(n - 8) * 0.125 : 0.0;
   // Riccati: a block may be sent straight onto the kink u_i = v_cur only when v_cur is feasible
   bool v_feasible = false;
   if (kRiccati) {
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   // this lane's step multiplier: the one lane-derived constant worth two registers for the whole loop
   // (half of the table sits in constant memory: re-reading it would put a global load on every
   // iteration's critical path)
-  const double my_scale = kRiccati ? 0.0 : lane_scale(lane);
+  const double my_scale = kRiccati ? 0.0 : lane_scale<kSecond>(lane);
   for (it = 0; it < p.max_it; ++it) {
     // The lane index is re-read opaquely every iteration: otherwise the compiler hoists two dozen
     // lane-derived constants (step multipliers, compare masks, LDS addresses) out of the loop and,
@@ -478,7 +485,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       if (kRiccati) for (int i = lane; i < n; i += kLanes) AMODE[4 * i + 3] = 0;
       WAVE_SYNC();
     } else if (kRiccati) {
-      riccati_prepare(a, c, L, n, lane, v_feasible);
+      riccati_prepare(a, c, L, n, lane, v_feasible, (float)TOL[T_MU]);
       WAVE_SYNC();
 #ifdef NEO_MPC_RICCATI_F64   // (study build: the same recursion in float64 on the float32 records)
       riccati_sweep<double>(a, L, n, lane);
@@ -708,7 +715,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     // ---- 64 candidates, one rollout per lane; lowest objective wins
     // (run-time-sized Riccati kernel: the multiplier is re-read here -- one constant-memory load per iteration
     // against 2 x control_steps stages of work, and two registers fewer across the sweep)
-    const double lscale = kRiccati ? lane_scale(lane) : my_scale;
+    const double lscale = kRiccati ? lane_scale<kSecond>(lane) : my_scale;
     const double pstep = alpha * lscale;
     const double step = lane < 32 ? pstep : lscale;
     double fc = rollout_cost<kSteps, kTame>(
@@ -779,6 +786,13 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     const bool creeping = wtol > 0.0 && gain + gain1 + gain2 <= wtol * fscale;
     gain2 = gain1; gain1 = gain;
     f = fb;
+    if (kRiccati && !(it == 0 && cold)) {   // (an iteration that had a Newton direction)
+      const float bs = (float)lane_value(step, best);
+      const double mu0 = n > 8 ? (double)(n - 8) * 0.125 : 0.0, mu = TOL[T_MU];
+      double* mu_slot = L + tol_off + T_MU;
+      if (best >= 32 && bs >= 0.8f) { if (lane == 0) *mu_slot = fmax(0.25 * mu, mu0 * 0.0625); }
+      else if (best < 32 || bs < 0.3f) { if (lane == 0) *mu_slot = fmin(4.0 * mu, 16.0 * mu0); }
+    }
     if (best < 32) {
       alpha = lane_value(step, best);
       alpha = clampd(alpha, 1e-6, 1e6);

@@ -73,8 +73,9 @@ template <typename T> __device__ __forceinline__ T ric_pivot(T p, T delta) { ret
 // lane = stage.  In: gt / gs / u / tangent-cone description (mode, wfroz, near | nx, ny, k2 = lambda/r of a
 // binding disc) and the stage's cs, sn (record).  Out (record): gradients and the step onto the kink in
 // displacement coordinates, tangent, flags, block curvature.
+// mu: Levenberg-Marquardt damping in units of one stage's tracking weights (k_solve adapts it).
 __device__ __forceinline__ void riccati_prepare(const SolveArgs& a, const Ctx& c, double* L, int n, int lane,
-                                                bool v_feasible) {
+                                                bool v_feasible, float mu) {
   if (lane >= n) return;
   const DevParams& p = a.p;
   float* rs = reinterpret_cast<float*>(L + a.lds.ric) + kRicStage * lane;
@@ -116,6 +117,8 @@ __device__ __forceinline__ void riccati_prepare(const SolveArgs& a, const Ctx& c
     const float k2 = (float)L[a.lds.rt + lane] * i2;
     c00 = sN * (1.0f - h0 * h0) + k2 * rtx * rtx; c01 = -sN * h0 * h1 + k2 * rtx * rty; c02 = -sN * h0 * h2;
     c11 = sN * (1.0f - h1 * h1) + k2 * rty * rty; c12 = -sN * h1 * h2; c22 = sN * (1.0f - h2 * h2);
+    const float mt = mu * (float)(2.0 * p.wt_n);
+    c00 += mt; c11 += mt; c22 += mu * (float)(2.0 * p.wo_n);
   }
   rs[RS_C00] = c00; rs[RS_C01] = c01; rs[RS_C02] = c02; rs[RS_C11] = c11; rs[RS_C12] = c12; rs[RS_C22] = c22;
 }

@@ -356,6 +356,7 @@ typedef struct orc_active {
   double lambda[ORC_MAXN]; /* mode 1: n . (-g) > 0, the multiplier estimate of the binding constraint */
   uint8_t tokink[ORC_MAXN]; /* Riccati direction: the stage model's minimiser is the kink itself (d_i = v - u_i) */
   int riccati;              /* the Riccati kernel's candidate rules apply (per-block prox step) */
+  int longshots;            /* lanes 61-63 are step lengths 8, 16, 32 (Newton directions) */
   uint8_t rest[ORC_MAXN];   /* near block exactly on the kink whose smooth gradient keeps it there */
 } orc_active;
 
@@ -775,6 +776,7 @@ static void orc_riccati_direction(const orc_ctx* c, const double* u, const doubl
  * T = [[0 0 SY] [0 0 -SX] [SY -SX kappa]], and every stage is solved in the coordinates of its face (0-3 free
  * directions) instead of through projector products.  float64 here, float32 on the device. */
 static int orc_disp = 1;
+static _Thread_local double orc_mu = 0.0;   /* damping of the displacement-form direction (set per call) */
 void orc_set_disp(int on) { orc_disp = on; }
 static int orc_piv_replaced = 0;
 static double orc_piv(double p, double delta) { if (!(p > delta)) ++orc_piv_replaced; return p > delta ? p : fmax(fabs(p), delta); }
@@ -867,6 +869,8 @@ static void orc_riccati_direction_disp_tau(const orc_ctx* c, const double* u, co
         const double k2 = (a->mode[i] == 1 && a->disc[i]) ? a->lambda[i] / c->r * idt * idt : 0.0;
         c00 = sN * (1 - h0 * h0) + k2 * tx * tx; c01 = -sN * h0 * h1 + k2 * tx * ty; c02 = -sN * h0 * h2;
         c11 = sN * (1 - h1 * h1) + k2 * ty * ty; c12 = -sN * h1 * h2; c22 = sN * (1 - h2 * h2);
+        /* Levenberg-Marquardt damping, in units of one stage's tracking weights (orc_pg_solve adapts it) */
+        c00 += orc_mu * w2; c11 += orc_mu * w2; c22 += orc_mu * 2.0 * c->wo_n;
       }
       const double Q00 = S00 + c00, Q01 = S01 + c01, Q02 = Z02 + c02, Q11 = S11 + c11, Q12 = Z12 + c12, Q22 = Z22 + c22;
       const double q0 = gt0 + z0, q1 = gt1 + z1, q2 = gt2 + z2;
@@ -959,7 +963,11 @@ static const double ORC_QN_T[32] = {
     0.125, 0.088, 0.0625, 0.044, 0.03125, 0.0156, 0.0078, 0.0039, 0.00195, 0.00098, 4.9e-4, 2.4e-4,
     1.2e-4, 6e-5, 3e-5, 1.5e-5};
 
-static double orc_lane_scale(int lane) {
+/* long: the Newton directions trade the three shortest step lengths (L-BFGS's last resort) for long shots,
+ * 8, 16 and 32 -- they find the way out of a lethal cell (measured on 8192 cold starts at control_steps 32:
+ * 39 objectives more than 1 % better against 31 worse; same iteration count) */
+static double orc_lane_scale(int lane, int longshots) {
+  if (longshots && lane >= 61) return ldexp(1.0, lane - 58);
   if (lane >= 32) return ORC_QN_T[lane - 32];
   double s = ldexp(1.0, -12 + (lane >> 1));
   return (lane & 1) ? s * 1.4142135623730951 : s;
@@ -967,7 +975,7 @@ static double orc_lane_scale(int lane) {
 
 static void orc_candidate(const orc_ctx* c, const orc_active* act, int lane, double alpha, const double* u,
                           const double* gs, const double* d, double* cand) {
-  const double sc = orc_lane_scale(lane);
+  const double sc = orc_lane_scale(lane, act->longshots);
   for (int i = 0; i < c->n; ++i) {
     double b[3];
     if (lane < 32 || act->near[i]) {
@@ -1032,6 +1040,7 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
   orc_active act;
   memset(&act, 0, sizeof(act));
   act.riccati = riccati;
+  act.longshots = newton;
   uint8_t near_prev[ORC_MAXN];
   memset(near_prev, 0, sizeof(near_prev));
 
@@ -1043,7 +1052,17 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
   double f = orc_eval(&c, u);
   int cold = 1;
   for (int k = 0; k < nv; ++k) cold = cold && (u[k] == 0.0);
-  double alpha = 1.0;
+  /* Long horizons (Riccati direction): the curvature of a block falls with 1/N^2, so the proximal step starts
+   * longer (one iteration of growing it saved); and two neighbouring blocks can trade displacement at almost no
+   * cost, so the Newton step is long along such valleys and leaves the region where the model holds (constraints,
+   * the control norm's kink, costmap cells): Levenberg-Marquardt damping mu (in units of one stage's tracking
+   * weights, added to the block curvature in displacement coordinates), relaxed x1/4 after an iteration won by
+   * the (nearly) full Newton step, tightened x4 after one won by a proximal step or a short Newton step.
+   * Measured on 8192 cold starts: 12.6 -> 9.0 iterations at control_steps 32, 20.2 -> 10.3 at 64, 9.1 -> 8.1 at
+   * 16; no gain at 8 and below (no damping there). */
+  double alpha = riccati ? fmax(1.0, n / 8.0) : 1.0;
+  const double mu0 = (riccati && n > 8) ? (n - 8) / 8.0 : 0.0, mu_lo = mu0 / 16.0, mu_hi = 16.0 * mu0;
+  double mu = mu0;
   int nfev = 1, it = 0, status = NEO_MPC_STATUS_MAX_ITER, stall = 0;
   /* three iterations in a row that together gain less than wtol end the search (Newton only by default) */
   const double wtol = p->window_tolerance > 0.0 ? p->window_tolerance
@@ -1059,7 +1078,7 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
        * Newton step almost never wins there (9 % of the cases): lanes 32-63 walk the reduced
        * steepest-descent direction in that first iteration instead */
       if (it == 0 && cold) for (int k = 0; k < nv; ++k) d[k] = -gr[k];
-      else if (riccati && orc_disp) orc_riccati_direction_disp(&c, u, gs, gt, &act, d);
+      else if (riccati && orc_disp) { orc_mu = mu; orc_riccati_direction_disp(&c, u, gs, gt, &act, d); orc_mu = 0.0; }
       else if (riccati) orc_riccati_direction(&c, u, gs, gt, &act, d);
       else orc_newton_direction(&c, u, gs, gr, &act, d);
       orc_apply_active(&c, &act, d);
@@ -1127,7 +1146,7 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
       if (fc < fb) { fb = fc; best = lane; memcpy(best_c, cand, sizeof(double) * nv); }
       if (lane >= 32 && fc < fb_qn) { fb_qn = fc; best_qn = lane; }
       if (orc_trace > 1 && it == orc_trace) {
-        fprintf(stderr, "  lane %2d sc %.3e fc-f %.3e cand", lane, orc_lane_scale(lane), fc - f);
+        fprintf(stderr, "  lane %2d sc %.3e fc-f %.3e cand", lane, orc_lane_scale(lane, act.longshots), fc - f);
         for (int k = 0; k < nv; ++k) fprintf(stderr, " %.7f", cand[k] - u[k]);
         fprintf(stderr, "\n");
       }
@@ -1158,8 +1177,12 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
     memcpy(near_prev, act.near, sizeof(near_prev));
     const double decrease = f - fb;
     f = fb;
+    if (!(it == 0 && cold)) {   /* (an iteration that had a Newton direction) */
+      if (best >= 32 && orc_lane_scale(best, act.longshots) >= 0.8) mu = fmax(0.25 * mu, mu_lo);
+      else if (best < 32 || orc_lane_scale(best, act.longshots) < 0.3) mu = fmin(4.0 * mu, mu_hi);
+    }
     if (best < 32) {
-      alpha *= orc_lane_scale(best);
+      alpha *= orc_lane_scale(best, act.longshots);
       alpha = orc_clamp(alpha, 1e-6, 1e6);
     }
     /* iterations that gain next to nothing or barely move (creeping along a costmap cell edge, the
