@@ -62,20 +62,22 @@ __device__ __forceinline__ double step_term(const SolveArgs& a, const Ctx& c, co
 // frame.  The Newton direction then slides along the cost step instead of running into it at every step
 // length (searches used to die creeping towards such an edge).
 constexpr double kSticky = 100.0, kStickyDist = 0.02;
-__device__ __forceinline__ void edge_stickiness(const SolveArgs& a, const Ctx& c, const double* L, double x, double y,
-                                                double& wxx, double& wxy, double& wyy) {
+// Returns the raw cost of the stage's own cell.
+__device__ __forceinline__ int edge_stickiness(const SolveArgs& a, const Ctx& c, const double* L, double x, double y,
+                                               double& wxx, double& wxy, double& wyy) {
   const double X = c.X0 + (c.c0 * x - c.s0 * y), Y = c.Y0 + (c.s0 * x + c.c0 * y);
   const int mx = cell_of(X, a.map.origin_x, a.map.resolution, a.map.inv_resolution);
   const int my = cell_of(Y, a.map.origin_y, a.map.resolution, a.map.inv_resolution);
   const double fx = (X - a.map.origin_x) / a.map.resolution - (double)mx;
   const double fy = (Y - a.map.origin_y) / a.map.resolution - (double)my;
-  const double here = L[a.lds.term + cell_raw(a, c, L, mx, my)];
+  const int raw_here = cell_raw(a, c, L, mx, my);
+  const double here = L[a.lds.term + raw_here];
   const double rho = kSticky * 2.0 * a.p.wt_n;
   wxx = 0.0; wxy = 0.0; wyy = 0.0;
   // (saturated cell indices -- positions far outside every map -- wrap in mx +- 1; such cells read lethal
   // on both sides, so no edge is sticky there)
   const bool far = mx <= -2147483647 || mx >= 2147483646 || my <= -2147483647 || my >= 2147483646;
-  if (far) return;
+  if (far) return raw_here;
   const bool ex = (fx < kStickyDist && L[a.lds.term + cell_raw(a, c, L, mx - 1, my)] > here) ||
                   (1.0 - fx < kStickyDist && L[a.lds.term + cell_raw(a, c, L, mx + 1, my)] > here);
   const bool ey = (fy < kStickyDist && L[a.lds.term + cell_raw(a, c, L, mx, my - 1)] > here) ||
@@ -83,6 +85,7 @@ __device__ __forceinline__ void edge_stickiness(const SolveArgs& a, const Ctx& c
   // world x axis in the rollout frame: (c0, -s0); world y axis: (s0, c0)
   if (ex) { wxx += rho * c.c0 * c.c0; wxy += rho * c.c0 * -c.s0; wyy += rho * c.s0 * c.s0; }
   if (ey) { wxx += rho * c.s0 * c.s0; wxy += rho * c.s0 * c.c0; wyy += rho * c.c0 * c.c0; }
+  return raw_here;
 }
 
 // Bresenham outline cost of one polygon edge (end points inclusive)

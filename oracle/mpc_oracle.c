@@ -315,6 +315,23 @@ static double orc_eval(const orc_ctx* c, const double* u) {
   return f + c->wterm_o * (et * et) + c->konst;
 }
 
+/* does every stage of the rollout sit in a free cell (raw cost 0, inside the map)? */
+static int orc_free_path(const orc_ctx* c, const double* u) {
+  double x = 0.0, y = 0.0, th = 0.0;
+  for (int i = 0; i < c->n; ++i) {
+    th += u[3 * i + 2] * c->dt;
+    const double cs = cos(th), sn = sin(th);
+    x += (u[3 * i] * cs - u[3 * i + 1] * sn) * c->dt;
+    y += (u[3 * i] * sn + u[3 * i + 1] * cs) * c->dt;
+    const double X = c->X0 + (c->c0 * x - c->s0 * y), Y = c->Y0 + (c->s0 * x + c->c0 * y);
+    int64_t mx, my;
+    orc_world_to_map(c->map, X, Y, &mx, &my);
+    if (mx < 0 || my < 0 || mx >= c->map->size_x || my >= c->map->size_y) return 0;
+    if (c->map->cells[my * (int64_t)c->map->size_x + mx] != 0) return 0;
+  }
+  return 1;
+}
+
 /* gradient of the smooth (tracking + terminal) part, adjoint sweep */
 static void orc_grad_smooth(const orc_ctx* c, const double* u, double* g) {
   const int n = c->n;
@@ -1001,6 +1018,9 @@ static void orc_candidate(const orc_ctx* c, const orc_active* act, int lane, dou
 static int orc_capture_it = -1;
 static double* orc_capture_d = NULL;
 void orc_capture_direction(int it, double* d_out) { orc_capture_it = it; orc_capture_d = d_out; }
+#define ORC_TRIAL_RATIO 0.75
+static int orc_trial = 1;
+void orc_set_trial(int on) { orc_trial = on; }
 static int orc_rest_rule = 1;
 void orc_set_rest_rule(int on) { orc_rest_rule = on; }
 static int orc_trace = 0;
@@ -1139,7 +1159,23 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
     /* 64 candidates, lowest objective wins (ties: lowest lane) */
     double fb = INFINITY, fb_qn = INFINITY;
     int best = -1, best_qn = -1;
-    for (int lane = 0; lane < ORC_LANES; ++lane) {
+    /* Riccati direction, rollout in free space (no costmap term at any stage: the objective is smooth up to the
+     * control norm's kink): the full Newton step (lane 32's candidate) is tried on its own first -- one
+     * objective evaluation, lane = stage on the device -- and taken without the 64-candidate search when it
+     * achieves ORC_TRIAL_RATIO of the decrease the quadratic model promises (-1/2 g_r . step).  Measured on 8192
+     * cold starts at control_steps 32: 71 % of such trials succeed, 3.9 searches saved per solve for 0.3
+     * iterations more, same results.  (With a costmap term under the rollout the search's spread of candidates
+     * is what steps over cost edges and out of lethal cells: trying the step alone there loses 0.1 % of the
+     * solves to worse minima and one of the reference-anchored P3 cases.) */
+    int trial_ok = 0;
+    if (riccati && orc_trial && it > 0 && orc_free_path(&c, u)) {
+      orc_candidate(&c, &act, 32, alpha, u, gs, d, cand);
+      const double ft = orc_eval(&c, cand);
+      double pred = 0.0;
+      for (int k = 0; k < nv; ++k) pred -= 0.5 * gr[k] * (cand[k] - u[k]);
+      if (ft < f && f - ft >= ORC_TRIAL_RATIO * pred) { trial_ok = 1; fb = ft; best = 32; memcpy(best_c, cand, sizeof(double) * nv); }
+    }
+    for (int lane = 0; lane < ORC_LANES && !trial_ok; ++lane) {
       orc_candidate(&c, &act, lane, alpha, u, gs, d, cand);
       if (it == 0 && lane == 0) memcpy(cand, u, sizeof(double) * nv); /* the kernel gets f(x0) from this lane */
       double fc = orc_eval(&c, cand);
