@@ -855,6 +855,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   NEO_WAVE_END();
 }
 
+#ifndef NEO_MPC_TU_RICCATI   // (neo_mpc_riccati.hip compiles this file again for the Riccati variants of K1 only)
 // K2 on its own: `solution` supplies x.x, `success` supplies x.success
 __global__ __launch_bounds__(kLanes) void k_postprocess(const SolveArgs args) {
   extern __shared__ __align__(16) double L[];
@@ -1035,6 +1036,7 @@ __global__ __launch_bounds__(kLanes) void k_carrot(const CarrotArgs a) {
     }
   }
 }
+#endif  // NEO_MPC_TU_RICCATI
 
 }  // namespace
 
@@ -1052,7 +1054,18 @@ static int solve_variant(int fallback) {
   return v ? v : fallback;
 }
 
+// The Riccati variants of K1 live in a translation unit of their own (neo_mpc_riccati.hip = this file with
+// NEO_MPC_TU_RICCATI, compiled with -fno-slp-vectorize): the SLP vectoriser packs the sweep's float32
+// arithmetic into v_pk_* instructions and pays for it with three hundred register moves that assemble the
+// operand pairs (859 vector instructions in the sweep against 757 without it) -- measured +7 % solves/s at
+// control_steps 8 and +9 % at 32 without; the dense-Newton kernels are 0.5 % faster WITH it.
+void launch_solve_riccati(const SolveArgs& a, void* stream, void* ev_start, void* ev_stop);
+
+#ifdef NEO_MPC_TU_RICCATI
+void launch_solve_riccati(const SolveArgs& a, void* stream, void* ev_start, void* ev_stop) {
+#else
 void launch_solve(const SolveArgs& a, void* stream, void* ev_start, void* ev_stop) {
+#endif
   if (a.count == 0) return;
   const dim3 grid(a.count), block(kLanes);
   hipStream_t st = (hipStream_t)stream;
@@ -1073,6 +1086,18 @@ void launch_solve(const SolveArgs& a, void* stream, void* ev_start, void* ev_sto
   do {                                                                                                   \
     if ((w) == 4) NEO_LAUNCH(4, __VA_ARGS__); else if ((w) == 3) NEO_LAUNCH(3, __VA_ARGS__); else NEO_LAUNCH(2, __VA_ARGS__); \
   } while (0)
+#ifdef NEO_MPC_TU_RICCATI
+  {  // any control_steps: Newton direction by the Riccati sweep (riccati.h)
+    // the 128-VGPR build (4 waves/SIMD) wherever LDS lets a CU hold more than 12 workgroups -- 13 need <= 12.3 KB
+    // each -- else the 168-VGPR build (measured: control_steps 8, 16 workgroups/CU: +17 %; control_steps 32 at
+    // 11.3 KB = 14 workgroups/CU: +9 %; with 12 workgroups/CU the 4-wave build's spills make it 4 % slower)
+    const int w = solve_variant(lds <= 12600 ? 4 : 3);
+    if (disc) NEO_LAUNCH_W(w, 0, 2, true);
+    else NEO_LAUNCH_W(w, 0, 2);
+  }
+  (void)generic; (void)small_tile;
+#else
+  if (a.p.newton == 2) { launch_solve_riccati(a, stream, ev_start, ev_stop); return; }
   if (a.p.n == 3 && a.p.newton == 1) {  // projected Newton, dense 9 x 9 system (its layout does not depend on lbfgs_memory)
     const int w = solve_variant(disc ? 4 : 3);
     if (disc && w == 4 && small_tile) NEO_LAUNCH_LDS(0, 4, 3, 1, true, 1024);   // (the static variant takes no dynamic LDS)
@@ -1080,13 +1105,6 @@ void launch_solve(const SolveArgs& a, void* stream, void* ev_start, void* ev_sto
     else NEO_LAUNCH_W(w, 3, 1);
   } else if (a.p.n == 3 && a.p.newton == 0 && !generic) {
     NEO_LAUNCH_W(solve_variant(3), 3);
-  } else if (a.p.newton == 2) {  // any control_steps: Newton direction by the Riccati sweep (riccati.h)
-    // the 128-VGPR build (4 waves/SIMD) wherever LDS lets a CU hold more than 12 workgroups -- 13 need <= 12.3 KB
-    // each -- else the 168-VGPR build (measured: control_steps 8, 16 workgroups/CU: +17 %; control_steps 32 at
-    // 11.3 KB = 14 workgroups/CU: +9 %; with 12 workgroups/CU the 4-wave build's spills make it 4 % slower)
-    const int w = solve_variant(lds <= 12600 ? 4 : 3);
-    if (disc) NEO_LAUNCH_W(w, 0, 2, true);
-    else NEO_LAUNCH_W(w, 0, 2);
   } else if (a.p.newton == 1) {  // control_steps <= kNewtonMaxSteps, dense system with run-time size
     // (a 24-entry row per lane: 158 VGPRs, 187 without the tame specialisation -- spill-free at 3 and 2 waves/SIMD)
     const int w = solve_variant(disc ? 3 : 2);
@@ -1098,10 +1116,12 @@ void launch_solve(const SolveArgs& a, void* stream, void* ev_start, void* ev_sto
     if (disc) NEO_LAUNCH_W(w, 0, 0, true);
     else NEO_LAUNCH_W(w, 0, 0);
   }
+#endif  // NEO_MPC_TU_RICCATI
 #undef NEO_LAUNCH_W
 #undef NEO_LAUNCH
 #undef NEO_LAUNCH_LDS
 }
+#ifndef NEO_MPC_TU_RICCATI
 void launch_carrots(const CarrotArgs& a, void* stream) {
   if (a.b.count == 0) return;
   hipLaunchKernelGGL(k_carrot, dim3((unsigned)a.b.count), dim3(kLanes), 0, (hipStream_t)stream, a);
@@ -1122,5 +1142,6 @@ void launch_ingest(const IngestArgs& a, void* stream) {
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(k_ingest, dim3(blocks, a.maps > 0 ? a.maps : 1), dim3(256), 0, (hipStream_t)stream, a);
 }
+#endif  // NEO_MPC_TU_RICCATI
 
 }  // namespace neo_mpc
