@@ -106,7 +106,7 @@ def source_sha():
     d = os.path.join(ROOT, "neo_mpc_planner2_amd", "csrc")
     h = hashlib.sha256()
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h", ".cpp")):
+        if name.endswith((".hip", ".h", ".cpp")) or name == "Makefile":   # (the Makefile carries per-file flags)
             h.update(name.encode())
             h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]

@@ -4,12 +4,15 @@ the call site inside the kernel).  usage: asm_profile.py <kernel-mangled-substri
 Compiles neo_mpc_kernels.hip with -gline-tables-only -S (device only) and parses the .loc chain."""
 import collections, os, re, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, "neo_mpc_planner2_amd/csrc/neo_mpc_kernels.hip")
-out = "/tmp/asm_profile.s"
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-pass-failed",
-                "-gline-tables-only", "-x", "hip", "--cuda-device-only", "-S", src, "-o", out],
-               check=True, stderr=subprocess.DEVNULL)
 key = sys.argv[1]
+# the Riccati variants of K1 (k_solve<*, 0, 2, *>: "...ELi0ELi2E...") live in neo_mpc_riccati.hip, built without SLP
+riccati = "ELi0ELi2E" in key
+src = os.path.join(root, "neo_mpc_planner2_amd/csrc", "neo_mpc_riccati.hip" if riccati else "neo_mpc_kernels.hip")
+out = "/tmp/asm_profile.s"
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-pass-failed"] +
+               (["-fno-slp-vectorize"] if riccati else []) +
+               ["-gline-tables-only", "-x", "hip", "--cuda-device-only", "-S", src, "-o", out],
+               check=True, stderr=subprocess.DEVNULL)
 lo, hi = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (0, 10**9)
 text = open(out).read().split("\n")
 start = next(i for i, l in enumerate(text) if l.startswith("_Z") and key in l and ":" in l)
