@@ -49,13 +49,16 @@ extern "C" {
 #define NEO_MPC_COMPAT_ODOM_YAW_GOAL_W 1 /* py:213: odom_yaw takes quaternion w from the goal pose */
 
 /* neo_mpc_params.method */
-#define NEO_MPC_METHOD_AUTO 0   /* dense Newton at control_steps <= 8, stage-wise (Riccati) Newton beyond */
+#define NEO_MPC_METHOD_AUTO 0   /* dense Newton at control_steps == 3 (the register-resident 9 x 9 kernel),
+                                   stage-wise (Riccati) Newton at every other control_steps */
 #define NEO_MPC_METHOD_LBFGS 1  /* projected L-BFGS, any control_steps */
 #define NEO_MPC_METHOD_NEWTON 2 /* projected Newton (finite-difference Hessian of the analytic
                                    gradient, one column per lane); control_steps <= 8 */
-#define NEO_MPC_METHOD_RICCATI 3 /* projected Newton, the same system solved stage by stage (Riccati
-                                   recursion over the rollout chain, 3x3 blocks, analytic second-order
-                                   terms): any control_steps, O(control_steps) per iteration */
+#define NEO_MPC_METHOD_RICCATI 3 /* projected Gauss-Newton, solved stage by stage (Riccati recursion over the
+                                   rollout chain, 3x3 blocks, float32): any control_steps, O(control_steps)
+                                   per iteration; beyond 8 control steps with adaptive Levenberg-Marquardt
+                                   damping; in free space (no costmap term under the rollout) the full
+                                   step is tried on its own before the 64-candidate search */
 #define NEO_MPC_NEWTON_MAX_CONTROL_STEPS 8
 
 #define NEO_MPC_MAX_CONTROL_STEPS 64

@@ -192,3 +192,59 @@ def test_window_tolerance_only_shortens_creeping_searches():
     a = _cold_solve(p12, cmap, probs[:128])[0]
     b = _cold_solve(orc.make_params(control_steps=12, method=1, window_tolerance=-1.0), cmap, probs[:128])[0]
     assert (a["iterations"] == b["iterations"]).all()
+
+
+def _free_space_workload(n_steps, count, seed):
+    """Zero costmap (every rollout in free space): unique minimisers, the trial step is eligible everywhere."""
+    cmap = synthetic.make_costmap(300, seed=seed)
+    zero = (np.zeros_like(cmap[0]),) + tuple(cmap[1:])
+    probs = synthetic.make_problems(count, 300, seed=seed + 1)
+    return util.orc.make_params(control_steps=n_steps), zero, probs
+
+
+def test_damping_beyond_8_control_steps_cuts_the_long_tail():
+    """Levenberg-Marquardt damping of the Riccati direction (orc_pg_solve): long horizons need about nine
+    iterations instead of a dozen with a tail of dozens; the first control still sits where a solve run to
+    the end puts it (the flat-problem drift check of tools/parity_report.py, on the mirror)."""
+    for n_steps, mean_bar in ((32, 10.5), (64, 12.5)):
+        params, zero, probs = _free_space_workload(n_steps, 256, seed=5)
+        cmds, x = _cold_solve(params, zero, probs)
+        assert (cmds["status"] == 0).all()
+        assert cmds["iterations"].mean() <= mean_bar, cmds["iterations"].mean()
+        assert np.percentile(cmds["iterations"], 99) <= 25
+        tight = dict(params, window_tolerance=-1.0, step_tolerance=1e-9, cost_tolerance=1e-12, max_iterations=300)
+        cmds_t, x_t = _cold_solve(tight, zero, probs)
+        assert np.abs(x[:, :3] - x_t[:, :3]).max() <= 4e-4
+        assert (cmds["cost"] - cmds_t["cost"]).max() <= 1e-5
+
+
+def test_trial_step_changes_the_path_not_the_answer():
+    """In free space the full Newton step is tried before the 64-candidate search: with the trial switched off
+    the same problems end at the same minimisers (1e-3 on every control of the first block, objective 1e-5)."""
+    lib = c_oracle.load()
+    for n_steps in (8, 32):
+        params, zero, probs = _free_space_workload(n_steps, 256, seed=9)
+        cmds, x = _cold_solve(params, zero, probs)
+        lib.orc_set_trial(0)
+        try:
+            cmds_s, x_s = _cold_solve(params, zero, probs)
+        finally:
+            lib.orc_set_trial(1)
+        assert np.abs(x[:, :3] - x_s[:, :3]).max() <= 1e-3
+        assert np.abs(cmds["cost"] - cmds_s["cost"]).max() <= 1e-5
+        assert (cmds["status"] == 0).all() and (cmds_s["status"] == 0).all()
+
+
+def test_trial_step_needs_free_space():
+    """With a costmap term under the rollout the search always runs: the trial changes nothing there.  A map of
+    raw cost 1 everywhere (constant term, same minimisers as the zero map) makes every rollout ineligible."""
+    lib = c_oracle.load()
+    params, zero, probs = _free_space_workload(8, 64, seed=13)
+    ones = (np.ones_like(zero[0]),) + tuple(zero[1:])
+    cmds, x = _cold_solve(params, ones, probs)
+    lib.orc_set_trial(0)
+    try:
+        cmds_s, x_s = _cold_solve(params, ones, probs)
+    finally:
+        lib.orc_set_trial(1)
+    assert np.array_equal(x, x_s) and np.array_equal(cmds["iterations"], cmds_s["iterations"])
