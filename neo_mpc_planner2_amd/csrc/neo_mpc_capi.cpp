@@ -309,13 +309,13 @@ int stage_in(neo_mpc_handle* h, const neo_mpc_batch* b, neo_mpc_batch& d, bool s
   d.states = (neo_mpc_state*)h->states.ptr;
   d.warm_start = (double*)h->warm.ptr;
   d.commands = (neo_mpc_command*)h->commands.ptr;
-  HIP_TRY(hipMemcpy(h->problems.ptr, b->problems, n * sizeof(neo_mpc_problem), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(h->states.ptr, b->states, n * sizeof(neo_mpc_state), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(h->warm.ptr, b->warm_start, n * nv * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpyAsync(h->problems.ptr, b->problems, n * sizeof(neo_mpc_problem), hipMemcpyHostToDevice, nullptr));
+  HIP_TRY(hipMemcpyAsync(h->states.ptr, b->states, n * sizeof(neo_mpc_state), hipMemcpyHostToDevice, nullptr));
+  HIP_TRY(hipMemcpyAsync(h->warm.ptr, b->warm_start, n * nv * 8, hipMemcpyHostToDevice, nullptr));
   if (b->solution) {
     if ((rc = h->solution.reserve(n * nv * 8))) return rc;
     d.solution = (double*)h->solution.ptr;
-    if (solution_is_input) HIP_TRY(hipMemcpy(h->solution.ptr, b->solution, n * nv * 8, hipMemcpyHostToDevice));
+    if (solution_is_input) HIP_TRY(hipMemcpyAsync(h->solution.ptr, b->solution, n * nv * 8, hipMemcpyHostToDevice, nullptr));
   }
   if (b->predicted_path) {
     if ((rc = h->path.reserve(n * nv * 8))) return rc;
@@ -332,7 +332,7 @@ int stage_in(neo_mpc_handle* h, const neo_mpc_batch* b, neo_mpc_batch& d, bool s
         return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "footprint vertex %zu of instance %zu is not finite",
                     (k / 2) % b->footprint_points, k / (2 * b->footprint_points));
     if ((rc = h->footprints.reserve(bytes))) return rc;
-    HIP_TRY(hipMemcpy(h->footprints.ptr, b->footprints, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(h->footprints.ptr, b->footprints, bytes, hipMemcpyHostToDevice, nullptr));
     d.footprints = (const double*)h->footprints.ptr;
   }
   return NEO_MPC_OK;
@@ -340,14 +340,18 @@ int stage_in(neo_mpc_handle* h, const neo_mpc_batch* b, neo_mpc_batch& d, bool s
 
 int stage_out(neo_mpc_handle* h, const neo_mpc_batch* b, bool solution_is_output) {
   const size_t n = b->count, nv = 3 * (size_t)h->params.control_steps;
-  HIP_TRY(hipMemcpy(b->commands, h->commands.ptr, n * sizeof(neo_mpc_command), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(b->states, h->states.ptr, n * sizeof(neo_mpc_state), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(b->warm_start, h->warm.ptr, n * nv * 8, hipMemcpyDeviceToHost));
+  // every copy is queued on the null stream behind the kernel and waited for once: with page-locked host buffers
+  // (hipHostMalloc / hipHostRegister / torch pin_memory) they are DMA transfers that overlap the host side of the
+  // next call; with pageable buffers the runtime stages them and each call returns when its copy is done
+  HIP_TRY(hipMemcpyAsync(b->commands, h->commands.ptr, n * sizeof(neo_mpc_command), hipMemcpyDeviceToHost, nullptr));
+  HIP_TRY(hipMemcpyAsync(b->states, h->states.ptr, n * sizeof(neo_mpc_state), hipMemcpyDeviceToHost, nullptr));
+  HIP_TRY(hipMemcpyAsync(b->warm_start, h->warm.ptr, n * nv * 8, hipMemcpyDeviceToHost, nullptr));
   if (b->solution && solution_is_output)
-    HIP_TRY(hipMemcpy(b->solution, h->solution.ptr, n * nv * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(b->solution, h->solution.ptr, n * nv * 8, hipMemcpyDeviceToHost, nullptr));
   if (b->predicted_path)
-    HIP_TRY(hipMemcpy(b->predicted_path, h->path.ptr, n * nv * 8, hipMemcpyDeviceToHost));
-  if (b->velocities) HIP_TRY(hipMemcpy(b->velocities, h->vel.ptr, n * 24, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(b->predicted_path, h->path.ptr, n * nv * 8, hipMemcpyDeviceToHost, nullptr));
+  if (b->velocities) HIP_TRY(hipMemcpyAsync(b->velocities, h->vel.ptr, n * 24, hipMemcpyDeviceToHost, nullptr));
+  HIP_TRY(hipStreamSynchronize(nullptr));
   return NEO_MPC_OK;
 }
 
@@ -543,14 +547,15 @@ int neo_mpc_solve_batch(neo_mpc_handle* h, const neo_mpc_batch* batch) {
   if (batch->count <= kLatencyPathMaxCount && !batch->footprints)
     return solve_batch_latency_path(h, batch);
   neo_mpc_batch d;
-  if ((rc = stage_in(h, batch, d, false))) return rc;
-  if ((rc = fill_args(h, &d, a))) return rc;
-  if ((rc = map_acquire(h, nullptr))) return rc;
+  // (the staging copies are asynchronous: no way out of here while one may still be reading the caller's buffers)
+  auto bail = [](int code) { (void)hipStreamSynchronize(nullptr); return code; };
+  if ((rc = stage_in(h, batch, d, false))) return bail(rc);
+  if ((rc = fill_args(h, &d, a))) return bail(rc);
+  if ((rc = map_acquire(h, nullptr))) return bail(rc);
   launch_solve(a, nullptr);
-  HIP_TRY(hipGetLastError());
-  if ((rc = map_release(h, nullptr))) return rc;
-  HIP_TRY(hipDeviceSynchronize());
-  return stage_out(h, batch, true);
+  if (hipGetLastError() != hipSuccess) return bail(fail(NEO_MPC_ERR_DEVICE, "kernel launch failed"));
+  if ((rc = map_release(h, nullptr))) return bail(rc);
+  return bail(stage_out(h, batch, true));   // (queued behind the kernel on the null stream, one wait at the end)
 }
 
 int neo_mpc_postprocess_batch(neo_mpc_handle* h, const neo_mpc_batch* batch, const int32_t* success) {
@@ -561,19 +566,20 @@ int neo_mpc_postprocess_batch(neo_mpc_handle* h, const neo_mpc_batch* batch, con
   if (batch->count == 0) return NEO_MPC_OK;
   HIP_TRY(hipSetDevice(h->device));
   neo_mpc_batch d;
-  if ((rc = stage_in(h, batch, d, true))) return rc;
-  if ((rc = fill_args(h, &d, a))) return rc;
+  auto bail = [](int code) { (void)hipStreamSynchronize(nullptr); return code; };
+  if ((rc = stage_in(h, batch, d, true))) return bail(rc);
+  if ((rc = fill_args(h, &d, a))) return bail(rc);
   if (success) {
-    if ((rc = h->success.reserve(batch->count * 4))) return rc;
-    HIP_TRY(hipMemcpy(h->success.ptr, success, batch->count * 4, hipMemcpyHostToDevice));
+    if ((rc = h->success.reserve(batch->count * 4))) return bail(rc);
+    if (hipMemcpy(h->success.ptr, success, batch->count * 4, hipMemcpyHostToDevice) != hipSuccess)
+      return bail(fail(NEO_MPC_ERR_DEVICE, "copy of the success flags failed"));
     a.success = (const int32_t*)h->success.ptr;
   }
-  if ((rc = map_acquire(h, nullptr))) return rc;
+  if ((rc = map_acquire(h, nullptr))) return bail(rc);
   launch_postprocess(a, nullptr);
-  HIP_TRY(hipGetLastError());
-  if ((rc = map_release(h, nullptr))) return rc;
-  HIP_TRY(hipDeviceSynchronize());
-  return stage_out(h, batch, false);
+  if (hipGetLastError() != hipSuccess) return bail(fail(NEO_MPC_ERR_DEVICE, "kernel launch failed"));
+  if ((rc = map_release(h, nullptr))) return bail(rc);
+  return bail(stage_out(h, batch, false));
 }
 
 int neo_mpc_objective_batch(neo_mpc_handle* h, const neo_mpc_problem* problems, const double* u, double* cost_out,

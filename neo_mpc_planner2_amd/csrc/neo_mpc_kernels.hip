@@ -824,7 +824,10 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     stall = (gain <= TOL[T_FTOL] * fscale || (double)stepmax <= TOL[T_STALL]) ? stall + 1 : 0;
     // three iterations that together gained less than wtol: creeping along a costmap cell edge
     const double wtol = TOL[T_WTOL];
-    const bool creeping = wtol > 0.0 && gain + gain1 + gain2 <= wtol * fscale;
+    bool creeping = wtol > 0.0 && gain + gain1 + gain2 <= wtol * fscale;
+    // ... and so does a step below stall_step whose gain halved twice in a row: the search is closing in on a
+    // costmap cell edge (or the kink) geometrically; what is left to gain is less than the last gain
+    creeping = creeping || (wtol > 0.0 && (double)stepmax <= TOL[T_STALL] && gain <= 0.5 * gain1 && gain1 <= 0.5 * gain2);
     gain2 = gain1; gain1 = gain;
     f = fb;
     if (kRiccati && !(it == 0 && cold)) {   // (an iteration that had a Newton direction)

@@ -102,13 +102,15 @@ class BatchSolver:
         return dict(lds_bytes=a.value, reach_cells=b.value, tile_in_lds=bool(c.value))
 
     # -- host batches ----------------------------------------------------------------
-    def _host_batch(self, problems, states, warm, solution, want_path, footprints):
+    def _host_batch(self, problems, states, warm, solution, want_path, footprints, commands=None):
         n = self.control_steps
         problems = np.ascontiguousarray(problems, dtype=abi.PROBLEM_DTYPE)
         count = problems.shape[0]
         assert states.dtype == abi.STATE_DTYPE and states.shape == (count,) and states.flags.c_contiguous
         assert warm.dtype == np.float64 and warm.shape == (count, 3 * n) and warm.flags.c_contiguous
-        commands = np.zeros(count, dtype=abi.COMMAND_DTYPE)
+        if commands is None:
+            commands = np.zeros(count, dtype=abi.COMMAND_DTYPE)
+        assert commands.dtype == abi.COMMAND_DTYPE and commands.shape == (count,) and commands.flags.c_contiguous
         path = np.zeros((count, n, 3)) if want_path else None
         if footprints is not None:
             footprints = np.ascontiguousarray(footprints, dtype=np.float64)
@@ -117,12 +119,14 @@ class BatchSolver:
         self._keep = (problems, footprints)
         return b, commands, path
 
-    def solve(self, problems, states, warm, want_path=False, footprints=None):
+    def solve(self, problems, states, warm, want_path=False, footprints=None, out=None):
         """`optimizer()` (py:349-403) for a batch of host records.  `states` / `warm` are
-        updated in place.  Returns (commands, solution[, path])."""
+        updated in place.  Returns (commands, solution[, path]).  `out` = (commands, solution) arrays to fill
+        instead of fresh ones -- page-locked ones (with page-locked inputs) make every transfer of the call a DMA."""
         count = len(problems)
-        solution = np.zeros((count, 3 * self.control_steps))
-        b, commands, path = self._host_batch(problems, states, warm, solution, want_path, footprints)
+        commands, solution = out if out is not None else (None, np.zeros((count, 3 * self.control_steps)))
+        assert solution.dtype == np.float64 and solution.shape == (count, 3 * self.control_steps) and solution.flags.c_contiguous
+        b, commands, path = self._host_batch(problems, states, warm, solution, want_path, footprints, commands)
         _lib.check(self._lib.neo_mpc_solve_batch(self._handle, C.byref(b)))
         return (commands, solution, path) if want_path else (commands, solution)
 

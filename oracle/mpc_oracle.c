@@ -1226,8 +1226,12 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
      * are in a row */
     stall = (decrease <= ftol * fmax(1.0, fabs(fb)) || step <= stall_step) ? stall + 1 : 0;
     const int creeping = wtol > 0.0 && decrease + gain1 + gain2 <= wtol * fmax(1.0, fabs(fb));
+    /* ... and so does a step below stall_step whose gain halved twice in a row: the search is closing in on a
+     * costmap cell edge (or the kink) geometrically, what is left to gain is less than the last gain (part of the
+     * window rule: off with it).  -3 % iterations at control_steps 3 and 32, no command moves by 1e-3. */
+    const int closing_in = wtol > 0.0 && step <= stall_step && decrease <= 0.5 * gain1 && gain1 <= 0.5 * gain2;
     gain2 = gain1; gain1 = decrease;
-    if (step < xtol || stall >= ORC_STALL_ITERATIONS || creeping || final) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
+    if (step < xtol || stall >= ORC_STALL_ITERATIONS || creeping || closing_in || final) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
   }
   memcpy(x_out, u, sizeof(double) * nv);
   *f_out = f;

@@ -445,3 +445,29 @@ def test_pool_larger_than_one_ingest_launch_and_bad_footprints_are_refused():
         fps[57, 2, 1] = 1e12
         cmds, _ = s.solve(probs, st, warm, footprints=fps)
         assert st["collision_footprint"][57] == 1 and (cmds["vel"][57] == 0.0).all()
+
+
+def test_host_entry_point_on_page_locked_buffers():
+    """neo_mpc_solve_batch queues its transfers on the null stream and waits once: on page-locked request /
+    result buffers (a server's own arena) they are DMA transfers; the results are those of the pageable call."""
+    import torch
+    from neo_mpc_planner2_amd.solver import BatchSolver
+
+    def pinned(a):
+        t = torch.empty(a.nbytes, dtype=torch.uint8).pin_memory()
+        v = t.numpy().view(a.dtype).reshape(a.shape)
+        v[...] = a
+        return v
+    n = 3
+    params = util.orc.make_params(control_steps=n)
+    cfg, cmap, probs, st, warm = synthetic.make_workload("C2", seed=4, batch=1000)
+    with BatchSolver(params) as s:
+        s.set_costmap(*cmap)
+        st_a, warm_a = st.copy(), warm.copy()
+        cmds_a, x_a = s.solve(probs, st_a, warm_a)
+        p_probs, p_st, p_warm = pinned(np.ascontiguousarray(probs)), pinned(st), pinned(warm)
+        out = (pinned(np.zeros(len(probs), dtype=abi.COMMAND_DTYPE)), pinned(np.zeros((len(probs), 3 * n))))
+        cmds_b, x_b = s.solve(p_probs, p_st, p_warm, out=out)
+        assert cmds_b is out[0] and x_b is out[1]
+        assert np.array_equal(x_a, x_b) and cmds_a.tobytes() == cmds_b.tobytes()
+        assert st_a.tobytes() == p_st.tobytes() and np.array_equal(warm_a, p_warm)
