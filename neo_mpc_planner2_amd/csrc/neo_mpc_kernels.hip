@@ -53,6 +53,18 @@ constexpr int kStallIterations = 5;
 // solver iteration 2 in entries 0-5 of `solution` (tools/phase_timing.py); wall-clock start and end of
 // the wave and its HW_ID in entries 6-8 (tools/wave_timeline.py; control_steps >= 3).
 #ifdef NEO_MPC_PHASE_TIMING
+// (-DNEO_MPC_SEGMENT_TIMING on top: wall-clock stamps at the first and behind the last solver iteration replace
+// the phase clocks of entries 4-5 -- set-up, iterations and K2 of every wave, tools/wave_timeline.py)
+#ifdef NEO_MPC_SEGMENT_TIMING
+#define NEO_SEGMENT_DECL unsigned long long seg_t0 = 0, seg_t1 = 0
+#define NEO_SEGMENT(k) seg_t##k = wall_clock64()
+#define NEO_SEGMENT_DUMP()                                                                          \
+  a.solution[(size_t)b * nv + 4] = (double)seg_t0; a.solution[(size_t)b * nv + 5] = (double)seg_t1
+#else
+#define NEO_SEGMENT_DECL
+#define NEO_SEGMENT(k)
+#define NEO_SEGMENT_DUMP()
+#endif
 #define NEO_WAVE_START const unsigned long long wave_t0 = wall_clock64()
 #define NEO_WAVE_END()                                                                              \
   if (a.solution && lane == 0 && nv >= 9) {                                                        \
@@ -61,6 +73,7 @@ constexpr int kStallIterations = 5;
     a.solution[(size_t)b * nv + 6] = (double)wave_t0;                                              \
     a.solution[(size_t)b * nv + 7] = (double)wall_clock64();                                       \
     a.solution[(size_t)b * nv + 8] = (double)hw_id;                                                \
+    NEO_SEGMENT_DUMP();                                                                            \
   }
 #define NEO_PHASE_DECL long long phase_clock[8]
 #define NEO_PHASE(k) phase_clock[k] = clock64()
@@ -70,6 +83,8 @@ constexpr int kStallIterations = 5;
 #else
 #define NEO_WAVE_START
 #define NEO_WAVE_END()
+#define NEO_SEGMENT_DECL
+#define NEO_SEGMENT(k)
 #define NEO_PHASE_DECL
 #define NEO_PHASE(k)
 #define NEO_PHASE_DUMP()
@@ -221,6 +236,8 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   // (half of the table sits in constant memory: re-reading it would put a global load on every
   // iteration's critical path)
   const double my_scale = kRiccati ? 0.0 : lane_scale<kSecond>(lane);
+  NEO_SEGMENT_DECL;
+  NEO_SEGMENT(0);
   for (it = 0; it < p.max_it; ++it) {
     // The lane index is re-read opaquely every iteration: otherwise the compiler hoists two dozen
     // lane-derived constants (step multipliers, compare masks, LDS addresses) out of the loop and,
@@ -847,6 +864,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     if ((double)stepmax < TOL[T_XTOL] || stall >= kStallIterations || creeping || final_step) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
   }
 
+  NEO_SEGMENT(1);
 #ifndef NEO_MPC_PHASE_TIMING
   if (a.solution)
     for (int k = lane; k < nv; k += kLanes) a.solution[(size_t)b * nv + k] = u[k];

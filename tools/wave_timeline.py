@@ -25,6 +25,12 @@ print("wave duration: mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f us" % (dur.m
 for k in sorted(set(it)):
     m = it == k
     print("  iterations %2d: n %4d  duration mean %.1f  max %.1f  end max %.1f us" % (k, m.sum(), dur[m].mean(), dur[m].max(), us(t1)[m].max()))
+if os.environ.get("NEO_MPC_SEGMENTS"):   # library built with -DNEO_MPC_SEGMENT_TIMING (make segments)
+    l0, l1 = x[:, 4], x[:, 5]
+    pro, loop, epi = us(l0) - us(t0), us(l1) - us(l0), us(t1) - us(l1)
+    print("set-up (records, yaw, reach tile): mean %.1f p50 %.1f p99 %.1f us; iterations: mean %.1f us (%.2f us per iteration); K2 + write-back: mean %.1f p99 %.1f us"
+          % (pro.mean(), np.median(pro), np.quantile(pro, .99), loop.mean(), (loop / it).mean(), epi.mean(), np.quantile(epi, .99)))
+    print("last set-up ends at %.1f us; first K2 starts at %.1f us" % (us(l0).max(), us(l1).min()))
 end = np.sort(us(t1))
 print("waves still running at t = 40/60/80/90/100 us:", [(end > t).sum() for t in (40, 60, 80, 90, 100)])
 # HW_ID: wave_id[3:0] simd[5:4] pipe[7:6] cu[11:8] sh[12] se[15:13] ... (gfx9 layout)
