@@ -56,15 +56,21 @@ __device__ __forceinline__ double step_term(const SolveArgs& a, const Ctx& c, co
   return L[a.lds.term + cell_raw(a, c, L, mx, my)];
 }
 
-// Wall sliding (Riccati kernel): a stage whose position (x, y: rollout frame) sits within kStickyDist cells of
-// a cell edge behind which the costmap term is higher gets motion along that edge's normal penalised in
-// the stage model -- w += kSticky * 2 w_trans/N * n n^T, n = the edge normal (a world axis) in the rollout's
-// frame.  The Newton direction then slides along the cost step instead of running into it at every step
-// length (searches used to die creeping towards such an edge).
-constexpr double kSticky = 100.0, kStickyDist = 0.02;
+// Wall model of the stage-wise direction (Riccati kernel).  A stage whose position (x, y: rollout frame) sits within
+// kStickyDist cells of a cell edge behind which the costmap term is higher gets motion along that edge's normal
+// penalised in the stage model, W += rho n n^T (n = the edge normal, a world axis, in the rollout's frame): the Newton
+// direction then slides along the cost step instead of running into it at every step length (searches used to die
+// creeping towards such an edge).  rho = kSticky x the tracking curvature for an ordinary cost step.  Behind a LETHAL
+// cell (or the map's border) the edge is a wall no candidate will ever cross: within kWallDist cells of it rho = kWall x
+// the tracking curvature and the penalty is centred kWallDist cells inside, 1/2 rho (n . dz - pb)^2 -- its linear term
+// l = -rho pb n pushes the stage back to that stand-off, so that a finite step along the wall does not end inside it
+// (with the soft penalty alone a search blocked by a lethal cell crept up to the wall and ended there with every
+// candidate lethal; the stage's path along a straight wall is curved in the controls: a stand-off of 2 % of a cell lets
+// a slide advance a centimetre per iteration, 10 % five times that).
 // Returns the raw cost of the stage's own cell.
+constexpr double kSticky = 100.0, kWall = 1e4, kStickyDist = 0.02, kWallDist = 0.1;
 __device__ __forceinline__ int edge_stickiness(const SolveArgs& a, const Ctx& c, const double* L, double x, double y,
-                                               double& wxx, double& wxy, double& wyy) {
+                                               double& wxx, double& wxy, double& wyy, double& lx, double& ly) {
   const double X = c.X0 + (c.c0 * x - c.s0 * y), Y = c.Y0 + (c.s0 * x + c.c0 * y);
   const int mx = cell_of(X, a.map.origin_x, a.map.resolution, a.map.inv_resolution);
   const int my = cell_of(Y, a.map.origin_y, a.map.resolution, a.map.inv_resolution);
@@ -72,19 +78,34 @@ __device__ __forceinline__ int edge_stickiness(const SolveArgs& a, const Ctx& c,
   const double fy = (Y - a.map.origin_y) / a.map.resolution - (double)my;
   const int raw_here = cell_raw(a, c, L, mx, my);
   const double here = L[a.lds.term + raw_here];
-  const double rho = kSticky * 2.0 * a.p.wt_n;
-  wxx = 0.0; wxy = 0.0; wyy = 0.0;
+  wxx = 0.0; wxy = 0.0; wyy = 0.0; lx = 0.0; ly = 0.0;
   // (saturated cell indices -- positions far outside every map -- wrap in mx +- 1; such cells read lethal
   // on both sides, so no edge is sticky there)
   const bool far = mx <= -2147483647 || mx >= 2147483646 || my <= -2147483647 || my >= 2147483646;
   if (far) return raw_here;
-  const bool ex = (fx < kStickyDist && L[a.lds.term + cell_raw(a, c, L, mx - 1, my)] > here) ||
-                  (1.0 - fx < kStickyDist && L[a.lds.term + cell_raw(a, c, L, mx + 1, my)] > here);
-  const bool ey = (fy < kStickyDist && L[a.lds.term + cell_raw(a, c, L, mx, my - 1)] > here) ||
-                  (1.0 - fy < kStickyDist && L[a.lds.term + cell_raw(a, c, L, mx, my + 1)] > here);
+  // at most one edge per axis can be within the (wider) wall zone: the low side (push back along +axis) or the high side
+  const bool xlo = fx < kWallDist, xhi = 1.0 - fx < kWallDist, ylo = fy < kWallDist, yhi = 1.0 - fy < kWallDist;
+  double rx = 0.0, ry = 0.0, pbx = 0.0, pby = 0.0;
+  if (xlo || xhi) {
+    const int raw_n = cell_raw(a, c, L, xlo ? mx - 1 : mx + 1, my);
+    const double dist = xlo ? fx : 1.0 - fx;
+    const bool wall = raw_n == 254 && raw_here != 254;
+    if (wall) { rx = kWall * 2.0 * a.p.wt_n; pbx = (xlo ? kWallDist - dist : dist - kWallDist) * a.map.resolution; }
+    else if (dist < kStickyDist && L[a.lds.term + raw_n] > here) rx = kSticky * 2.0 * a.p.wt_n;
+  }
+  if (ylo || yhi) {
+    const int raw_n = cell_raw(a, c, L, mx, ylo ? my - 1 : my + 1);
+    const double dist = ylo ? fy : 1.0 - fy;
+    const bool wall = raw_n == 254 && raw_here != 254;
+    if (wall) { ry = kWall * 2.0 * a.p.wt_n; pby = (ylo ? kWallDist - dist : dist - kWallDist) * a.map.resolution; }
+    else if (dist < kStickyDist && L[a.lds.term + raw_n] > here) ry = kSticky * 2.0 * a.p.wt_n;
+  }
   // world x axis in the rollout frame: (c0, -s0); world y axis: (s0, c0)
-  if (ex) { wxx += rho * c.c0 * c.c0; wxy += rho * c.c0 * -c.s0; wyy += rho * c.s0 * c.s0; }
-  if (ey) { wxx += rho * c.s0 * c.s0; wxy += rho * c.s0 * c.c0; wyy += rho * c.c0 * c.c0; }
+  wxx = rx * c.c0 * c.c0 + ry * c.s0 * c.s0;
+  wxy = rx * c.c0 * -c.s0 + ry * c.s0 * c.c0;
+  wyy = rx * c.s0 * c.s0 + ry * c.c0 * c.c0;
+  lx = -(rx * pbx * c.c0 + ry * pby * c.s0);
+  ly = -(rx * pbx * -c.s0 + ry * pby * c.c0);
   return raw_here;
 }
 

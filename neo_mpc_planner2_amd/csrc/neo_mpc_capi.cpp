@@ -176,6 +176,11 @@ void derive(neo_mpc_handle* h) {
   d.ftol = p.cost_tolerance > 0.0 ? p.cost_tolerance : (d.newton ? 3e-4 * flat : 3e-6) * p.opt_tolerance;
   d.wtol = p.window_tolerance > 0.0 ? p.window_tolerance
            : (p.window_tolerance == 0.0 && d.newton) ? 3e-3 * p.opt_tolerance * flat * fmin(1.0, 3.0 / n) : 0.0;
+  // (a long-horizon search that has run twice its usual length is creeping, gaining 1e-8 of f per iteration up to the
+  // iteration cap -- a handful per 65 536 solves, but a launch lasts as long as its slowest wave: from iteration
+  // kLateIteration on the window is the control_steps-3 one again)
+  d.wtol_late = p.window_tolerance > 0.0 ? p.window_tolerance
+                : (p.window_tolerance == 0.0 && d.newton) ? 3e-3 * p.opt_tolerance : 0.0;
 
   // LDS carve-up (shared with the kernel specialisations) + reach tile geometry
   LdsLayout& l = h->lds;

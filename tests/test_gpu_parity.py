@@ -164,6 +164,47 @@ def test_p2_p3_against_reference_slsqp_solves(solver_mod, n_steps, method):
             assert (cmds["cost"] <= g[k + "f_tight"][mask] + 1e-6).all()
 
 
+@pytest.mark.parametrize("pset,n_steps,method", [("cut", 3, 0), ("cut", 8, 0), ("cut", 8, 2), ("cut", 3, 1),
+                                                 ("turn", 3, 0), ("turn", 8, 0), ("turn", 8, 2), ("turn", 3, 1), ("turn", 3, 3)])
+def test_p2_p3_at_other_parameter_sets(solver_mod, pset, n_steps, method):
+    """G8: the reference's SLSQP solves for parameter sets that take the GENERAL kernels (not the README-like
+    "tame" specialisations): the vx/vy box cutting the speed disc with v_cur outside the feasible set for many
+    requests ("cut"), and a fast-turning robot whose heading leaves [-pi/4, pi/4] within a 1.2 s horizon, with
+    other weights ("turn").  P2 on the zero map, P3 everywhere -- for "turn" on the costmap as a distribution:
+    w_costmap = 0.3 turns cost steps into walls that block either local search somewhere else."""
+    g = util.load("g8_solves_params.npz")
+    k = "%s_n%d_" % (pset, n_steps)
+    params = util.params_from(g["param_keys"], g[k + "params"])
+    assert params["control_steps"] == n_steps
+    params["method"] = method
+    probs = util.problems_from(g[k + "problems"])
+    hm = g[k + "has_map"].astype(bool)
+    for mask, cells in ((~hm, np.zeros_like(g[k + "cells"])), (hm, g[k + "cells"])):
+        cmap = (cells,) + tuple(g[k + "map_meta"])
+        pr = probs[mask]
+        st, warm = synthetic.make_states(pr, n_steps)
+        with _solver(solver_mod, params, cmap) as s:
+            cmds, x = s.solve(pr, st, warm)
+            f_at = s.objective(pr, g[k + "x_tight"][mask])
+        assert np.allclose(f_at, g[k + "f_tight"][mask], rtol=1e-12, atol=1e-12)   # the objective kernel, these parameters
+        worse = cmds["cost"] - g[k + "f_loose"][mask]
+        riccati = method == 3 or (method == 0 and n_steps != 3)   # (the direction with the wall model: no outliers)
+        if cells.any() and pset == "turn" and not riccati:
+            assert (worse <= 1e-3).mean() >= 0.9 and np.median(worse) <= 0.0, (worse.max(), np.median(worse))
+        else:
+            assert (worse <= 1e-3).all(), worse.max()
+        xs = x.reshape(len(x), -1, 3)
+        assert (np.hypot(xs[:, :, 0], xs[:, :, 1]) <= params["max_vel_trans"] + 1e-9).all()
+        assert (xs[:, :, 0] <= params["max_vel_x"] + 1e-12).all() and (xs[:, :, 0] >= params["min_vel_x"] - 1e-12).all()
+        assert (np.abs(xs[:, :, 2]) <= params["max_vel_theta"] + 1e-12).all()
+        assert (cmds["status"] == 0).all()
+        if not cells.any():
+            ok = g[k + "status_tight"][mask] == 0
+            du0 = np.abs(x[:, :3] - g[k + "x_tight"][mask][:, :3]).max(axis=1)
+            assert du0[ok].max() <= 1e-3, du0[ok].max()
+            assert (cmds["cost"] <= g[k + "f_tight"][mask] + 1e-6).all()
+
+
 @pytest.mark.parametrize("fixture", ["g4_episodes.npz", "g4_episodes_n8.npz"])
 def test_p3_on_the_reference_warm_starts(solver_mod, fixture):
     """G4: every call of the recorded episodes is solved from the REFERENCE's own state (its warm start

@@ -187,3 +187,27 @@ def test_g6_analytic_gradient_of_the_solver_mirror(n_steps):
     scale = np.abs(g[k + "grad"]).max(axis=1, keepdims=True)
     assert (np.abs(out - g[k + "grad"]) <= 2e-6 * np.maximum(scale, 1e-3)).all(), \
         (np.abs(out - g[k + "grad"]) / np.maximum(scale, 1e-3)).max()
+
+
+@pytest.mark.parametrize("pset", ["cut", "turn"])
+def test_g8_restated_objective_at_other_parameter_sets(pset):
+    """G8: the reference's own objective values at its SLSQP solutions for parameter sets away from the README's
+    (the vx/vy box cutting the speed disc; a fast-turning robot, longer horizon, other weights), control_steps 3
+    and 8: the restated objective (Python and C) reproduces them."""
+    from oracle import c_oracle
+    g = util.load("g8_solves_params.npz")
+    for n_steps in (3, 8):
+        k = "%s_n%d_" % (pset, n_steps)
+        params = util.params_from(g["param_keys"], g[k + "params"])
+        assert params["control_steps"] == n_steps
+        probs = util.problems_from(g[k + "problems"])
+        hm = g[k + "has_map"].astype(bool)
+        for mask, cells in ((~hm, np.zeros_like(g[k + "cells"])), (hm, g[k + "cells"])):
+            cmap_c = (cells,) + tuple(g[k + "map_meta"])
+            for tag in ("loose", "tight"):
+                f_c = c_oracle.objective_batch(params, cmap_c, probs[mask], g[k + "x_" + tag][mask])
+                assert np.allclose(f_c, g[k + "f_" + tag][mask], rtol=1e-12, atol=1e-12)
+            cm = util.oracle_costmap(cells, g[k + "map_meta"])
+            for j in np.where(mask)[0][:6]:
+                f_py = orc.objective(g[k + "x_tight"][j], util.oracle_problem(probs[j]), params, cm)
+                assert abs(f_py - g[k + "f_tight"][j]) <= 1e-12 * max(1.0, abs(f_py))

@@ -72,6 +72,31 @@ def cold_starts():
                      (cmds["status"] == 1).sum(), g[k + "nit_loose"][mask].mean()))
 
 
+def other_parameter_sets():
+    """G8: the reference's SLSQP solves at parameter sets away from the README's (general kernels)."""
+    print("\n# other parameter sets (G8): 'cut' = vx/vy box cutting the speed disc; 'turn' = max_vel_theta 3, horizon 1.2 s, "
+          "w_orient 2, w_costmap 0.3, w_control 0.1")
+    g = util.load("g8_solves_params.npz")
+    for pset in ("cut", "turn"):
+        for n in (3, 8):
+            k = "%s_n%d_" % (pset, n)
+            params = util.params_from(g["param_keys"], g[k + "params"])
+            probs = util.problems_from(g[k + "problems"])
+            hm = g[k + "has_map"].astype(bool)
+            for mask, cells, name in ((~hm, np.zeros_like(g[k + "cells"]), "zero costmap"), (hm, g[k + "cells"], "costmap")):
+                pr = probs[mask]
+                st, warm = synthetic.make_states(pr, n)
+                with BatchSolver(params) as s:
+                    s.set_costmap(cells, *g[k + "map_meta"])
+                    cmds, x = s.solve(pr, st, warm)
+                worse = cmds["cost"] - g[k + "f_loose"][mask]
+                du = np.abs(x[:, :3] - g[k + "x_tight"][mask][:, :3]).max(axis=1)
+                print("%-4s control_steps %d, %-12s: P3 f - f(SLSQP 1e-3): max %.3e, above 1e-3: %d of %d, below -1e-3: %d, median %.2e"
+                      " | P2 |u0 - u0(SLSQP 1e-12)|: %s | iterations %.1f"
+                      % (pset, n, name, worse.max(), (worse > 1e-3).sum(), len(worse), (worse < -1e-3).sum(), np.median(worse),
+                         pct(du), cmds["iterations"].mean()))
+
+
 def warm_starts():
     print("\n# warm starts: every call of the reference's recorded episodes (G4) solved from the reference's own state")
     for fixture in ("g4_episodes.npz", "g4_episodes_n8.npz"):
@@ -131,5 +156,6 @@ def flat_problem_drift():
 
 if __name__ == "__main__":
     cold_starts()
+    other_parameter_sets()
     warm_starts()
     flat_problem_drift()
