@@ -50,7 +50,9 @@ extern "C" {
 
 /* neo_mpc_params.method */
 #define NEO_MPC_METHOD_AUTO 0   /* dense Newton at control_steps == 3 (the register-resident 9 x 9 kernel),
-                                   stage-wise (Riccati) Newton at every other control_steps */
+                                   stage-wise (Riccati) Newton at every other control_steps -- and at 3 when
+                                   w_costmap > w_trans / 4 (cost steps become walls: the wall model is part
+                                   of the stage-wise direction) */
 #define NEO_MPC_METHOD_LBFGS 1  /* projected L-BFGS, any control_steps */
 #define NEO_MPC_METHOD_NEWTON 2 /* projected Newton (finite-difference Hessian of the analytic
                                    gradient, one column per lane); control_steps <= 8 */

@@ -160,11 +160,16 @@ void derive(neo_mpc_handle* h) {
                    p.min_vel_y <= -p.max_vel_trans && p.max_vel_y >= p.max_vel_trans) ? 1 : 0;
   d.tame = (d.disc_in_box && fmax(fabs(p.min_vel_theta), fabs(p.max_vel_theta)) * p.prediction_horizon <= 0.78) ? 1 : 0;
   // search direction: AUTO = the register-resident dense Newton kernel at control_steps 3 (the headline
-  // specialisation), the stage-wise (Riccati) Newton sweep of the run-time-sized kernel otherwise
+  // specialisation), the stage-wise (Riccati) Newton sweep of the run-time-sized kernel otherwise -- and at 3 too
+  // when the costmap weight is heavy (w_costmap > w_trans / 4; the README's is w_trans / 16): cost steps are then
+  // walls the search has to slide along, and the wall model lives in the stage-wise direction (costmap.h).  Against
+  // the reference's SLSQP solves at w_costmap = 0.3 (G8 "turn") the dense direction ends 3e-3 and 9e-3 above
+  // SLSQP's value in 2 of 24 cases, the stage-wise one in none.
+  const bool heavy_costmap = p.w_costmap > 0.25 * p.w_trans;
   d.newton = p.method == NEO_MPC_METHOD_LBFGS ? 0
              : p.method == NEO_MPC_METHOD_NEWTON ? 1
              : p.method == NEO_MPC_METHOD_RICCATI ? 2
-             : (n == 3 ? 1 : 2);
+             : (n == 3 && !heavy_costmap ? 1 : 2);
   d.early_tol = getenv("NEO_MPC_NO_EARLY") ? 0.0 : d.xtol;
   d.final_tol = getenv("NEO_MPC_NO_EARLY") ? 0.0 : (p.step_tolerance > 0.0 ? p.step_tolerance : p.opt_tolerance);
   // Beyond 3 control steps the objective is flatter per block (the weights are divided by N, and two neighbouring

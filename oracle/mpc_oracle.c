@@ -1054,8 +1054,10 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
   const double xtol = p->step_tolerance > 0.0 ? p->step_tolerance : 1e-3 * p->opt_tolerance;
   const double stall_step = p->stall_step > 0.0 ? p->stall_step : 0.3 * p->opt_tolerance;
   /* search direction of lanes 32-63: stage-wise (Riccati) Newton, dense Newton (control_steps <= 8) or L-BFGS */
+  /* (AUTO: dense at control_steps 3 unless the costmap weight is heavy -- the wall model lives in the stage-wise
+   * direction, neo_mpc_capi.cpp) */
   const int riccati = p->method == NEO_MPC_METHOD_RICCATI ||
-                      (p->method == NEO_MPC_METHOD_AUTO && p->control_steps != 3);
+                      (p->method == NEO_MPC_METHOD_AUTO && (p->control_steps != 3 || p->w_costmap > 0.25 * p->w_trans));
   const int newton = riccati || (p->method != NEO_MPC_METHOD_LBFGS && 3 * p->control_steps <= ORC_NEWTON_MAXV);
   /* Newton converges quadratically, so a run of tiny gains means creeping along a costmap cell
    * edge much earlier than with L-BFGS: looser default */

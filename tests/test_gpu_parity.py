@@ -165,7 +165,7 @@ def test_p2_p3_against_reference_slsqp_solves(solver_mod, n_steps, method):
 
 
 @pytest.mark.parametrize("pset,n_steps,method", [("cut", 3, 0), ("cut", 8, 0), ("cut", 8, 2), ("cut", 3, 1),
-                                                 ("turn", 3, 0), ("turn", 8, 0), ("turn", 8, 2), ("turn", 3, 1), ("turn", 3, 3)])
+                                                 ("turn", 3, 0), ("turn", 8, 0), ("turn", 8, 2), ("turn", 3, 1), ("turn", 3, 2)])
 def test_p2_p3_at_other_parameter_sets(solver_mod, pset, n_steps, method):
     """G8: the reference's SLSQP solves for parameter sets that take the GENERAL kernels (not the README-like
     "tame" specialisations): the vx/vy box cutting the speed disc with v_cur outside the feasible set for many
@@ -188,7 +188,8 @@ def test_p2_p3_at_other_parameter_sets(solver_mod, pset, n_steps, method):
             f_at = s.objective(pr, g[k + "x_tight"][mask])
         assert np.allclose(f_at, g[k + "f_tight"][mask], rtol=1e-12, atol=1e-12)   # the objective kernel, these parameters
         worse = cmds["cost"] - g[k + "f_loose"][mask]
-        riccati = method == 3 or (method == 0 and n_steps != 3)   # (the direction with the wall model: no outliers)
+        # (the direction with the wall model: no outliers; AUTO picks it at control_steps 3 too when w_costmap > w_trans / 4)
+        riccati = method == 3 or (method == 0 and (n_steps != 3 or params["w_costmap"] > 0.25 * params["w_trans"]))
         if cells.any() and pset == "turn" and not riccati:
             assert (worse <= 1e-3).mean() >= 0.9 and np.median(worse) <= 0.0, (worse.max(), np.median(worse))
         else:
