@@ -256,9 +256,20 @@ class FakeClock:
         return self.t
 
 
-def gen_g4(mod, n_steps=3, n_ep=8, n_calls=50, fname="g4_episodes.npz"):
+#: G4 at another parameter set: other acceleration limits and low-pass gain (K2), the box cutting the disc, a
+#: footprint weight, a shorter wait before the collision latch lets go
+G4B_PARAMS = dict(acc_x_limit=1.0, acc_y_limit=1.5, acc_theta_limit=2.0, low_pass_gain=0.3, max_vel_trans=0.7,
+                  max_vel_x=0.4, min_vel_x=-0.2, max_vel_y=0.65, min_vel_y=-0.65, w_footprint=0.2, w_control=0.1)
+
+
+def gen_g4b(mod):
+    gen_g4(mod, n_steps=3, n_ep=6, n_calls=40, fname="g4_episodes_params.npz", overrides=G4B_PARAMS)
+
+
+def gen_g4(mod, n_steps=3, n_ep=8, n_calls=50, fname="g4_episodes.npz", overrides=None):
     """`n_ep` episodes x `n_calls` sequential optimizer() calls through the reference wrapper."""
     params = dict(README_PARAMS, control_steps=n_steps)
+    params.update(overrides or {})
     cmap = synthetic.make_costmap(200, seed=4)
     cells, res, ox, oy = cmap
     clock = FakeClock()
@@ -457,6 +468,7 @@ def main():
     gen_g6(mod)
     gen_g7(mod)
     gen_g8(mod)
+    gen_g4b(mod)
 
 
 if __name__ == "__main__":

@@ -34,7 +34,7 @@ def test_g2_yaw():
         assert c_oracle.yaw(*q) == rpy[2]
 
 
-@pytest.mark.parametrize("fixture", ["g4_episodes.npz", "g4_episodes_n8.npz"])
+@pytest.mark.parametrize("fixture", ["g4_episodes.npz", "g4_episodes_n8.npz", "g4_episodes_params.npz"])
 def test_g4_wrapper_episodes_injected(fixture):
     """P5 for the C wrapper: responses and state over the recorded episodes, reference x.x injected."""
     g = util.load(fixture)

@@ -43,7 +43,7 @@ def test_objective_kernel_matches_reference_golden(solver_mod, n_steps):
 
 
 # ------------------------------------------------------------------ P5: wrapper episodes
-@pytest.mark.parametrize("fixture", ["g4_episodes.npz", "g4_episodes_n8.npz"])
+@pytest.mark.parametrize("fixture", ["g4_episodes.npz", "g4_episodes_n8.npz", "g4_episodes_params.npz"])
 def test_postprocess_kernel_reproduces_reference_episodes(solver_mod, fixture):
     from oracle import c_oracle
     g = util.load(fixture)
@@ -206,7 +206,7 @@ def test_p2_p3_at_other_parameter_sets(solver_mod, pset, n_steps, method):
             assert (cmds["cost"] <= g[k + "f_tight"][mask] + 1e-6).all()
 
 
-@pytest.mark.parametrize("fixture", ["g4_episodes.npz", "g4_episodes_n8.npz"])
+@pytest.mark.parametrize("fixture", ["g4_episodes.npz", "g4_episodes_n8.npz", "g4_episodes_params.npz"])
 def test_p3_on_the_reference_warm_starts(solver_mod, fixture):
     """G4: every call of the recorded episodes is solved from the REFERENCE's own state (its warm start
     `initial_guess`, `last_control`, goal bookkeeping, real costmap): the kernel's answer must be feasible and
@@ -234,7 +234,9 @@ def test_p3_on_the_reference_warm_starts(solver_mod, fixture):
             worse.append(cmds["cost"] - f_ref)
             xs = x.reshape(n_ep, n, 3)
             assert (np.hypot(xs[:, :, 0], xs[:, :, 1]) <= params["max_vel_trans"] + 1e-9).all()
-            assert (np.abs(xs) <= params["max_vel_x"] + 1e-12).all()
+            for q, axis in enumerate(("x", "y", "theta")):
+                assert (xs[:, :, q] <= params["max_vel_" + axis] + 1e-12).all()
+                assert (xs[:, :, q] >= params["min_vel_" + axis] - 1e-12).all()
             assert (cmds["status"] == 0).all()
             s.postprocess(rows, states, warm, g["raw_x"][:, k], g["success"][:, k])   # the reference's next state
     worse = np.array(worse)
@@ -282,7 +284,7 @@ def test_predicted_path_matches_reference_local_plan(solver_mod, n_steps):
     assert (ref[:, :, 2:4] == 0.0).all()
 
 
-@pytest.mark.parametrize("fixture", ["g4_episodes.npz", "g4_episodes_n8.npz"])
+@pytest.mark.parametrize("fixture", ["g4_episodes.npz", "g4_episodes_n8.npz", "g4_episodes_params.npz"])
 def test_predicted_path_of_the_reference_episodes(solver_mod, fixture):
     """G4 `local_plan`: the Path published inside optimizer() (rollout of the UNFILTERED x.x from the request's
     pose) == K2's predicted_path with the reference's x.x injected, over all 520 calls."""

@@ -99,7 +99,7 @@ def other_parameter_sets():
 
 def warm_starts():
     print("\n# warm starts: every call of the reference's recorded episodes (G4) solved from the reference's own state")
-    for fixture in ("g4_episodes.npz", "g4_episodes_n8.npz"):
+    for fixture in ("g4_episodes.npz", "g4_episodes_n8.npz", "g4_episodes_params.npz"):
         g = util.load(fixture)
         params = util.params_from(g["param_keys"], g["params"])
         n = params["control_steps"]
