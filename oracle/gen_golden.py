@@ -239,6 +239,9 @@ def gen_g8(mod):
         for n_steps, count in ((3, 48), (8, 24)):
             grp = _g3_group(mod, n_steps, count, 800 + 10 * si + n_steps, G8_SETS[name])
             out.update({"%s_n%d_%s" % (name, n_steps, k): v for k, v in grp.items()})
+    # ... and the README's parameters at control_steps 16: between BASELINE configs 3 and 5, where the damping of the
+    # stage-wise direction sets in
+    out.update({"readme_n16_%s" % k: v for k, v in _g3_group(mod, 16, 24, 816).items()})
     np.savez_compressed(os.path.join(OUT, "g8_solves_params.npz"), **out)
 
 

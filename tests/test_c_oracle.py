@@ -260,12 +260,15 @@ def _g8(pset, n_steps):
 
 
 @pytest.mark.parametrize("pset,n_steps,method", [("cut", 3, 0), ("cut", 8, 0), ("cut", 8, 2), ("cut", 3, 1),
-                                                 ("turn", 3, 0), ("turn", 8, 0), ("turn", 8, 2), ("turn", 3, 1), ("turn", 3, 2)])
+                                                 ("turn", 3, 0), ("turn", 8, 0), ("turn", 8, 2), ("turn", 3, 1), ("turn", 3, 2),
+                                                 ("readme", 16, 0), ("readme", 16, 1)])
 def test_p2_p3_solver_mirror_at_other_parameter_sets(pset, n_steps, method):
     """G8: P2 / P3 against the reference's SLSQP solves for parameter sets that take the general code paths (box
     cutting the disc, v_cur outside the feasible set, heading beyond pi/4 within the horizon)."""
     g, params, probs, hm = _g8(pset, n_steps)
     params["method"] = method
+    if method == 1 and n_steps > 8:
+        params["max_iterations"] = 600
     for mask, cells in ((~hm, np.zeros_like(g["cells"])), (hm, g["cells"])):
         cmap = (cells,) + tuple(g["map_meta"])
         cmds, x = _cold_solve(params, cmap, probs[mask])

@@ -165,7 +165,8 @@ def test_p2_p3_against_reference_slsqp_solves(solver_mod, n_steps, method):
 
 
 @pytest.mark.parametrize("pset,n_steps,method", [("cut", 3, 0), ("cut", 8, 0), ("cut", 8, 2), ("cut", 3, 1),
-                                                 ("turn", 3, 0), ("turn", 8, 0), ("turn", 8, 2), ("turn", 3, 1), ("turn", 3, 2)])
+                                                 ("turn", 3, 0), ("turn", 8, 0), ("turn", 8, 2), ("turn", 3, 1), ("turn", 3, 2),
+                                                 ("readme", 16, 0), ("readme", 16, 1)])
 def test_p2_p3_at_other_parameter_sets(solver_mod, pset, n_steps, method):
     """G8: the reference's SLSQP solves for parameter sets that take the GENERAL kernels (not the README-like
     "tame" specialisations): the vx/vy box cutting the speed disc with v_cur outside the feasible set for many
@@ -177,6 +178,8 @@ def test_p2_p3_at_other_parameter_sets(solver_mod, pset, n_steps, method):
     params = util.params_from(g["param_keys"], g[k + "params"])
     assert params["control_steps"] == n_steps
     params["method"] = method
+    if method == 1 and n_steps > 8:
+        params["max_iterations"] = 600
     probs = util.problems_from(g[k + "problems"])
     hm = g[k + "has_map"].astype(bool)
     for mask, cells in ((~hm, np.zeros_like(g[k + "cells"])), (hm, g[k + "cells"])):

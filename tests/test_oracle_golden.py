@@ -189,14 +189,14 @@ def test_g6_analytic_gradient_of_the_solver_mirror(n_steps):
         (np.abs(out - g[k + "grad"]) / np.maximum(scale, 1e-3)).max()
 
 
-@pytest.mark.parametrize("pset", ["cut", "turn"])
+@pytest.mark.parametrize("pset", ["cut", "turn", "readme"])
 def test_g8_restated_objective_at_other_parameter_sets(pset):
     """G8: the reference's own objective values at its SLSQP solutions for parameter sets away from the README's
     (the vx/vy box cutting the speed disc; a fast-turning robot, longer horizon, other weights), control_steps 3
     and 8: the restated objective (Python and C) reproduces them."""
     from oracle import c_oracle
     g = util.load("g8_solves_params.npz")
-    for n_steps in (3, 8):
+    for n_steps in ((16,) if pset == "readme" else (3, 8)):
         k = "%s_n%d_" % (pset, n_steps)
         params = util.params_from(g["param_keys"], g[k + "params"])
         assert params["control_steps"] == n_steps

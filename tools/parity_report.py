@@ -77,8 +77,8 @@ def other_parameter_sets():
     print("\n# other parameter sets (G8): 'cut' = vx/vy box cutting the speed disc; 'turn' = max_vel_theta 3, horizon 1.2 s, "
           "w_orient 2, w_costmap 0.3, w_control 0.1")
     g = util.load("g8_solves_params.npz")
-    for pset in ("cut", "turn"):
-        for n in (3, 8):
+    for pset in ("cut", "turn", "readme"):   # ("readme": the README's parameters at control_steps 16)
+        for n in ((16,) if pset == "readme" else (3, 8)):
             k = "%s_n%d_" % (pset, n)
             params = util.params_from(g["param_keys"], g[k + "params"])
             probs = util.problems_from(g[k + "problems"])
