@@ -11,10 +11,10 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-def random_params(rng):
+def random_params(rng, steps=(1, 2, 3, 3, 3, 4, 6, 8)):
     vmax = rng.uniform(0.2, 1.5)
     p = util.orc.make_params(
-        control_steps=int(rng.choice([1, 2, 3, 3, 3, 4, 6, 8])),
+        control_steps=int(rng.choice(steps)),
         prediction_horizon=float(rng.uniform(0.3, 1.5)),
         w_trans=float(rng.uniform(0.1, 2.0)), w_orient=float(rng.uniform(0.05, 1.0)),
         w_control=float(rng.choice([0.0, 0.02, 0.05, 0.3])), w_terminal=float(rng.uniform(0.0, 0.5)),
@@ -34,16 +34,34 @@ def random_params(rng):
     return p
 
 
-@pytest.mark.parametrize("seed", range(12))
+import os
+
+#: NEO_MPC_FUZZ_SEEDS=<count> runs that many seeds of each test instead of the default dozen / eight (a stress run)
+_SEEDS = int(os.environ.get("NEO_MPC_FUZZ_SEEDS", "0"))
+
+
+@pytest.mark.parametrize("seed", range(_SEEDS or 8))
+def test_random_long_horizon_configuration_matches_cpu_mirror(seed):
+    """The same at long horizons (damped stage-wise direction, trial step, wall model, late window)."""
+    # (float32 sweep on the device, float64 on the mirror: on costmaps the two walk into different local minima now and
+    # then -- in a stress run of 60 seeds the worst had the device above the mirror in 6 of 96 solves and below in 13)
+    _fuzz(seed + 500, steps=(12, 16, 24, 32, 48, 64), count=96, not_worse=0.9)
+
+
+@pytest.mark.parametrize("seed", range(_SEEDS or 12))
 def test_random_configuration_matches_cpu_mirror(seed):
+    _fuzz(seed, steps=(1, 2, 3, 3, 3, 4, 6, 8), count=192)
+
+
+def _fuzz(seed, steps, count, not_worse=0.95):
     from neo_mpc_planner2_amd.solver import BatchSolver
     from oracle import c_oracle
     rng = np.random.default_rng(1000 + seed)
-    params = random_params(rng)
+    params = random_params(rng, steps)
     n = params["control_steps"]
     res = float(rng.choice([0.025, 0.05, 0.1]))
     cmap = synthetic.make_costmap(240, seed=seed, resolution=res)
-    probs = synthetic.make_problems(192, 240, seed=seed + 50, resolution=res)
+    probs = synthetic.make_problems(count, 240, seed=seed + 50, resolution=res)
     probs["cur_vel"] *= params["max_vel_trans"]
     probs["footprint_cost"] = rng.choice([0.0, 0.5, 1.0], size=len(probs), p=[0.8, 0.1, 0.1])
     st, warm = synthetic.make_states(probs, n)
@@ -57,7 +75,7 @@ def test_random_configuration_matches_cpu_mirror(seed):
     assert np.allclose(f_at, cg["cost"], rtol=1e-11, atol=1e-11)
     dv = np.abs(cg["vel"] - cc["vel"]).max(axis=1)
     assert (dv <= 1e-3).mean() >= 0.95, ((dv <= 1e-3).mean(), params)
-    assert (cg["cost"] <= cc["cost"] + 1e-5).mean() >= 0.95
+    assert (cg["cost"] <= cc["cost"] + 1e-5).mean() >= not_worse
     assert (st["collision"] == st_c["collision"]).mean() >= 0.97
     xs = xg.reshape(len(xg), n, 3)
     assert (xs[:, :, 0] <= params["max_vel_x"] + 1e-12).all() and (xs[:, :, 0] >= params["min_vel_x"] - 1e-12).all()
