@@ -11,14 +11,18 @@
 //                     evaluates 64 candidate control sequences at once (one rollout per
 //                     lane): lanes 0-31 walk the projected proximal-gradient arc at 32
 //                     step sizes, lanes 32-63 a projected second-order direction at 32 step
-//                     lengths -- Newton at control_steps <= 8 (finite-difference Hessian of the
-//                     analytic gradient, one column per lane, solved in registers), L-BFGS
-//                     otherwise (rollout/adjoint as DPP prefix scans, lane = step); the lowest
-//                     objective wins (wave arg-min).  Iterates, gradients and the quasi-Newton
+//                     lengths -- dense Newton at control_steps 3 (finite-difference Hessian of the
+//                     analytic gradient, one column per lane, solved in registers; the headline
+//                     specialisation), the stage-wise (Riccati) Gauss-Newton sweep of riccati.h at
+//                     every other control_steps (rollout/adjoint as DPP prefix scans, lane = stage;
+//                     damped beyond 8 steps; wall model for costmap steps; in free space the full
+//                     step is tried alone before the search), projected L-BFGS on request; the lowest
+//                     objective wins (wave arg-min).  Iterates, gradients and the direction's
 //                     state live in LDS; the (2R+1)^2 costmap reach tile is staged into LDS
 //                     once per solve with coalesced dword loads.  float64 throughout (the arc
 //                     search compares objective values, which resolves the minimiser to
-//                     sqrt(eps); MI355X has full-rate vector f64).
+//                     sqrt(eps); MI355X has full-rate vector f64); the Newton systems themselves
+//                     are float32 (they only yield a direction).
 //   K2 postprocess    py:365-403, fused as the epilogue of K1 and launchable on its own.
 //   K3 k_ingest       raw nav2 costmap -> device map with a lethal border and 128-byte
 //                     row pitch (16 B per lane, HBM-streaming).

@@ -18,6 +18,11 @@
 // -- for 1-3 % fewer iterations (measured on the CPU mirror, which carries both variants: 12.07 against
 // 12.21 iterations at control_steps 32, 7.01 / 7.06 at 8).
 //
+// Beyond 8 control steps the block curvature carries an adaptive Levenberg-Marquardt term (k_solve keeps mu: two
+// neighbouring blocks of a long horizon trade displacement at almost no cost, and the undamped step along such a
+// valley leaves the region where the model holds); a stage next to a cost step carries the wall model of costmap.h
+// (curvature on the stage position, and behind a lethal cell a linear push-back term that enters the value gradient).
+//
 // Three passes:
 //   riccati_prepare  lane = stage: rotates everything the sweep needs into the stage's DISPLACEMENT
 //                    coordinates w = B0 du, B0 = dt diag(Rot(theta_i), 1) -- the linearised step is then
