@@ -253,7 +253,7 @@ int neo_mpc_set_costmap_pool_device(neo_mpc_handle* handle, const uint8_t* d_cel
  * Synchronous; host buffers are staged through device memory: every transfer is queued on the null stream
  * around the kernel and waited for once, so page-locked buffers (hipHostMalloc / hipHostRegister) make the
  * call three DMA transfers in, the kernel, and the results out, with one wait (measured at 4096 instances:
- * 0.24 ms against 0.31 ms from pageable memory). */
+ * 0.24-0.28 ms against 0.31-0.47 ms from pageable memory). */
 int neo_mpc_solve_batch(neo_mpc_handle* handle, const neo_mpc_batch* batch);
 /* Same with every pointer in device memory; enqueued on `stream`, returns without waiting. */
 int neo_mpc_solve_batch_device(neo_mpc_handle* handle, const neo_mpc_batch* batch, void* stream);
