@@ -23,10 +23,13 @@ from neo_mpc_planner2_amd.mpc_optimization_server import README_PARAMS  # noqa: 
 from neo_mpc_planner2_amd.solver import BatchSolver, DeviceBatch  # noqa: E402
 
 TICKS, HZ = 40, 30.0
+DUMP_TICK = int(os.environ.get("NEO_MPC_DUMP_TICK", "-1"))
 POOL = "--pool" in sys.argv   # every robot gets its own 200x200 rolling window (neo_mpc_set_costmap_pool)
 cfg, cmap, probs, st, warm = synthetic.make_workload("C2", seed=0)
 params = dict(README_PARAMS)
 params.update(control_steps=3)
+if os.environ.get("NEO_MPC_KINK_RADIUS"):   # study knob
+    params["kink_radius"] = float(os.environ["NEO_MPC_KINK_RADIUS"])
 dev = "cuda:0"
 with BatchSolver(params) as s:
     if POOL:
@@ -51,7 +54,7 @@ with BatchSolver(params) as s:
     P[:, 22] = 1.0 / HZ
     P[:, 23] = 1.0 / HZ
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(TICKS)]
-    iters, stopped = [], []
+    iters, stopped, itmax = [], [], []
     ing = []
     for t in range(TICKS):
         if POOL:
@@ -61,6 +64,9 @@ with BatchSolver(params) as s:
             s.set_costmap_pool(d_cells, 0.05, d_orig)
             e1.record()
             ing.append((e0, e1))
+        if DUMP_TICK == t:   # study: the inputs of this tick, for the CPU mirror (tools: trace the long searches)
+            np.savez(os.path.join(ROOT, "gpurun_out", "fleet_tick%d.npz" % t), problems=b.problems.cpu().numpy(),
+                     states=b.states.cpu().numpy(), warm=b.warm.cpu().numpy())
         evs[t][0].record()
         s.solve_device(b.problems, b.states, b.warm, b.commands, velocities=b.vel)
         evs[t][1].record()
@@ -79,6 +85,9 @@ with BatchSolver(params) as s:
         torch.cuda.synchronize()
         cm = b.commands.cpu().numpy().view(abi.COMMAND_DTYPE).reshape(-1)
         iters.append(float(cm["iterations"].mean()))
+        itmax.append(int(cm["iterations"].max()))
+        if DUMP_TICK == t:
+            np.save(os.path.join(ROOT, "gpurun_out", "fleet_tick%d_iterations.npy" % t), cm["iterations"])
         stopped.append(float(((cm["flags"] & 2) != 0).mean()))
     ms = [a.elapsed_time(e) for a, e in evs]
 extra = {}
@@ -94,4 +103,5 @@ print(json.dumps({
     "warm_ticks_mean_iterations": float(np.mean(iters[5:])),
     "warm_solves_per_s": 4096 / (1e-3 * float(np.median(ms[5:]))),
     "stopped_fraction_last_tick": stopped[-1],
-    "per_tick_kernel_ms": [round(x, 4) for x in ms[:12]], "per_tick_mean_iterations": [round(x, 2) for x in iters[:12]]}))
+    "per_tick_kernel_ms": [round(x, 4) for x in ms[:12]], "per_tick_mean_iterations": [round(x, 2) for x in iters[:12]],
+    "per_tick_max_iterations": itmax[:12], "warm_ticks_max_iterations_median": float(np.median(itmax[5:]))}))
