@@ -171,3 +171,21 @@ def test_cb_params_accepts_rclpy_style_enum_types():
                     NS(name="w_control", value=0.2, type_=3)])
     assert node.w_trans == 0.4 and node.w_control == 0.2 and not hasattr(node, "w_orient")
     assert applied == {"w_trans": 0.4, "w_control": 0.2}
+
+
+def test_bench_cpu_worker_and_cpu_count_without_a_gpu():
+    """The all-cores CPU leg of bench.py: a worker is a fresh interpreter that never touches torch or the HIP
+    library (it runs beside a live HIP runtime on the GPU box), and the process count respects the cgroup quota."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--cpu-worker", "1:4:0.5"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-500:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["done"] > 0 and rec["rate"] > 0.0
+    sys.path.insert(0, root)
+    import bench
+    n = bench.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
