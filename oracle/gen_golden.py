@@ -9,7 +9,12 @@ and the reference's outputs.
 
 Fixture sets: G1 objective/f_constraint values, G2 yaw extraction,
 G3 cold-start SLSQP solves (ftol 1e-3 and 1e-12), G4 stateful optimizer() episodes,
-G5 warm-start shift, G6 SciPy forward-difference gradients, G7 publishLocalPlan paths.
+G5 warm-start shift, G6 SciPy forward-difference gradients, G7 publishLocalPlan paths,
+G8 G3's solves at parameter sets away from the README's (box cutting the disc; fast-turning robot with a
+heavy costmap weight; the README's parameters at control_steps 16), G4b episodes at another parameter set
+(acceleration limits, low-pass gain, footprint weight, box cutting the disc).
+
+    python oracle/gen_golden.py g8 g4b     # regenerates single sets
 """
 import contextlib
 import io
