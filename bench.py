@@ -92,17 +92,34 @@ def pcie_inclusive(solver, probs, st, warm, n, seconds=3.0):
         p_probs, p_st, p_warm = pinned(np.ascontiguousarray(probs)), pinned(st), pinned(warm)
         p_cmd = pinned(np.zeros(count, dtype=abi.COMMAND_DTYPE))
         p_sol = pinned(np.zeros((count, 3 * n)))
-        solver.solve(p_probs, p_st, p_warm, out=(p_cmd, p_sol))
-        reps, t_all = 0, 0.0
-        while t_all < seconds and reps < 200:
+        ref_cmd = None
+        what = {"zerocopy": "page-locked host arrays (torch pin_memory), K1 reads the records and writes the results "
+                            "in place over PCIe: no copy, one launch, one wait",
+                "zerocopy_out": "page-locked arrays: inputs up as three DMA copies, results written in place by K1",
+                "staged": "page-locked arrays staged through device memory: three DMA copies in, K1, four out"}
+        for mode in ("zerocopy", "zerocopy_out", "staged"):
+            solver.set_host_path(mode)
             p_st[...] = st
             p_warm[...] = warm
-            t0 = time.perf_counter()
             solver.solve(p_probs, p_st, p_warm, out=(p_cmd, p_sol))
-            t_all += time.perf_counter() - t0
-            reps += 1
-        res["pinned"] = {"value": count * reps / t_all, "unit": "solves/s", "ms_per_call": 1e3 * t_all / reps, "calls": reps,
-                         "what": "the same call on page-locked host buffers (torch pin_memory)"}
+            if ref_cmd is None:
+                ref_cmd = p_cmd["vel"].copy()
+            same = bool((p_cmd["vel"] == ref_cmd).all())     # (one kernel, three ways of feeding it)
+            reps, t_all = 0, 0.0
+            while t_all < seconds / 2 and reps < 200:
+                p_st[...] = st
+                p_warm[...] = warm
+                t0 = time.perf_counter()
+                solver.solve(p_probs, p_st, p_warm, out=(p_cmd, p_sol))
+                t_all += time.perf_counter() - t0
+                reps += 1
+            rec = {"value": count * reps / t_all, "unit": "solves/s", "ms_per_call": 1e3 * t_all / reps, "calls": reps,
+                   "commands_identical": same, "what": what[mode]}
+            if mode == "zerocopy":
+                res["pinned"] = rec          # the default path of page-locked batches
+            else:
+                res["pinned_" + mode] = rec
+        solver.set_host_path("auto")
     except Exception as e:   # (the pageable figure stands on its own)
         res["pinned"] = {"error": str(e)}
     return res
@@ -175,6 +192,7 @@ def cpu_mirror_rate(params, cmap, probs, st, warm):
     """Secondary: the build's own algorithm on the host cores (oracle/mpc_oracle.c, OpenMP)."""
     from oracle import c_oracle
     c_oracle.load()
+    c_oracle.set_threads(usable_cpus())     # (the OpenMP default is every hardware thread of the host)
     t0 = time.perf_counter()
     c_oracle.solve_batch(params, cmap, probs, st.copy(), warm.copy())
     return len(probs) / (time.perf_counter() - t0)
@@ -191,6 +209,112 @@ def source_sha():
             h.update(name.encode())
             h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
+
+
+
+def pmc_entry(workload, batch):
+    """HBM bytes / VALU instructions per launch from the committed PMC passes (profiles/hbm_traffic.json): reported
+    only while the device sources are the ones the counters were collected on (source_sha) and the batch is the
+    config's; (None, None, reason) otherwise."""
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if not os.path.exists(tpath):
+        return None, None, "no profiles/hbm_traffic.json"
+    try:
+        entry = json.load(open(tpath)).get(workload)
+    except Exception as e:
+        return None, None, "profiles/hbm_traffic.json unreadable: %s" % e
+    if not isinstance(entry, dict):
+        return None, None, "no PMC entry for this workload in profiles/hbm_traffic.json"
+    if entry.get("source_sha") != source_sha():
+        return None, None, "stale: PMC passes ran on source_sha %s, this build is %s" % (entry.get("source_sha"), source_sha())
+    if entry.get("batch") != batch:
+        return None, None, "PMC passes ran at batch %s" % entry.get("batch")
+    return entry.get("hbm_bytes"), entry.get("valu_insts"), entry.get("note")
+
+
+def valu_issue(valu, k_ms):
+    """what actually bounds K1: VALU issue.  SQ_INSTS_VALU of the committed PMC pass x 4 cycles
+    (a wave64 instruction on a 16-lane SIMD) over 1024 SIMDs x this run's kernel time"""
+    if not valu:
+        return None
+    return {"insts_per_launch": valu, "cycles_per_inst": 4, "simds": 1024, "clock_ghz": SIMD_CLOCK_GHZ,
+            "frac": valu * 4 / (1024 * k_ms * 1e-3 * SIMD_CLOCK_GHZ * 1e9)}
+
+
+def other_workload(name, dev, local_rank, steps=3, warmup=1, params_over=None, label=None):
+    """One more BASELINE config on this GPU, HBM-resident, cold start, `steps` launches timed with dispatch-stamped
+    events: so that the driver's line carries C3 / C5 / the C4 shard (and the parameter sets that take the general
+    kernels) next to the headline."""
+    import torch
+    from neo_mpc_planner2_amd import synthetic
+    from neo_mpc_planner2_amd.solver import BatchSolver, DeviceBatch
+    cfg = dict(synthetic.CONFIGS["C2" if name == "C4" else name])
+    if name == "C4":
+        cfg["batch"] = synthetic.CONFIGS["C4"]["batch"] // 8
+    n = cfg["control_steps"]
+    params = readme_params(n)
+    params.update(params_over or {})
+    cmap = synthetic.make_costmap(cfg["map_size"], seed=0)
+    probs = synthetic.make_problems(cfg["batch"], cfg["map_size"], seed=1000)
+    st, warm = synthetic.make_states(probs, n)
+    with BatchSolver(params, device=local_rank) as solver:
+        solver.set_costmap(torch.from_numpy(cmap[0]).to(dev), *cmap[1:])
+        base = DeviceBatch(probs, st, warm, dev, want_solution=False)
+        sets = [base.fresh_state() for _ in range(steps + warmup)]
+        stream = torch.cuda.current_stream()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in sets]
+        for e0, e1 in evs:
+            e0.record(stream)
+            e1.record(stream)
+        torch.cuda.synchronize()
+        t0 = None
+        for i, b in enumerate(sets):
+            if i == warmup:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            solver.solve_device(base.problems, b.states, b.warm, b.commands, velocities=b.vel, events=evs[i])
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        k_ms = float(np.mean([a.elapsed_time(b) for a, b in evs[warmup:]]))
+        cmds = sets[-1].commands_host()
+    algo = ALGO_BYTES.get(n, (17 + 3 * n) * 4 + (3 + 3 * n + 1) * 4 + 729)
+    achieved = algo * cfg["batch"] / (k_ms * 1e-3) / 1e9
+    traffic, valu, note = pmc_entry(name, cfg["batch"]) if not params_over else (None, None, "other parameter set")
+    return {"workload": label or name, "batch": cfg["batch"], "control_steps": n, "map_size": cfg["map_size"],
+            "steps": steps, "value": cfg["batch"] * steps / elapsed, "unit": "solves/s", "ms_per_step": 1e3 * elapsed / steps,
+            "kernel_ms": k_ms,
+            "solver": {"mean_iterations": float(cmds["iterations"].mean()), "max_iterations_seen": int(cmds["iterations"].max()),
+                       "converged_frac": float((cmds["status"] == 0).mean()), "status_max_iter": int((cmds["status"] == 1).sum())},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": note,
+                         "algorithmic_bytes_per_solve": algo},
+            "valu_issue": valu_issue(valu, k_ms)}
+
+
+#: parameter sets away from the README's that take the GENERAL (non-"tame") kernels -- the ones the G8 fixtures pin:
+#: the vx/vy box cutting the speed disc; a fast-turning robot with a heavy costmap weight over a 1.2 s horizon
+GENERAL_SETS = {
+    "C2/cut": dict(max_vel_trans=0.7, max_vel_x=0.4, min_vel_x=-0.2, max_vel_y=0.65, min_vel_y=-0.65),
+    "C2/turn": dict(max_vel_theta=3.0, min_vel_theta=-3.0, w_orient=2.0, w_costmap=0.3, w_control=0.1,
+                    prediction_horizon=1.2),
+}
+
+
+def warm_tick(dev, local_rank, ticks=60):
+    """The deployed mode: the C2 fleet (4096 robots) in a closed 30 Hz control loop, state resident, every tick
+    warm-started the reference's way (py:397-400) -- ms per tick and iterations over the warm ticks."""
+    import torch
+    from neo_mpc_planner2_amd import fleet, synthetic
+    from neo_mpc_planner2_amd.solver import BatchSolver, DeviceBatch
+    cfg, cmap, probs, st, warm = synthetic.make_workload("C2", seed=0)
+    with BatchSolver(readme_params(3), device=local_rank) as solver:
+        solver.set_costmap(torch.from_numpy(cmap[0]).to(dev), *cmap[1:])
+        b = DeviceBatch(probs, st, warm, dev, want_solution=False)
+        res = fleet.summary(fleet.closed_loop(solver, b, ticks))
+    res["what"] = ("C2 fleet in closed loop: 4096 robots, 30 Hz, robots moved by their own commands, warm start = the "
+                   "previous solution shifted by one control step; kernel ms between events around each tick's launch")
+    res["solves_per_s"] = 4096 / (1e-3 * res["ms_per_tick_median"])
+    return res
 
 
 def spawn_ranks(n):
@@ -222,6 +346,9 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="instances per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) leg")
+    ap.add_argument("--no-others", action="store_true",
+                    help="skip the other BASELINE configs (C3, C5, C4 shard, general-kernel parameter sets) and the "
+                         "closed-loop warm ticks that ride in the default line")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)   # internal: one process of the all-cores CPU leg
     ap.add_argument("--max-iterations", type=int, default=None, help="study knob: cap the solver iterations")
     ap.add_argument("--control-steps", type=int, default=None, help="study knob: override the config's control_steps")
@@ -362,7 +489,13 @@ def main():
     kernel_ms = [a.elapsed_time(b) for a, b in evs]
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    per_rank = None
     if use_dist:
+        # every rank's own time beside the maximum: a SCALE run that falls short shows which rank (GPU) was slow
+        mine = torch.tensor([elapsed, float(np.mean(kernel_ms))], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, mine)
+        per_rank = [(float(e[0]), float(e[1])) for e in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -373,26 +506,7 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         algo_bytes = ALGO_BYTES.get(n, (17 + 3 * n) * 4 + (3 + 3 * n + 1) * 4 + 729)   # BASELINE.md's per-solve figure
         achieved = algo_bytes * cfg["batch"] / (k_ms * 1e-3) / 1e9
-        # HBM bytes / VALU instructions per launch from the committed PMC passes (profiles/hbm_traffic.json):
-        # reported only while the device sources are the ones the counters were collected on (source_sha)
-        # and the batch is the config's; null + the reason otherwise
-        traffic = valu = None
-        traffic_note = "no PMC entry for this workload in profiles/hbm_traffic.json"
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                prof = json.load(open(tpath))
-                entry = prof.get(args.workload)
-                if isinstance(entry, dict):
-                    if entry.get("source_sha") != source_sha():
-                        traffic_note = "stale: PMC passes ran on source_sha %s, this build is %s" % (
-                            entry.get("source_sha"), source_sha())
-                    elif entry.get("batch") != cfg["batch"]:
-                        traffic_note = "PMC passes ran at batch %s" % entry.get("batch")
-                    else:
-                        traffic, valu, traffic_note = entry.get("hbm_bytes"), entry.get("valu_insts"), entry.get("note")
-            except Exception as e:
-                traffic_note = "profiles/hbm_traffic.json unreadable: %s" % e
+        traffic, valu, traffic_note = pmc_entry(args.workload, cfg["batch"])
         out = {
             "metric": "MPC solves/sec (control_steps=%d, %dx%d costmap)" % (n, cfg["map_size"], cfg["map_size"]),
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -407,11 +521,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": "k_solve", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_solve": algo_bytes},
-            # what actually bounds K1: VALU issue.  SQ_INSTS_VALU of the committed PMC
-            # pass x 4 cycles (a wave64 instruction on a 16-lane SIMD) over 1024 SIMDs x this run's kernel time
-            "valu_issue": None if not valu else {
-                "insts_per_launch": valu, "cycles_per_inst": 4, "simds": 1024, "clock_ghz": SIMD_CLOCK_GHZ,
-                "frac": valu * 4 / (1024 * k_ms * 1e-3 * SIMD_CLOCK_GHZ * 1e9)},
+            "valu_issue": valu_issue(valu, k_ms),
             **({"study_streams": args.streams} if args.streams > 1 else {}),
             "solver": {"mean_iterations": float(cmds["iterations"].mean()),
                        "max_iterations_seen": int(cmds["iterations"].max()),
@@ -423,10 +533,27 @@ def main():
             out["rccl"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
                            "gather_ms": float(np.mean([a.elapsed_time(b) for a, b in gather_evs])) if gather_evs else None,
                            "gather_bytes_per_rank": cfg["batch"] * 24,
+                           "per_rank": [{"rank": r, "ms_per_step": 1e3 * e / args.steps, "kernel_ms": k,
+                                         "value": cfg["batch"] * args.steps / e} for r, (e, k) in enumerate(per_rank)],
                            "what": "one all-gather of (vx, vy, w) per step on a side stream, overlapped with the next "
                                    "step's solve; gather_ms = its own duration (events on the side stream)"}
         if world == 1 and not args.no_pcie:
             out["pcie_inclusive"] = pcie_inclusive(solver, probs, st, warm, n)
+        if world == 1 and not args.no_others and args.workload == "C2" and not args.batch:
+            # the other BASELINE configs and the deployed (closed-loop, warm-started) mode, a few launches each, so
+            # that the driver's line carries them; the inputs are generated here, outside every timed region
+            others = []
+            for name, over, label in [("C3", None, None), ("C5", None, None), ("C4", None, "C4 per-GPU shard")] + \
+                    [("C2", GENERAL_SETS[k], k) for k in sorted(GENERAL_SETS)]:
+                try:
+                    others.append(other_workload(name, dev, local_rank, params_over=over, label=label))
+                except Exception as e:
+                    others.append({"workload": label or name, "error": str(e)})
+            out["other_workloads"] = others
+            try:
+                out["warm_tick"] = warm_tick(dev, local_rank)
+            except Exception as e:
+                out["warm_tick"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
             rate, cnt, secs = cpu_baseline(params, cmap, probs)
             out["cpu_baseline"] = {"value": rate, "unit": "solves/s", "cores": 1, "kind": "port",
@@ -445,7 +572,7 @@ def main():
             try:
                 sub = min(len(probs), 4096)
                 out["cpu_mirror"] = {"value": cpu_mirror_rate(params, cmap, probs[:sub], st[:sub], warm[:sub]),
-                                     "unit": "solves/s", "cores": usable_cpus(), "omp_threads": os.cpu_count(),
+                                     "unit": "solves/s", "cores": usable_cpus(), "omp_threads": usable_cpus(),
                                      "what": "the build's own algorithm in C with OpenMP (oracle/mpc_oracle.c)"}
             except Exception as e:  # the mirror is informational
                 out["cpu_mirror"] = {"error": str(e)}

@@ -11,6 +11,7 @@
 //   g++ -std=c++17 -I include examples/plugin_seam.cpp -L neo_mpc_planner2_amd -lneo_mpc
 //       (tests/test_abi.py::test_plugin_seam_example_compiles_and_links does this)
 #include <chrono>
+#include <functional>
 #include <stdexcept>
 #include <string>
 
@@ -44,10 +45,16 @@ struct NeoMpcPlannerSeam {
   neo_mpc_handle* mpc_ = nullptr;       // replaces rclcpp::Client<neo_srvs2::srv::Optimizer>::SharedPtr client
   neo_mpc_state mpc_state_{};           // the state the Python node kept (py:115-152)
   double mpc_warm_[3 * NEO_MPC_MAX_CONTROL_STEPS] = {};
-  std::chrono::steady_clock::time_point mpc_last_call_{};
+  double mpc_last_call_ = 0.0;           // seconds on mpc_clock_
   bool mpc_called_ = false;
+  // the Python node stamped its calls with time.time() (py:369); a test injects a deterministic clock here
+  std::function<double()> mpc_clock_ = [] {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  };
   double control_frequency = 30.0;
   bool closer_to_goal = false;
+  neo_mpc_problem last_request_{};      // (diagnostics: what the last tick sent and got -- `--dump` records them)
+  neo_mpc_command last_command_{};
 
   // configure(): replaces create_client (cpp:308) and the wait_for_service loop (cpp:325-330).
   // `declare` stands for the plugin's declare_parameter_if_not_declared/get_parameter pair; the
@@ -110,14 +117,15 @@ struct NeoMpcPlannerSeam {
     req.goal_q[2] = goal_pose.orientation.z; req.goal_q[3] = goal_pose.orientation.w;
     req.cur_vel[0] = speed.linear.x; req.cur_vel[1] = speed.linear.y; req.cur_vel[2] = speed.angular.z;
     req.control_interval = 1.0 / control_frequency;          // cpp:246
-    const auto now = std::chrono::steady_clock::now();        // py:369-371 (wall clock between calls)
-    req.delta_t = mpc_called_ ? std::chrono::duration<double>(now - mpc_last_call_).count() : 1.0e9;
+    const double now = mpc_clock_();                          // py:369-371 (wall clock between calls)
+    req.delta_t = mpc_called_ ? now - mpc_last_call_ : 1.0e9;
     mpc_last_call_ = now; mpc_called_ = true;
     // footprintCostAtPose (cpp:218-219) is already computed by the plugin on nav2's 0..255 scale;
     // 254 (lethal) is what the Python node saw as getFootprintCost(...) == 1.0 (py:343)
     req.footprint_cost = footprint_cost_raw >= 254.0 ? 1.0 : 0.0;
     req.switch_opt = 0;                        // cpp:245 closer_to_goal (stored by the node, py:354, never read)
 
+    last_request_ = req;
     neo_mpc_command out{};
     neo_mpc_batch batch{};
     batch.count = 1;
@@ -125,6 +133,7 @@ struct NeoMpcPlannerSeam {
     if (neo_mpc_solve_batch(mpc_, &batch) != NEO_MPC_OK)     // == async_send_request + result.get()
       throw ControllerException(neo_mpc_last_error());
 
+    last_command_ = out;
     geometry_msgs::msg::TwistStamped cmd_vel_final;           // == out->output_vel (cpp:251-252)
     cmd_vel_final.twist.linear.x = out.vel[0];
     cmd_vel_final.twist.linear.y = out.vel[1];
@@ -138,6 +147,14 @@ struct NeoMpcPlannerSeam {
 // that slides along a straight plan, costmap handed over every tick, README parameters
 // (README.md:53-84) -- and prints the per-tick latency of `solve()` (set_costmap + solve_batch,
 // host buffers, count = 1).  tests/test_gpu_parity.py runs it on the GPU box.
+//   --ticks N        number of control ticks (default 300)
+//   --fake-clock     the wall clock of py:369 advances exactly one control interval per tick (deterministic latch)
+//   --obstacle       the rolling costmap CHANGES while the robot drives: a lethal block appears across the plan at
+//                    tick 60 and is gone again at tick 260 -- the per-tick costmap hand-over (cpp:290-334's
+//                    costmap_, getCharMap()) is what makes the robot stop in front of it (collision latch,
+//                    py:312-347, 374-382) and move on afterwards
+//   --dump FILE      every tick's request, state and warm start before and after, command and costmap version
+//                    (tests replay them through the oracle, tick by tick)
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -150,6 +167,16 @@ int main(int argc, char** argv) {
     (void)seam;
     return neo_mpc_abi_version() == NEO_MPC_ABI_VERSION ? 0 : 1;
   }
+  int ticks = 300;
+  bool fake_clock = false, obstacle = false;
+  const char* dump_path = nullptr;
+  for (int k = 2; k < argc; ++k) {
+    if (!std::strcmp(argv[k], "--ticks") && k + 1 < argc) ticks = std::atoi(argv[++k]);
+    else if (!std::strcmp(argv[k], "--fake-clock")) fake_clock = true;
+    else if (!std::strcmp(argv[k], "--obstacle")) obstacle = true;
+    else if (!std::strcmp(argv[k], "--dump") && k + 1 < argc) dump_path = argv[++k];
+    else { std::fprintf(stderr, "unknown option %s\n", argv[k]); return 64; }
+  }
   NeoMpcPlannerSeam seam;
   seam.configureSolver([](const char* name, double dflt) {   // the README's YAML block
     const struct { const char* n; double v; } readme[] = {
@@ -161,18 +188,43 @@ int main(int argc, char** argv) {
     for (const auto& kv : readme) if (std::strcmp(kv.n, name) == 0) return kv.v;
     return dflt;
   });
+  double fake_now = 1000.0;
+  if (fake_clock) seam.mpc_clock_ = [&fake_now] { return fake_now; };
   const unsigned S = 200;                                      // 10 m x 10 m rolling window, 5 cm cells
   std::vector<unsigned char> cells(S * S, 0);
   for (unsigned y = 120; y < 130; ++y) for (unsigned x = 40; x < 160; ++x) cells[y * S + x] = 254;   // a wall north of the path
+  const std::vector<unsigned char> cells_clear = cells;
+  std::vector<unsigned char> cells_blocked = cells;
+  for (unsigned y = 70; y < 120; ++y) for (unsigned x = 110; x < 114; ++x) cells_blocked[y * S + x] = 254;   // across the plan at x = 0.5 m
   nav2_costmap_2d::Costmap2D costmap;
   costmap.cells = cells.data(); costmap.sx = S; costmap.sy = S; costmap.res = 0.05; costmap.ox = -5.0; costmap.oy = -5.0;
+  std::FILE* dump = nullptr;
+  neo_mpc_params used{};
+  neo_mpc_get_params(seam.mpc_, &used);
+  const int nv = 3 * used.control_steps;
+  if (dump_path) {
+    dump = std::fopen(dump_path, "wb");
+    if (!dump) { std::perror(dump_path); return 65; }
+    // header: magic, ticks, control_steps, map size, maps; parameters; map geometry; the two costmap versions
+    const char magic[8] = {'N', 'E', 'O', 'S', 'E', 'A', 'M', '1'};
+    const int32_t hdr[4] = {ticks, used.control_steps, (int32_t)S, 2};
+    const double geom[3] = {costmap.res, costmap.ox, costmap.oy};
+    std::fwrite(magic, 1, 8, dump); std::fwrite(hdr, 4, 4, dump); std::fwrite(&used, sizeof(used), 1, dump);
+    std::fwrite(geom, 8, 3, dump);
+    std::fwrite(cells_clear.data(), 1, cells_clear.size(), dump);
+    std::fwrite(cells_blocked.data(), 1, cells_blocked.size(), dump);
+  }
   double x = -3.0, y = 0.0, yaw = 0.3;
   geometry_msgs::msg::Twist speed;
   geometry_msgs::msg::Pose goal;
   goal.position.x = 4.0; goal.orientation.w = 1.0;
   std::vector<double> us;
   double worst = 0.0;
-  for (int tick = 0; tick < 300; ++tick) {
+  int stopped_ticks = 0;
+  for (int tick = 0; tick < ticks; ++tick) {
+    // the local costmap as nav2 would have updated it by now, in the buffer getCharMap() points at
+    const bool blocked = obstacle && tick >= 60 && tick < 260;
+    std::memcpy(cells.data(), blocked ? cells_blocked.data() : cells_clear.data(), cells.size());
     geometry_msgs::msg::PoseStamped position, carrot;
     position.pose.position.x = x; position.pose.position.y = y;
     position.pose.orientation.z = std::sin(0.5 * yaw); position.pose.orientation.w = std::cos(0.5 * yaw);
@@ -182,22 +234,39 @@ int main(int argc, char** argv) {
     carrot.pose.position.x = std::cos(yaw) * dx + std::sin(yaw) * dy;
     carrot.pose.position.y = -std::sin(yaw) * dx + std::cos(yaw) * dy;
     carrot.pose.orientation.z = std::sin(-0.5 * yaw); carrot.pose.orientation.w = std::cos(-0.5 * yaw);
+    const neo_mpc_state state_before = seam.mpc_state_;
+    double warm_before[3 * NEO_MPC_MAX_CONTROL_STEPS];
+    std::memcpy(warm_before, seam.mpc_warm_, sizeof(warm_before));
+    fake_now += 1.0 / seam.control_frequency;
     const auto t0 = std::chrono::steady_clock::now();
     const auto cmd = seam.solve(position, speed, carrot, goal, costmap, /*footprint_cost_raw=*/0.0);
     const double dt_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     if (tick >= 20) us.push_back(dt_us);
+    if (dump) {
+      const int32_t which[2] = {blocked ? 1 : 0, tick};
+      std::fwrite(which, 4, 2, dump);
+      std::fwrite(&seam.last_request_, sizeof(neo_mpc_problem), 1, dump);
+      std::fwrite(&state_before, sizeof(neo_mpc_state), 1, dump);
+      std::fwrite(warm_before, 8, nv, dump);
+      std::fwrite(&seam.last_command_, sizeof(neo_mpc_command), 1, dump);
+      std::fwrite(&seam.mpc_state_, sizeof(neo_mpc_state), 1, dump);
+      std::fwrite(seam.mpc_warm_, 8, nv, dump);
+    }
     const double vx = cmd.twist.linear.x, vy = cmd.twist.linear.y, w = cmd.twist.angular.z;
     if (!std::isfinite(vx) || !std::isfinite(vy) || !std::isfinite(w)) { std::printf("non-finite command at tick %d\n", tick); return 2; }
+    if (seam.last_command_.flags & NEO_MPC_FLAG_STOPPED) ++stopped_ticks;
     worst = std::max(worst, std::hypot(vx, vy));
     yaw += w / 30.0;
     x += (vx * std::cos(yaw) - vy * std::sin(yaw)) / 30.0;
     y += (vx * std::sin(yaw) + vy * std::cos(yaw)) / 30.0;
     speed.linear.x = vx; speed.linear.y = vy; speed.angular.z = w;
   }
+  if (dump) std::fclose(dump);
   seam.cleanupSolver();
   std::sort(us.begin(), us.end());
-  std::printf("{\"what\": \"plugin seam (C++ -> C-ABI, host buffers, count = 1), 280 warm ticks\", \"tick_us_median\": %.1f, "
-              "\"tick_us_p99\": %.1f, \"final_x\": %.3f, \"final_y\": %.3f, \"final_yaw\": %.3f, \"max_speed\": %.3f}\n",
-              us[us.size() / 2], us[us.size() * 99 / 100], x, y, yaw, worst);
+  std::printf("{\"what\": \"plugin seam (C++ -> C-ABI, host buffers, count = 1), %d warm ticks\", \"tick_us_median\": %.1f, "
+              "\"tick_us_p99\": %.1f, \"final_x\": %.3f, \"final_y\": %.3f, \"final_yaw\": %.3f, \"max_speed\": %.3f, "
+              "\"stopped_ticks\": %d}\n",
+              (int)us.size(), us[us.size() / 2], us[us.size() * 99 / 100], x, y, yaw, worst, stopped_ticks);
   return (x > 3.0 && std::fabs(y) < 0.2 && worst <= 0.7 + 1e-9) ? 0 : 3;
 }

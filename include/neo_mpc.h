@@ -249,12 +249,24 @@ int neo_mpc_set_costmap_pool_device(neo_mpc_handle* handle, const uint8_t* d_cel
                                     const double* d_origins, void* stream);
 
 /* Replaces `client->async_send_request(request); result.get()` (cpp:248-250), i.e. the whole of
- * `MpcOptimizationServer.optimizer` (py:349-403), for `count` independent instances.
- * Synchronous; host buffers are staged through device memory: every transfer is queued on the null stream
- * around the kernel and waited for once, so page-locked buffers (hipHostMalloc / hipHostRegister) make the
- * call three DMA transfers in, the kernel, and the results out, with one wait (measured at 4096 instances:
- * 0.24-0.28 ms against 0.31-0.47 ms from pageable memory). */
+ * `MpcOptimizationServer.optimizer` (py:349-403), for `count` independent instances.  Synchronous.
+ * Pageable host arrays are staged through device memory (copies queued around the kernel, one wait).  When EVERY
+ * array of the batch is page-locked (hipHostMalloc, hipHostRegister, neo_mpc_pin_host_memory below, torch
+ * pin_memory) nothing is copied: the kernel reads the records from the caller's arrays and writes the results into
+ * them over PCIe while other instances compute -- one launch and one wait per call. */
 int neo_mpc_solve_batch(neo_mpc_handle* handle, const neo_mpc_batch* batch);
+/* Page-locks `bytes` of host memory at `ptr` for the device (hipHostRegister) / releases it: lets a caller built
+ * without HIP headers -- the nav2 plugin is plain g++ -- keep its request arena where neo_mpc_solve_batch can work on
+ * it in place.  The caller unpins before it frees the memory. */
+int neo_mpc_pin_host_memory(void* ptr, size_t bytes);
+int neo_mpc_unpin_host_memory(void* ptr);
+/* How neo_mpc_solve_batch moves a batch whose arrays are all page-locked (pageable arrays are always staged). */
+#define NEO_MPC_HOST_PATH_AUTO 0          /* = ZEROCOPY (the environment variable NEO_MPC_HOST_PATH=staged|zerocopy|
+                                             zerocopy_out overrides AUTO, for A/B runs) */
+#define NEO_MPC_HOST_PATH_STAGED 1        /* copies into device staging and back (DMA), as for pageable arrays */
+#define NEO_MPC_HOST_PATH_ZEROCOPY 2      /* the kernel reads and writes the caller's arrays in place */
+#define NEO_MPC_HOST_PATH_ZEROCOPY_OUT 3  /* inputs copied up by DMA, results written in place by the kernel */
+int neo_mpc_set_host_path(neo_mpc_handle* handle, int mode);
 /* Same with every pointer in device memory; enqueued on `stream`, returns without waiting. */
 int neo_mpc_solve_batch_device(neo_mpc_handle* handle, const neo_mpc_batch* batch, void* stream);
 /* Same; `start_event` / `stop_event` (hipEvent_t, either may be NULL) are stamped with the start and the

@@ -21,7 +21,7 @@ EXPORTS = (
     "neo_mpc_set_costmap_device", "neo_mpc_set_costmap_pool", "neo_mpc_set_costmap_pool_device", "neo_mpc_solve_batch", "neo_mpc_solve_batch_device",
     "neo_mpc_solve_batch_device_timed",
     "neo_mpc_postprocess_batch", "neo_mpc_objective_batch", "neo_mpc_gradient_batch", "neo_mpc_direction_batch",
-    "neo_mpc_kernel_info",
+    "neo_mpc_kernel_info", "neo_mpc_pin_host_memory", "neo_mpc_unpin_host_memory", "neo_mpc_set_host_path",
     "neo_mpc_select_carrots", "neo_mpc_select_carrots_device",
     "neo_mpc_rccl_available", "neo_mpc_comm_init_all", "neo_mpc_comm_destroy", "neo_mpc_group_start",
     "neo_mpc_group_end", "neo_mpc_allgather_velocities", "neo_mpc_broadcast_costmap",
@@ -81,6 +81,9 @@ def load():
     lib.neo_mpc_select_carrots.argtypes = [C.c_void_p, P(abi.NeoMpcLookaheadParams), P(abi.NeoMpcPlanBatch)]
     lib.neo_mpc_select_carrots_device.argtypes = [C.c_void_p, P(abi.NeoMpcLookaheadParams),
                                                   P(abi.NeoMpcPlanBatch), C.c_void_p]
+    lib.neo_mpc_pin_host_memory.argtypes = [C.c_void_p, C.c_size_t]
+    lib.neo_mpc_unpin_host_memory.argtypes = [C.c_void_p]
+    lib.neo_mpc_set_host_path.argtypes = [C.c_void_p, C.c_int]
     lib.neo_mpc_kernel_info.argtypes = [C.c_void_p, P(C.c_uint32), P(C.c_uint32), P(C.c_uint32)]
     for name in EXPORTS:
         getattr(lib, name)     # AttributeError here = the .so is older than include/neo_mpc.h

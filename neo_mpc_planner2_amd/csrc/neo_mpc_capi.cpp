@@ -91,10 +91,15 @@ struct neo_mpc_handle {
   DeviceBuffer arena;
   // Stream ordering around the device map: every ingest records map_ready on the stream it ran on and
   // every solve / postprocess / objective launch waits for it on its own stream; every such launch
-  // records map_in_use and the next ingest waits for that before it rewrites map_buf in place.
-  hipEvent_t map_ready = nullptr, map_in_use = nullptr;
-  bool map_used = false;
+  // records the in-use event OF ITS STREAM (one per distinct stream the caller has used), and the next
+  // ingest waits for all of them -- and for the previous ingest -- before it rewrites map_buf in place.
+  hipEvent_t map_ready = nullptr;
+  hipStream_t map_ready_stream = nullptr;   // (waits on the stream an event was recorded on are skipped: in order anyway)
+  struct MapUser { hipStream_t stream; hipEvent_t done; bool pending; };
+  std::vector<MapUser> map_users;
+  int host_path = NEO_MPC_HOST_PATH_AUTO;   // neo_mpc_set_host_path
 };
+constexpr size_t kMaxMapUsers = 64;   // distinct streams with a launch in flight between two ingests
 constexpr size_t kLatencyPathMaxCount = 64;
 constexpr size_t kLatencyPathBytes = kLatencyPathMaxCount * (sizeof(neo_mpc_problem) + sizeof(neo_mpc_state) +
                                                             sizeof(neo_mpc_command) + 24 +
@@ -250,8 +255,14 @@ int ingest(neo_mpc_handle* h, const uint8_t* d_cells, uint32_t maps, uint32_t sx
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (!h->map_ready) HIP_TRY(hipEventCreateWithFlags(&h->map_ready, hipEventDisableTiming));
-  if (!h->map_in_use) HIP_TRY(hipEventCreateWithFlags(&h->map_in_use, hipEventDisableTiming));
-  if (h->map_used) HIP_TRY(hipStreamWaitEvent(st, h->map_in_use, 0));   // solves still reading the old map
+  // behind the previous ingest (two ingests on different streams must not overlap in map_buf) ...
+  else if (h->map_ready_stream != st) HIP_TRY(hipStreamWaitEvent(st, h->map_ready, 0));
+  // ... and behind every launch still reading the old map, whatever stream it went to
+  for (auto& u : h->map_users)
+    if (u.pending) {
+      if (u.stream != st) HIP_TRY(hipStreamWaitEvent(st, u.done, 0));
+      u.pending = false;
+    }
   IngestArgs a;
   a.src = d_cells;
   a.dst = (uint8_t*)h->map_buf.ptr;
@@ -260,6 +271,7 @@ int ingest(neo_mpc_handle* h, const uint8_t* d_cells, uint32_t maps, uint32_t sx
   launch_ingest(a, stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(h->map_ready, st));
+  h->map_ready_stream = st;
   h->map.cells = (const uint8_t*)h->map_buf.ptr + (size_t)border * pitch + border;
   h->map.size_x = (int)sx; h->map.size_y = (int)sy; h->map.pitch = pitch;
   h->map.resolution = res; h->map.inv_resolution = 1.0 / res;
@@ -285,6 +297,7 @@ int fill_args(neo_mpc_handle* h, const neo_mpc_batch* b, SolveArgs& a) {
   std::memset(&a, 0, sizeof(a));
   a.problems = b->problems; a.states = b->states; a.warm = b->warm_start; a.commands = b->commands;
   a.solution = b->solution; a.path = b->predicted_path; a.velocities = b->velocities;
+  a.states_out = b->states; a.warm_out = b->warm_start;
   a.footprints = b->footprint_points ? b->footprints : nullptr;
   a.footprint_points = b->footprints ? b->footprint_points : 0;
   a.count = (uint32_t)b->count;
@@ -295,14 +308,30 @@ int fill_args(neo_mpc_handle* h, const neo_mpc_batch* b, SolveArgs& a) {
 
 // order a launch that reads the device map on `stream`: behind the last ingest ...
 int map_acquire(neo_mpc_handle* h, void* stream) {
-  if (h->map_ready) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, h->map_ready, 0));
+  if (h->map_ready && h->map_ready_stream != (hipStream_t)stream)
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, h->map_ready, 0));
   return NEO_MPC_OK;
 }
-// ... and in front of the next one
+// ... and in front of the next one: one event per distinct stream, re-recorded by that stream's latest launch
 int map_release(neo_mpc_handle* h, void* stream) {
-  if (!h->map_in_use) HIP_TRY(hipEventCreateWithFlags(&h->map_in_use, hipEventDisableTiming));
-  HIP_TRY(hipEventRecord(h->map_in_use, (hipStream_t)stream));
-  h->map_used = true;
+  hipStream_t st = (hipStream_t)stream;
+  neo_mpc_handle::MapUser* slot = nullptr;
+  for (auto& u : h->map_users) if (u.stream == st) { slot = &u; break; }
+  if (!slot) {
+    if (h->map_users.size() >= kMaxMapUsers) {
+      // more streams than slots: the oldest slot's launch is waited for here and the slot re-used
+      slot = &h->map_users.front();
+      if (slot->pending) HIP_TRY(hipEventSynchronize(slot->done));
+      slot->stream = st;
+    } else {
+      hipEvent_t ev;
+      HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      h->map_users.push_back({st, ev, false});
+      slot = &h->map_users.back();
+    }
+  }
+  HIP_TRY(hipEventRecord(slot->done, st));
+  slot->pending = true;
   return NEO_MPC_OK;
 }
 
@@ -427,7 +456,7 @@ void neo_mpc_destroy(neo_mpc_handle* h) {
   for (DeviceBuffer* b : all) b->release();
   if (h->pin) (void)hipHostFree(h->pin);
   if (h->map_ready) (void)hipEventDestroy(h->map_ready);
-  if (h->map_in_use) (void)hipEventDestroy(h->map_in_use);
+  for (auto& u : h->map_users) (void)hipEventDestroy(u.done);
   delete h;
 }
 
@@ -548,6 +577,63 @@ static int solve_batch_latency_path(neo_mpc_handle* h, const neo_mpc_batch* b) {
   return NEO_MPC_OK;
 }
 
+// Is `p` page-locked host memory the device can address (hipHostMalloc / hipHostRegister / neo_mpc_pin_host_memory /
+// torch pin_memory)?  -> its device-side address.
+static bool pinned_host(const void* p, void** dev) {
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // (unregistered memory: an error before ROCm 6)
+  if (at.type != hipMemoryTypeHost || !at.devicePointer) return false;
+  *dev = at.devicePointer;
+  return true;
+}
+
+// neo_mpc_solve_batch when every array of the batch is page-locked: no staging copy at all.
+//  kZeroCopy  K1 reads the request / state / warm-start records straight from the caller's arrays over PCIe -- they
+//             are read once, at the start of each wave, as coalesced 8-byte-per-lane loads -- and writes commands,
+//             state, warm start (and solution / path / velocities) straight back; the link is busy while other
+//             waves compute.  One launch, one wait.
+//  kZeroCopyOut  the inputs go up as three DMA copies into device staging, the results are written straight into the
+//             caller's arrays by K1 (no D2H copies).
+// NEO_MPC_HOST_PATH=staged|zerocopy|zerocopy_out overrides the default for A/B runs.
+enum HostPath { kStaged = NEO_MPC_HOST_PATH_STAGED, kZeroCopy = NEO_MPC_HOST_PATH_ZEROCOPY,
+                kZeroCopyOut = NEO_MPC_HOST_PATH_ZEROCOPY_OUT };
+static HostPath host_path_mode(const neo_mpc_handle* h) {
+  if (h->host_path != NEO_MPC_HOST_PATH_AUTO) return (HostPath)h->host_path;
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("NEO_MPC_HOST_PATH");
+    mode = !e ? kZeroCopy : !strcmp(e, "staged") ? kStaged : !strcmp(e, "zerocopy_out") ? kZeroCopyOut : kZeroCopy;
+  }
+  return (HostPath)mode;
+}
+
+static int solve_batch_zero_copy(neo_mpc_handle* h, const neo_mpc_batch* b, const neo_mpc_batch& dev, HostPath mode) {
+  const size_t n = b->count, nv = 3 * (size_t)h->params.control_steps;
+  neo_mpc_batch d = dev;          // every pointer: the device-side address of the caller's page-locked array
+  SolveArgs a;
+  int rc;
+  auto bail = [](int code) { (void)hipStreamSynchronize(nullptr); return code; };
+  if (mode == kZeroCopyOut) {
+    if ((rc = h->problems.reserve(n * sizeof(neo_mpc_problem)))) return rc;
+    if ((rc = h->states.reserve(n * sizeof(neo_mpc_state)))) return rc;
+    if ((rc = h->warm.reserve(n * nv * 8))) return rc;
+    HIP_TRY(hipMemcpyAsync(h->problems.ptr, b->problems, n * sizeof(neo_mpc_problem), hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(h->states.ptr, b->states, n * sizeof(neo_mpc_state), hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(h->warm.ptr, b->warm_start, n * nv * 8, hipMemcpyHostToDevice, nullptr));
+    d.problems = (const neo_mpc_problem*)h->problems.ptr;
+    d.states = (neo_mpc_state*)h->states.ptr;
+    d.warm_start = (double*)h->warm.ptr;
+  }
+  if ((rc = fill_args(h, &d, a))) return bail(rc);
+  a.states_out = dev.states; a.warm_out = dev.warm_start;
+  if ((rc = map_acquire(h, nullptr))) return bail(rc);
+  launch_solve(a, nullptr);
+  if (hipGetLastError() != hipSuccess) return bail(fail(NEO_MPC_ERR_DEVICE, "kernel launch failed"));
+  if ((rc = map_release(h, nullptr))) return bail(rc);
+  HIP_TRY(hipStreamSynchronize(nullptr));   // kernel end = system-scope release: the results are in the caller's arrays
+  return NEO_MPC_OK;
+}
+
 int neo_mpc_solve_batch(neo_mpc_handle* h, const neo_mpc_batch* batch) {
   SolveArgs a;
   int rc = fill_args(h, batch, a);  // validates
@@ -556,6 +642,17 @@ int neo_mpc_solve_batch(neo_mpc_handle* h, const neo_mpc_batch* batch) {
   HIP_TRY(hipSetDevice(h->device));
   if (batch->count <= kLatencyPathMaxCount && !batch->footprints)
     return solve_batch_latency_path(h, batch);
+  if (host_path_mode(h) != kStaged) {
+    // page-locked arrays throughout (a fleet server's request arena): K1 works on them in place
+    neo_mpc_batch dv = *batch;
+    bool all = pinned_host(batch->problems, (void**)&dv.problems) && pinned_host(batch->states, (void**)&dv.states) &&
+               pinned_host(batch->warm_start, (void**)&dv.warm_start) && pinned_host(batch->commands, (void**)&dv.commands);
+    if (all && batch->solution) all = pinned_host(batch->solution, (void**)&dv.solution);
+    if (all && batch->predicted_path) all = pinned_host(batch->predicted_path, (void**)&dv.predicted_path);
+    if (all && batch->velocities) all = pinned_host(batch->velocities, (void**)&dv.velocities);
+    if (all && batch->footprints && batch->footprint_points) all = pinned_host(batch->footprints, (void**)&dv.footprints);
+    if (all) return solve_batch_zero_copy(h, batch, dv, host_path_mode(h));
+  }
   neo_mpc_batch d;
   // (the staging copies are asynchronous: no way out of here while one may still be reading the caller's buffers)
   auto bail = [](int code) { (void)hipStreamSynchronize(nullptr); return code; };
@@ -566,6 +663,27 @@ int neo_mpc_solve_batch(neo_mpc_handle* h, const neo_mpc_batch* batch) {
   if (hipGetLastError() != hipSuccess) return bail(fail(NEO_MPC_ERR_DEVICE, "kernel launch failed"));
   if ((rc = map_release(h, nullptr))) return bail(rc);
   return bail(stage_out(h, batch, true));   // (queued behind the kernel on the null stream, one wait at the end)
+}
+
+int neo_mpc_set_host_path(neo_mpc_handle* h, int mode) {
+  if (!h) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "null handle");
+  if (mode < NEO_MPC_HOST_PATH_AUTO || mode > NEO_MPC_HOST_PATH_ZEROCOPY_OUT)
+    return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "unknown host path %d", mode);
+  h->host_path = mode;
+  return NEO_MPC_OK;
+}
+
+// Page-lock / release a host array of the caller's (hipHostRegister / hipHostUnregister behind a C signature, for
+// callers built without the HIP headers -- the nav2 plugin is plain g++).
+int neo_mpc_pin_host_memory(void* ptr, size_t bytes) {
+  if (!ptr || bytes == 0) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "null argument");
+  HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable));
+  return NEO_MPC_OK;
+}
+int neo_mpc_unpin_host_memory(void* ptr) {
+  if (!ptr) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "null argument");
+  HIP_TRY(hipHostUnregister(ptr));
+  return NEO_MPC_OK;
 }
 
 int neo_mpc_postprocess_batch(neo_mpc_handle* h, const neo_mpc_batch* batch, const int32_t* success) {

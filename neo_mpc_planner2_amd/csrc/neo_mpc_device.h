@@ -140,6 +140,8 @@ struct SolveArgs {
   const double* footprints;  // optional
   const int32_t* success;    // postprocess only, optional
   double* velocities;        // optional packed [count][3] copy of the commands
+  neo_mpc_state* states_out; // where K2 writes the state / the warm start back: the arrays they were read from
+  double* warm_out;          // (device batches), or the caller's page-locked host arrays (neo_mpc_solve_batch)
   const double* term_table;  // [256] per-step costmap term by raw cell value
   uint32_t footprint_points;
   uint32_t count;

@@ -31,6 +31,7 @@ struct Rccl {
   int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   bool ok = false;
+  char why[256] = "";   // why it is not: the dlopen error, captured where it happened (dlerror() reads once, per thread)
 };
 constexpr int kNcclUint8 = 1, kNcclDouble = 8;   // ncclDataType_t
 
@@ -41,6 +42,8 @@ Rccl& rccl() {
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
       r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
       if (r.lib) break;
+      const char* e = dlerror();
+      if (e) snprintf(r.why, sizeof(r.why), "%s", e);
     }
     if (!r.lib) return;
 #define NEO_SYM(field, sym) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, sym))
@@ -50,13 +53,13 @@ Rccl& rccl() {
 #undef NEO_SYM
     r.ok = r.CommInitAll && r.CommDestroy && r.CommCount && r.AllGather && r.Broadcast && r.GroupStart && r.GroupEnd &&
            r.GetErrorString;
+    if (!r.ok) snprintf(r.why, sizeof(r.why), "librccl.so lacks one of the nccl* entry points this library binds");
   });
   return r;
 }
 
 int need_rccl() {
-  if (!rccl().ok) return neo_mpc_set_error(NEO_MPC_ERR_UNSUPPORTED, "RCCL (librccl.so) could not be loaded: %s",
-                                           rccl().lib ? "missing symbols" : dlerror());
+  if (!rccl().ok) return neo_mpc_set_error(NEO_MPC_ERR_UNSUPPORTED, "RCCL (librccl.so) could not be loaded: %s", rccl().why);
   return NEO_MPC_OK;
 }
 
@@ -69,7 +72,7 @@ int check(int rc, const char* what) {
 
 extern "C" {
 
-int neo_mpc_rccl_available(void) { return rccl().ok ? 1 : 0; }
+int neo_mpc_rccl_available(void) { return need_rccl() == NEO_MPC_OK ? 1 : 0; }   // (0: neo_mpc_last_error() says why)
 
 int neo_mpc_comm_init_all(int ndev, const int* devices, void** comms_out) {
   if (ndev <= 0 || !comms_out) return neo_mpc_set_error(NEO_MPC_ERR_INVALID_ARGUMENT, "bad communicator arguments");

@@ -193,7 +193,7 @@ __device__ void postprocess(const SolveArgs& a, const Ctx& c, double* L, uint32_
     out2 = fmax(fmin(x2, S[S_LAST + 2] + p.acc[2] * ci), S[S_LAST + 2] - p.acc[2] * ci);
   }
   // warm start (py:397-400, 198-202)
-  double* warm = a.warm + (size_t)b * nv;
+  double* warm = a.warm_out + (size_t)b * nv;
   for (int k = lane; k < nv; k += kLanes) {
     double v;
     if (success) v = (k < nv - 3) ? x[k + 3] : x[k - (nv - 3)];
@@ -214,7 +214,7 @@ __device__ void postprocess(const SolveArgs& a, const Ctx& c, double* L, uint32_
     if (a.velocities) { double* v = a.velocities + 3 * (size_t)b; v[0] = out0; v[1] = out1; v[2] = out2; }
   }
   WAVE_SYNC();
-  if (lane < 16) reinterpret_cast<double*>(a.states + b)[lane] = S[lane];
+  if (lane < 16) reinterpret_cast<double*>(a.states_out + b)[lane] = S[lane];
 }
 
 // py:358-361; returns true when the reset is taken.  x0 -> L[u]

@@ -96,6 +96,14 @@ class BatchSolver:
                 self._handle, C.c_void_p(cells.data_ptr()), m, sx, sy, float(resolution),
                 C.c_void_p(origins.data_ptr()), C.c_void_p(stream)))
 
+    HOST_PATHS = {"auto": 0, "staged": 1, "zerocopy": 2, "zerocopy_out": 3}
+
+    def set_host_path(self, mode):
+        """How `solve` moves a batch whose arrays are all page-locked: "auto" (= "zerocopy": K1 works on the
+        caller's arrays in place over PCIe), "staged" (DMA copies in and out), "zerocopy_out" (DMA in, results
+        written in place)."""
+        _lib.check(self._lib.neo_mpc_set_host_path(self._handle, self.HOST_PATHS[mode]))
+
     def kernel_info(self):
         a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
         _lib.check(self._lib.neo_mpc_kernel_info(self._handle, C.byref(a), C.byref(b), C.byref(c)))

@@ -40,6 +40,11 @@ def _map_args(cmap):
                    C.c_double(res), C.c_double(ox), C.c_double(oy)]
 
 
+def set_threads(n):
+    """OpenMP threads of solve_batch (bench.py: the CPUs this process may use, not the host's thread count)."""
+    load().orc_set_threads(C.c_int(int(n)))
+
+
 def yaw(x, y, z, w):
     return load().orc_yaw(x, y, z, w)
 

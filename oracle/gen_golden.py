@@ -12,7 +12,9 @@ G3 cold-start SLSQP solves (ftol 1e-3 and 1e-12), G4 stateful optimizer() episod
 G5 warm-start shift, G6 SciPy forward-difference gradients, G7 publishLocalPlan paths,
 G8 G3's solves at parameter sets away from the README's (box cutting the disc; fast-turning robot with a
 heavy costmap weight; the README's parameters at control_steps 16), G4b episodes at another parameter set
-(acceleration limits, low-pass gain, footprint weight, box cutting the disc).
+(acceleration limits, low-pass gain, footprint weight, box cutting the disc), G8mid the README's parameters with
+w_costmap / w_trans from 0.10 to 0.30 on costmaps, G9 the node's own declared defaults (opt_tolerance 1e-5) as cold
+solves and episodes, G3n32 64 zero-map problems at control_steps 32 with SLSQP's maxiter raised until status 0.
 
     python oracle/gen_golden.py g8 g4b     # regenerates single sets
 """
@@ -179,14 +181,16 @@ def gen_g2(mod):
     print("G2: 256 + 64 cases")
 
 
-def _g3_group(mod, n_steps, count, seed, overrides=None):
+def _g3_group(mod, n_steps, count, seed, overrides=None, maps="alternate"):
     """`count` cold-start solves at control_steps = n_steps through the reference's own
-    objective / bounds / constraints objects (py:125-134, 363-364): SLSQP as shipped (ftol 1e-3,
-    maxiter 100) and run to the end (ftol 1e-12, maxiter 500); odd cases on the costmap, even ones
-    on an all-free map (unique minimiser).  `overrides`: parameters other than the README's."""
+    objective / bounds / constraints objects (py:125-134, 363-364): SLSQP as shipped (ftol = the set's
+    `opt_tolerance`, py:72, 364 -- 1e-3 for the README's parameters --, maxiter 100) and run to the end
+    (ftol 1e-12, maxiter 500); odd cases on the costmap, even ones on an all-free map (unique minimiser),
+    or every case on the costmap (`maps="all"`).  `overrides`: parameters other than the README's."""
     from scipy.optimize import minimize
     params = dict(README_PARAMS, control_steps=n_steps)
     params.update(overrides or {})
+    params["control_steps"] = n_steps
     cmap = synthetic.make_costmap(200, seed=3)
     zero = (np.zeros((200, 200), np.uint8),) + cmap[1:]
     probs = synthetic.make_problems(count, 200, seed=seed)
@@ -196,11 +200,11 @@ def _g3_group(mod, n_steps, count, seed, overrides=None):
     has_map = np.zeros(count, dtype=np.int32)
     t0 = time.time()
     for j in range(count):
-        ref = refs[j % 2]
-        has_map[j] = j % 2
+        has_map[j] = 1 if maps == "all" else j % 2
+        ref = refs[has_map[j]]
         ref.load(probs[j])
         s = ref.srv
-        for tag, ftol, maxiter in (("loose", 1e-3, 100), ("tight", 1e-12, 500)):
+        for tag, ftol, maxiter in (("loose", float(params["opt_tolerance"]), 100), ("tight", 1e-12, 500)):
             r = minimize(s.objective, np.zeros(3 * n_steps), method="SLSQP", bounds=s.bnds,
                          constraints=s.cons, options={"ftol": ftol, "disp": False,
                                                       "maxiter": maxiter})
@@ -248,6 +252,78 @@ def gen_g8(mod):
     # stage-wise direction sets in
     out.update({"readme_n16_%s" % k: v for k, v in _g3_group(mod, 16, 24, 816).items()})
     np.savez_compressed(os.path.join(OUT, "g8_solves_params.npz"), **out)
+
+
+#: G8 "mid": the README's parameters with w_costmap / w_trans between the two ratios the other fixtures sit at (0.061 the
+#: README's, 0.366 "turn"), across the threshold (1/4) at which AUTO hands control_steps 3 to the stage-wise direction
+G8_MID_RATIOS = (0.10, 0.15, 0.20, 0.25, 0.30)
+
+
+def gen_g8mid(mod):
+    """Cold-start solves ON THE COSTMAP (every case) at control_steps 3 for the README's parameters with w_costmap =
+    ratio * w_trans, ratio in G8_MID_RATIOS (keys r<percent>_<name>) -- costmap term py:256-260."""
+    out = dict(versions=np.array(repr(versions())), param_keys=np.array(PARAM_KEYS),
+               ratios=np.array(G8_MID_RATIOS))
+    for ratio in G8_MID_RATIOS:
+        grp = _g3_group(mod, 3, 32, 850 + int(round(100 * ratio)),
+                        dict(w_costmap=ratio * README_PARAMS["w_trans"]), maps="all")
+        out.update({"r%02d_%s" % (int(round(100 * ratio)), k): v for k, v in grp.items()})
+    np.savez_compressed(os.path.join(OUT, "g8_mid.npz"), **out)
+
+
+def gen_g9(mod):
+    """G9 "pydefaults": the parameter values the node itself declares (py:49-75: opt_tolerance 1e-5, every weight 0.5,
+    w_footprint 2000, limits 0.5, horizon 0.5) -- cold solves at control_steps 3 and 8 (SLSQP as shipped = ftol 1e-5,
+    and ftol 1e-12) and one episode set through optimizer()."""
+    out = dict(versions=np.array(repr(versions())), param_keys=np.array(PARAM_KEYS))
+    for n_steps, count in ((3, 96), (8, 48)):
+        grp = _g3_group(mod, n_steps, count, 900 + n_steps, PY_DEFAULT_PARAMS)
+        out.update({"n%d_%s" % (n_steps, k): v for k, v in grp.items()})
+    np.savez_compressed(os.path.join(OUT, "g9_solves_pydefaults.npz"), **out)
+    gen_g4(mod, n_steps=3, n_ep=6, n_calls=40, fname="g9_episodes_pydefaults.npz", overrides=PY_DEFAULT_PARAMS)
+
+
+def _n32_case(args):
+    """worker of gen_g3n32: one zero-map control_steps-32 problem, SLSQP as shipped and run to the end with the
+    iteration cap raised until it reports status 0 (500 -> 2000 -> 8000)."""
+    seed, j, count = args
+    from scipy.optimize import minimize
+    mod = ros_stubs.load_reference()
+    params = dict(README_PARAMS, control_steps=32)
+    zero = (np.zeros((200, 200), np.uint8), 0.05, -5.0, -5.0)
+    ref = Ref(mod, params, zero)
+    probs = synthetic.make_problems(count, 200, seed=seed)
+    ref.load(probs[j])
+    s = ref.srv
+    r = minimize(s.objective, np.zeros(96), method="SLSQP", bounds=s.bnds, constraints=s.cons,
+                 options={"ftol": 1e-3, "disp": False, "maxiter": 100})
+    loose = (r.x, r.fun, r.nit, r.nfev, r.status)
+    for maxiter in (500, 2000, 8000):
+        r = minimize(s.objective, np.zeros(96), method="SLSQP", bounds=s.bnds, constraints=s.cons,
+                     options={"ftol": 1e-12, "disp": False, "maxiter": maxiter})
+        if r.status == 0:
+            break
+    return j, loose, (r.x, r.fun, r.nit, r.nfev, r.status)
+
+
+def gen_g3n32(mod, count=64, seed=3320):
+    """G3 at control_steps 32 (BASELINE config 5) on the all-free map only: `count` unique-minimiser problems with
+    SLSQP's maxiter raised until ftol 1e-12 reports status 0 (py:363-364 with other options) -- P2 at 32 control
+    steps rests on these.  One process per CPU (a solve takes minutes)."""
+    import multiprocessing as mp
+    t0 = time.time()
+    with mp.Pool(max(1, (os.cpu_count() or 2) - 1)) as pool:
+        rows = sorted(pool.imap_unordered(_n32_case, [(seed, j, count) for j in range(count)]), key=lambda r: r[0])
+    probs = synthetic.make_problems(count, 200, seed=seed)
+    params = dict(README_PARAMS, control_steps=32)
+    out = dict(versions=np.array(repr(versions())), param_keys=np.array(PARAM_KEYS), params=params_vec(params),
+               map_meta=np.array((0.05, -5.0, -5.0)), problems=probs.view(np.uint8).reshape(count, -1))
+    for tag, col in (("loose", 1), ("tight", 2)):
+        for i, name in enumerate(("x", "f", "nit", "nfev", "status")):
+            out["%s_%s" % (name, tag)] = np.array([r[col][i] for r in rows])
+    np.savez_compressed(os.path.join(OUT, "g3_solves_n32_zero.npz"), **out)
+    print("G3 n32 zero-map: %d solves in %.0fs, status 0 on %d" % (count, time.time() - t0,
+                                                                   int((out["status_tight"] == 0).sum())), flush=True)
 
 
 def path_array(path):

@@ -1309,6 +1309,15 @@ void orc_postprocess_batch(const neo_mpc_params* p, const uint8_t* cells, int32_
   }
 }
 
+/* number of OpenMP threads of orc_solve_batch (bench.py's cpu_mirror: the CPUs the process may actually use -- the
+ * runtime's default is every hardware thread of the host, 256 on a box whose container owns 16) */
+#ifdef _OPENMP
+#include <omp.h>
+void orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+#else
+void orc_set_threads(int n) { (void)n; }
+#endif
+
 /* full path with the build's solver: reset -> pg_solve -> postprocess */
 void orc_solve_batch(const neo_mpc_params* p, const uint8_t* cells, int32_t sx, int32_t sy,
                      double res, double ox, double oy, const neo_mpc_batch* b) {

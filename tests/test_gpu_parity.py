@@ -450,12 +450,7 @@ def test_server_mirror_episode_matches_oracle_wrapper():
     node2.close()
 
 
-def test_plugin_seam_example_runs_a_control_loop(tmp_path):
-    """examples/plugin_seam.cpp --run: the C++ a maintainer pastes into NeoMpcPlanner.cpp (cpp:240-252
-    replacement), compiled with g++ against include/neo_mpc.h, drives one robot for 300 ticks through
-    the C-ABI alone (no Python, no torch): finite commands inside the speed disc, the robot follows
-    the plan past a wall to its end, and the per-tick latency is printed."""
-    import json
+def _build_seam(tmp_path):
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -465,12 +460,72 @@ def test_plugin_seam_example_runs_a_control_loop(tmp_path):
                            "-L", os.path.join(root, "neo_mpc_planner2_amd"), "-lneo_mpc",
                            "-Wl,-rpath," + os.path.join(root, "neo_mpc_planner2_amd"),
                            "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    return exe
+
+
+def test_plugin_seam_example_runs_a_control_loop(tmp_path):
+    """examples/plugin_seam.cpp --run: the C++ a maintainer pastes into NeoMpcPlanner.cpp (cpp:240-252
+    replacement), compiled with g++ against include/neo_mpc.h, drives one robot for 300 ticks through
+    the C-ABI alone (no Python, no torch): finite commands inside the speed disc, the robot follows
+    the plan past a wall to its end, and the per-tick latency is printed."""
+    import json
+    import subprocess
+    exe = _build_seam(tmp_path)
     out = subprocess.run([str(exe), "--run"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, (out.returncode, out.stdout[-500:], out.stderr[-500:])
     rec = json.loads(out.stdout.strip().splitlines()[-1])
     assert rec["final_x"] > 3.0 and abs(rec["final_y"]) < 0.2 and rec["max_speed"] <= 0.7 + 1e-9
     assert rec["tick_us_median"] < 5000.0   # (the reference's tick is 11.6 ms + the DDS hop)
     print(rec)
+
+
+def test_plugin_seam_ticks_replayed_through_the_oracle(tmp_path):
+    """f-3: the C++ seam (cpp:240-252 replacement) against the oracle, TICK BY TICK.  `--dump` records what every one
+    of 520 control ticks sent (the Optimizer request incl. delta_t), held (state, warm start) and got; the local
+    costmap handed over through a getCharMap()-shaped buffer CHANGES while the robot drives (cpp:290-334's
+    costmap_: a lethal block appears across the plan at tick 60, gone at tick 260), so the robot stops in front of
+    it, sits out the 3 s latch twice and moves on.  Every tick is replayed through the C oracle from the seam's own
+    pre-tick state with the costmap version of that tick: |d command| <= 2e-5, equal latch flags / waiting time /
+    status, warm start and last_control within 2e-5 -- and the chained oracle (its own state evolving over the
+    same requests) agrees on every latch flag as well."""
+    import json
+    import subprocess
+    from oracle import c_oracle
+    exe = _build_seam(tmp_path)
+    dump = tmp_path / "seam.bin"
+    out = subprocess.run([str(exe), "--run", "--ticks", "520", "--fake-clock", "--obstacle", "--dump", str(dump)],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.returncode, out.stdout[-500:], out.stderr[-500:])
+    summary = json.loads(out.stdout.strip().splitlines()[-1])
+    params, geom, maps, ticks = util.load_seam_dump(str(dump))
+    assert len(ticks) == 520 and params["control_steps"] == 3 and params["opt_tolerance"] == 1e-3
+    assert set(np.unique(ticks["map"])) == {0, 1} and (maps[0] != maps[1]).any()
+    stopped = (ticks["command"]["flags"] & abi.FLAG_STOPPED) != 0
+    assert summary["stopped_ticks"] == stopped.sum() and stopped.sum() >= 150      # two 3 s waits in front of the block
+    assert ticks["state_after"]["collision"].max() == 1 and summary["final_x"] > 3.0
+    st_chain, warm_chain = abi.new_states(1, 3)
+    worst = 0.0
+    for k, t in enumerate(ticks):
+        cmap = (maps[t["map"]],) + geom
+        rows = t["problem"].reshape(1).copy()
+        st, warm = t["state_before"].reshape(1).copy(), t["warm_before"].reshape(1, -1).copy()
+        cc, xc, _ = c_oracle.solve_batch(params, cmap, rows, st, warm)
+        dv = np.abs(cc["vel"][0] - t["command"]["vel"]).max()
+        worst = max(worst, dv)
+        assert dv <= 2e-5, (k, dv)
+        assert cc["flags"][0] == t["command"]["flags"] and cc["status"][0] == t["command"]["status"], k
+        for f in ("collision", "collision_footprint", "has_old_goal"):
+            assert st[f][0] == t["state_after"][f], (k, f)
+        assert abs(st["waiting_time"][0] - t["state_after"]["waiting_time"]) <= 1e-12, k
+        assert np.abs(st["last_control"][0] - t["state_after"]["last_control"]).max() <= 2e-5, k
+        assert np.abs(warm[0] - t["warm_after"]).max() <= 2e-5, k
+        # the seam threads its state from tick to tick itself
+        if k + 1 < len(ticks):
+            assert ticks[k + 1]["state_before"].tobytes() == t["state_after"].tobytes()
+            assert (ticks[k + 1]["warm_before"] == t["warm_after"]).all()
+        c2, _, _ = c_oracle.solve_batch(params, cmap, rows, st_chain, warm_chain)
+        assert c2["flags"][0] == t["command"]["flags"] and st_chain["collision"][0] == t["state_after"]["collision"], k
+    print("seam vs oracle over %d ticks: max |d command| %.2e, %d stopped ticks" % (len(ticks), worst, stopped.sum()))
 
 
 def test_bench_emits_the_contract_line():

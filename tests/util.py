@@ -36,4 +36,30 @@ def oracle_problem(row, footprint=None):
 def oracle_costmap(cells, meta):
     return orc.Costmap(cells, meta[0], meta[1], meta[2])
 
+
+
+def load_seam_dump(path):
+    """`examples/plugin_seam.cpp --run --dump FILE`: header (tick count, control_steps, map size, parameters, map
+    geometry, the costmap versions) and one record per control tick -- what the C++ seam sent, held and got."""
+    import ctypes as C
+    from neo_mpc_planner2_amd import abi
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"NEOSEAM1", raw[:8]
+    ticks, n_steps, size, n_maps = np.frombuffer(raw, dtype="<i4", count=4, offset=8)
+    off = 24
+    ps = abi.NeoMpcParams.from_buffer_copy(raw[off:off + C.sizeof(abi.NeoMpcParams)])
+    off += C.sizeof(abi.NeoMpcParams)
+    params = {name: getattr(ps, name) for name, _ in abi.NeoMpcParams._fields_ if name != "reserved_i"}
+    geom = np.frombuffer(raw, dtype="<f8", count=3, offset=off)
+    off += 24
+    maps = np.frombuffer(raw, dtype=np.uint8, count=n_maps * size * size, offset=off).reshape(n_maps, size, size)
+    off += n_maps * size * size
+    nv = 3 * int(n_steps)
+    rec = np.dtype([("map", "<i4"), ("tick", "<i4"), ("problem", abi.PROBLEM_DTYPE), ("state_before", abi.STATE_DTYPE),
+                    ("warm_before", "<f8", (nv,)), ("command", abi.COMMAND_DTYPE), ("state_after", abi.STATE_DTYPE),
+                    ("warm_after", "<f8", (nv,))])
+    assert len(raw) - off == int(ticks) * rec.itemsize, (len(raw) - off, int(ticks), rec.itemsize)
+    return params, tuple(geom), maps, np.frombuffer(raw, dtype=rec, count=int(ticks), offset=off)
+
+
 orc = orc  # re-export: tests use util.orc.make_params

@@ -18,11 +18,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
-from neo_mpc_planner2_amd import abi, synthetic  # noqa: E402
+from neo_mpc_planner2_amd import abi, fleet, synthetic  # noqa: E402
 from neo_mpc_planner2_amd.mpc_optimization_server import README_PARAMS  # noqa: E402
 from neo_mpc_planner2_amd.solver import BatchSolver, DeviceBatch  # noqa: E402
 
-TICKS, HZ = 40, 30.0
+TICKS, HZ = int(os.environ.get("NEO_MPC_TICKS", "60")), 30.0
 DUMP_TICK = int(os.environ.get("NEO_MPC_DUMP_TICK", "-1"))
 POOL = "--pool" in sys.argv   # every robot gets its own 200x200 rolling window (neo_mpc_set_costmap_pool)
 cfg, cmap, probs, st, warm = synthetic.make_workload("C2", seed=0)
@@ -43,20 +43,9 @@ with BatchSolver(params) as s:
     else:
         s.set_costmap(torch.from_numpy(cmap[0]).to(dev), *cmap[1:])
     b = DeviceBatch(probs, st, warm, dev, want_solution=False)
-    P = b.problems.view(torch.float64).reshape(b.count, -1)          # the 32 doubles of each request
-    q = P[:, 2:6]
-    yaw = torch.atan2(2 * (q[:, 3] * q[:, 2] + q[:, 0] * q[:, 1]), 1 - 2 * (q[:, 1] ** 2 + q[:, 2] ** 2)).clone()
-    pos = P[:, 0:2].clone()
-    c, sn = torch.cos(yaw), torch.sin(yaw)
-    carrot_off = torch.stack([c * P[:, 6] - sn * P[:, 7], sn * P[:, 6] + c * P[:, 7]], 1)   # world frame
-    cq = P[:, 8:12]
-    carrot_yaw_w = yaw + torch.atan2(2 * (cq[:, 3] * cq[:, 2] + cq[:, 0] * cq[:, 1]), 1 - 2 * (cq[:, 1] ** 2 + cq[:, 2] ** 2))
-    P[:, 22] = 1.0 / HZ
-    P[:, 23] = 1.0 / HZ
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(TICKS)]
-    iters, stopped, itmax = [], [], []
     ing = []
-    for t in range(TICKS):
+
+    def before_tick(t, pos):
         if POOL:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -67,29 +56,13 @@ with BatchSolver(params) as s:
         if DUMP_TICK == t:   # study: the inputs of this tick, for the CPU mirror (tools: trace the long searches)
             np.savez(os.path.join(ROOT, "gpurun_out", "fleet_tick%d.npz" % t), problems=b.problems.cpu().numpy(),
                      states=b.states.cpu().numpy(), warm=b.warm.cpu().numpy())
-        evs[t][0].record()
-        s.solve_device(b.problems, b.states, b.warm, b.commands, velocities=b.vel)
-        evs[t][1].record()
-        cmd = b.vel
-        yaw = yaw + cmd[:, 2] / HZ
-        c, sn = torch.cos(yaw), torch.sin(yaw)
-        pos = pos + torch.stack([c * cmd[:, 0] - sn * cmd[:, 1], sn * cmd[:, 0] + c * cmd[:, 1]], 1) / HZ
-        P[:, 0:2] = pos
-        P[:, 2] = 0.0; P[:, 3] = 0.0; P[:, 4] = torch.sin(0.5 * yaw); P[:, 5] = torch.cos(0.5 * yaw)
-        d = carrot_off
-        P[:, 6] = c * d[:, 0] + sn * d[:, 1]
-        P[:, 7] = -sn * d[:, 0] + c * d[:, 1]
-        rel = carrot_yaw_w - yaw
-        P[:, 8] = 0.0; P[:, 9] = 0.0; P[:, 10] = torch.sin(0.5 * rel); P[:, 11] = torch.cos(0.5 * rel)
-        P[:, 19:22] = cmd
-        torch.cuda.synchronize()
-        cm = b.commands.cpu().numpy().view(abi.COMMAND_DTYPE).reshape(-1)
-        iters.append(float(cm["iterations"].mean()))
-        itmax.append(int(cm["iterations"].max()))
+
+    def after_tick(t, cm):
         if DUMP_TICK == t:
             np.save(os.path.join(ROOT, "gpurun_out", "fleet_tick%d_iterations.npy" % t), cm["iterations"])
-        stopped.append(float(((cm["flags"] & 2) != 0).mean()))
-    ms = [a.elapsed_time(e) for a, e in evs]
+
+    loop = fleet.closed_loop(s, b, TICKS, HZ, before_tick, after_tick)
+    ms, iters, itmax, stopped = loop["kernel_ms"], loop["mean_iterations"], loop["max_iterations"], loop["stopped_fraction"]
 extra = {}
 if POOL:
     extra = {"pool": "4096 rolling windows of 200x200 cells (160 MB raw), re-centred and re-ingested every tick",
@@ -104,4 +77,5 @@ print(json.dumps({
     "warm_solves_per_s": 4096 / (1e-3 * float(np.median(ms[5:]))),
     "stopped_fraction_last_tick": stopped[-1],
     "per_tick_kernel_ms": [round(x, 4) for x in ms[:12]], "per_tick_mean_iterations": [round(x, 2) for x in iters[:12]],
-    "per_tick_max_iterations": itmax[:12], "warm_ticks_max_iterations_median": float(np.median(itmax[5:]))}))
+    "per_tick_max_iterations": itmax[:12], "warm_ticks_max_iterations_median": float(np.median(itmax[5:])),
+    "warm_ticks_max_iterations_max": int(np.max(itmax[5:])), "ticks": TICKS}))
