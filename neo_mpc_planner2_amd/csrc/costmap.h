@@ -8,6 +8,7 @@
 #include "neo_mpc_device.h"
 #include "wave_ops.h"
 #include "solver_context.h"
+#include "fast_math.h"
 
 namespace neo_mpc {
 namespace {
@@ -69,8 +70,17 @@ __device__ __forceinline__ double step_term(const SolveArgs& a, const Ctx& c, co
 // a slide advance a centimetre per iteration, 10 % five times that).
 // Returns the raw cost of the stage's own cell.
 constexpr double kSticky = 100.0, kWall = 1e4, kStickyDist = 0.02, kWallDist = 0.1;
+// Hop candidates.  The costmap term is piecewise constant: a stage within `hop_range` cells of a cell edge behind which
+// the term is LOWER (by more than hop_min_drop) can gain that step for a displacement of millimetres, but no descent
+// direction says so -- the term has no gradient -- and at a heavy costmap weight one such step is worth more than the
+// whole 1e-3 budget (found with the G9 fixtures: the node's own defaults, every weight 0.5; SLSQP's line search lands
+// across such edges by chance).  hop_x / hop_y: the change of THIS stage's block (vx, vy) that puts the stage
+// kHopMargin cells inside the cheaper neighbour (every later stage shifts with it); lanes 1-4 of the search try the
+// current point with one such block changed (feasible_set.h).
+constexpr double kHopMargin = 0.02;
 __device__ __forceinline__ int edge_stickiness(const SolveArgs& a, const Ctx& c, const double* L, double x, double y,
-                                               double& wxx, double& wxy, double& wyy, double& lx, double& ly) {
+                                               double cs, double sn, double& wxx, double& wxy, double& wyy, double& lx,
+                                               double& ly, bool& hop, float& hop_x, float& hop_y) {
   const double X = c.X0 + (c.c0 * x - c.s0 * y), Y = c.Y0 + (c.s0 * x + c.c0 * y);
   const int mx = cell_of(X, a.map.origin_x, a.map.resolution, a.map.inv_resolution);
   const int my = cell_of(Y, a.map.origin_y, a.map.resolution, a.map.inv_resolution);
@@ -79,26 +89,38 @@ __device__ __forceinline__ int edge_stickiness(const SolveArgs& a, const Ctx& c,
   const int raw_here = cell_raw(a, c, L, mx, my);
   const double here = L[a.lds.term + raw_here];
   wxx = 0.0; wxy = 0.0; wyy = 0.0; lx = 0.0; ly = 0.0;
+  hop = false; hop_x = 0.0f; hop_y = 0.0f;
   // (saturated cell indices -- positions far outside every map -- wrap in mx +- 1; such cells read lethal
   // on both sides, so no edge is sticky there)
   const bool far = mx <= -2147483647 || mx >= 2147483646 || my <= -2147483647 || my >= 2147483646;
   if (far) return raw_here;
-  // at most one edge per axis can be within the (wider) wall zone: the low side (push back along +axis) or the high side
-  const bool xlo = fx < kWallDist, xhi = 1.0 - fx < kWallDist, ylo = fy < kWallDist, yhi = 1.0 - fy < kWallDist;
+  // at most one edge per axis can be within the (wider) wall / hop zone: the low side (push back along +axis) or the high side
+  const double hop_range = L[a.lds.tol + T_HOP_RANGE];
+  const double zone = fmax(kWallDist, hop_range);
+  const bool xlo = fx < zone, xhi = 1.0 - fx < zone, ylo = fy < zone, yhi = 1.0 - fy < zone;
   double rx = 0.0, ry = 0.0, pbx = 0.0, pby = 0.0;
+  double drop = L[a.lds.tol + T_HOP_DROP], hwx = 0.0, hwy = 0.0;   // best drop so far, hop in world axes (metres)
   if (xlo || xhi) {
     const int raw_n = cell_raw(a, c, L, xlo ? mx - 1 : mx + 1, my);
-    const double dist = xlo ? fx : 1.0 - fx;
+    const double dist = xlo ? fx : 1.0 - fx, there = L[a.lds.term + raw_n];
     const bool wall = raw_n == 254 && raw_here != 254;
-    if (wall) { rx = kWall * 2.0 * a.p.wt_n; pbx = (xlo ? kWallDist - dist : dist - kWallDist) * a.map.resolution; }
-    else if (dist < kStickyDist && L[a.lds.term + raw_n] > here) rx = kSticky * 2.0 * a.p.wt_n;
+    if (wall) { if (dist < kWallDist) { rx = kWall * 2.0 * a.p.wt_n; pbx = (xlo ? kWallDist - dist : dist - kWallDist) * a.map.resolution; } }
+    else if (dist < kStickyDist && there > here) rx = kSticky * 2.0 * a.p.wt_n;
+    if (dist < hop_range && here - there > drop) {
+      drop = here - there; hop = true;
+      hwx = (xlo ? -1.0 : 1.0) * (dist + kHopMargin) * a.map.resolution; hwy = 0.0;
+    }
   }
   if (ylo || yhi) {
     const int raw_n = cell_raw(a, c, L, mx, ylo ? my - 1 : my + 1);
-    const double dist = ylo ? fy : 1.0 - fy;
+    const double dist = ylo ? fy : 1.0 - fy, there = L[a.lds.term + raw_n];
     const bool wall = raw_n == 254 && raw_here != 254;
-    if (wall) { ry = kWall * 2.0 * a.p.wt_n; pby = (ylo ? kWallDist - dist : dist - kWallDist) * a.map.resolution; }
-    else if (dist < kStickyDist && L[a.lds.term + raw_n] > here) ry = kSticky * 2.0 * a.p.wt_n;
+    if (wall) { if (dist < kWallDist) { ry = kWall * 2.0 * a.p.wt_n; pby = (ylo ? kWallDist - dist : dist - kWallDist) * a.map.resolution; } }
+    else if (dist < kStickyDist && there > here) ry = kSticky * 2.0 * a.p.wt_n;
+    if (dist < hop_range && here - there > drop) {
+      hop = true;
+      hwx = 0.0; hwy = (ylo ? -1.0 : 1.0) * (dist + kHopMargin) * a.map.resolution;
+    }
   }
   // world x axis in the rollout frame: (c0, -s0); world y axis: (s0, c0)
   wxx = rx * c.c0 * c.c0 + ry * c.s0 * c.s0;
@@ -106,6 +128,10 @@ __device__ __forceinline__ int edge_stickiness(const SolveArgs& a, const Ctx& c,
   wyy = rx * c.s0 * c.s0 + ry * c.c0 * c.c0;
   lx = -(rx * pbx * c.c0 + ry * pby * c.s0);
   ly = -(rx * pbx * -c.s0 + ry * pby * c.c0);
+  if (hop) {   // world -> rollout frame -> this block's frame, as a velocity change
+    const double hrx = c.c0 * hwx + c.s0 * hwy, hry = -c.s0 * hwx + c.c0 * hwy, idt = rcp_fast(a.p.dt);
+    hop_x = (float)((cs * hrx + sn * hry) * idt); hop_y = (float)((-sn * hrx + cs * hry) * idt);
+  }
   return raw_here;
 }
 

@@ -73,11 +73,18 @@ __device__ __forceinline__ double lane_scale(int lane) {
 //    blocks crawling at long horizons;
 //  * blocks the Riccati sweep sends onto the kink (AMODE slot 3) stop there: step min(t, 1), and
 //    exactly v_cur at t >= 1.
+//  * hop candidates (lanes 1..count of the hop table, costmap.h): the current point with block `hop_stage` changed by
+//    (hop_x, hop_y); hop_stage < 0: an ordinary candidate.
 template <bool kTame = false, bool kRiccati = false>
 __device__ __forceinline__ void candidate_block(const SolveArgs& a, const Ctx& c, const double* L, int lane,
                                                 double step, double pstep, int i, double& b0, double& b1,
-                                                double& b2) {
+                                                double& b2, int hop_stage = -1, float hop_x = 0.0f, float hop_y = 0.0f) {
   const double* u = L + a.lds.u + 3 * i;
+  if (kRiccati && hop_stage >= 0) {
+    b0 = u[0]; b1 = u[1]; b2 = u[2];
+    if (i == hop_stage) { b0 += (double)hop_x; b1 += (double)hop_y; project_block<kTame>(a.p, b0, b1, b2); }
+    return;
+  }
   const int* am = reinterpret_cast<const int*>(L + a.lds.mode) + 4 * i;
   const bool near = am[2] != 0;
   if (lane < 32 || near) {  // proximal gradient: forward step on the smooth part, prox of the control norm

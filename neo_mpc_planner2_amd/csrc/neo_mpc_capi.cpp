@@ -158,6 +158,8 @@ void derive(neo_mpc_handle* h) {
   d.xtol = p.step_tolerance > 0.0 ? p.step_tolerance : 1e-3 * p.opt_tolerance;
   d.kink_radius = p.kink_radius > 0.0 ? p.kink_radius : 3e-3;
   d.stall_step = p.stall_step > 0.0 ? p.stall_step : 0.3 * p.opt_tolerance;
+  d.hop_min_drop = 0.1 * p.opt_tolerance;
+  d.hop_range = h->has_map ? fmin(0.25, 0.05 * d.dt / h->map.resolution) : 0.25;
   d.max_it = p.max_iterations > 0 ? p.max_iterations : 100;
   d.mem = p.lbfgs_memory > 0 ? p.lbfgs_memory : 4;
   d.compat = p.compat_flags;

@@ -33,6 +33,9 @@ struct DevParams {
   double wtol;               // three iterations in a row gaining less than this (relative) end the search; 0: off
   double wtol_late;          // ... the same from iteration kLateIteration on (the control_steps-3 window)
   double kink_radius;        // |u_i - v_cur| below which a block is handled by the prox step only
+  double hop_min_drop;       // stage-wise direction: a cheaper neighbour cell is worth a hop candidate when its costmap
+                             // term is lower by more than this (0.1 * opt_tolerance)
+  double hop_range;          // ... and its edge is closer than this (cells): min(0.25, 0.05 m/s * dt / resolution)
   int32_t n;                 // control_steps
   int32_t max_it;
   int32_t mem;               // L-BFGS pairs
@@ -80,7 +83,8 @@ constexpr LdsLayout make_lds_layout(int n, int mem, bool riccati) {
   int off = 0;
   l.prob = off; off += 32;
   l.state = off; off += 16;
-  l.tol = off; off += 12;   // stop tolerances + two cold per-instance constants (read once per iteration; kept out of the scalar registers)
+  l.tol = off; off += 20;   // stop tolerances + two cold per-instance constants (read once per iteration; kept out of the scalar
+                            // registers), then the hop candidates of the current iteration (solver_context.h)
   l.term = off; off += 256;
   l.u = off; off += nv;
   l.gs = off; off += nv;

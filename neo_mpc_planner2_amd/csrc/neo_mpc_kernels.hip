@@ -173,12 +173,14 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   // spilled from) scalar registers all through the loop.
   // So do two per-instance constants the loop has no use for: the request's true yaw (K2 only) and
   // the part of the objective that does not depend on u -- inside the loop f excludes it.
-  enum { T_XTOL, T_EARLY, T_FINAL, T_FTOL, T_STALL, T_WTOL, T_KINK, T_KONST, T_TRUE_YAW, T_MU, T_WTOL_LATE };
+  // (layout: solver_context.h)
   if (lane == 0) {
     double* t = L + a.lds.tol;
     t[T_XTOL] = p.xtol; t[T_EARLY] = p.early_tol; t[T_FINAL] = p.final_tol; t[T_FTOL] = p.ftol;
     t[T_STALL] = p.stall_step; t[T_WTOL] = p.wtol; t[T_WTOL_LATE] = p.wtol_late; t[T_KINK] = p.kink_radius;
     t[T_KONST] = c.konst; t[T_TRUE_YAW] = c.true_yaw;
+    t[T_HOP_DROP] = p.hop_min_drop; t[T_HOP_RANGE] = p.hop_range;
+    reinterpret_cast<int*>(t + T_HOP_STAGE)[kHopLanes] = 0;   // no hop candidates yet
   }
   c.konst = 0.0; c.true_yaw = 0.0;
   double* u = L + a.lds.u;
@@ -260,6 +262,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     constexpr int kVars = 3 * kNwSteps;  // compile-time bound of the Newton system (= its size when kSteps > 0)
     const int nvr = kSteps ? kVars : nv;  // its size
     bool free_path = false;   // Riccati: every stage of the rollout at u sits in a free cell (raw cost 0)
+    int nhops = 0;            // Riccati: hop candidates of this iteration (wave-uniform; the table is in the tolerance block)
     float hc[kVars];     // Newton: column `lane` of the Hessian, then row `lane` (float32, see below)
     float newton_sol = 0.0f;  // Newton: entry `lane` of the direction
     double hcol[kSteps ? kVars : 1];  // control_steps specialisation: gradient of this lane's perturbed copy
@@ -344,6 +347,8 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       const double pt = wave_scan(tt);
       const double ST = lane_value(pt, 63) - pt + tt;
       int raw_here = 0;
+      bool has_hop = false;
+      float hop_x = 0.0f, hop_y = 0.0f;
       if (on) {
         gs[3 * lane] = p.dt * (cs * SX + sn * SY);
         gs[3 * lane + 1] = p.dt * (-sn * SX + cs * SY);
@@ -354,12 +359,25 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
           float* rs = RS + kRicStage * lane;
           rs[RS_CS] = (float)cs; rs[RS_SN] = (float)sn; rs[RS_PX] = (float)ddx; rs[RS_PY] = (float)ddy;
           double wxx, wxy, wyy, wlx, wly;
-          raw_here = edge_stickiness(a, c, L, x, y, wxx, wxy, wyy, wlx, wly);
+          raw_here = edge_stickiness(a, c, L, x, y, cs, sn, wxx, wxy, wyy, wlx, wly, has_hop, hop_x, hop_y);
           rs[RS_WXX] = (float)wxx; rs[RS_WXY] = (float)wxy; rs[RS_WYY] = (float)wyy;
           rs[RS_WLX] = (float)wlx; rs[RS_WLY] = (float)wly;
         }
       }
-      if (kRiccati) free_path = __ballot(raw_here != 0) == 0ull;
+      if (kRiccati) {
+        free_path = __ballot(raw_here != 0) == 0ull;
+        // hop table of this iteration: the first kHopLanes stages with a cheaper cell a hop away (lanes 1.. of the search)
+        const unsigned long long hmask = __ballot(has_hop);
+        const int rank = __popcll(hmask & ((1ull << lane) - 1ull));
+        double* t = L + a.lds.tol;
+        if (has_hop && rank < kHopLanes) {
+          reinterpret_cast<int*>(t + T_HOP_STAGE)[rank] = lane;
+          reinterpret_cast<float*>(t + T_HOP_VEC)[2 * rank] = hop_x;
+          reinterpret_cast<float*>(t + T_HOP_VEC)[2 * rank + 1] = hop_y;
+        }
+        nhops = min(__popcll(hmask), (int)kHopLanes);
+        if (lane == 0) reinterpret_cast<int*>(t + T_HOP_STAGE)[kHopLanes] = nhops;
+      }
       WAVE_SYNC();
     } else {
       // specialisations: all lanes walk the same short sweep, reusing the winner's sin/cos
@@ -727,7 +745,8 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       } else if (lane < nvr) { dm = fabsf(newton_sol); anynear = (AMODE[4 * (lane / 3) + 2] == 1); }   // (d[lane], still in a register)
       dm = wave_max_f(dm);
       const bool near_any = __ballot(anynear != 0) != 0ull;
-      if ((double)dm < TOL[T_EARLY] && !near_any) { status = NEO_MPC_STATUS_CONVERGED; break; }
+      // (with a cheaper cell a hop away the search runs once more: its hop lanes decide)
+      if ((double)dm < TOL[T_EARLY] && !near_any && nhops == 0) { status = NEO_MPC_STATUS_CONVERGED; break; }
       // a full Newton step below opt_tolerance (SLSQP's own step test) is the last one: searched
       // and taken like any other, but nothing re-checks the point it lands on
       if ((double)dm < TOL[T_FINAL] && !near_any) final_step = true;
@@ -781,10 +800,19 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       WAVE_SYNC();
     }
     if (!took_trial) {
+    // hop lanes (Riccati): lane h in 1..nhops tries the current point with the block of hop stage h - 1 changed
+    int hop_stage = -1;
+    float hop_x = 0.0f, hop_y = 0.0f;
+    if (kRiccati && lane >= 1 && lane <= nhops) {
+      const double* t = TOL;
+      hop_stage = reinterpret_cast<const int*>(t + T_HOP_STAGE)[lane - 1];
+      hop_x = reinterpret_cast<const float*>(t + T_HOP_VEC)[2 * (lane - 1)];
+      hop_y = reinterpret_cast<const float*>(t + T_HOP_VEC)[2 * (lane - 1) + 1];
+    }
     double fc = rollout_cost<kSteps, kTame>(
         a, c, L,
         [&](int i, double& b0, double& b1, double& b2) {
-          candidate_block<kTame, kRiccati>(a, c, L, lane, step, pstep, i, b0, b1, b2);
+          candidate_block<kTame, kRiccati>(a, c, L, lane, step, pstep, i, b0, b1, b2, hop_stage, hop_x, hop_y);
           if (it == 0 && lane == 0) { b0 = u[3 * i]; b1 = u[3 * i + 1]; b2 = u[3 * i + 2]; }
           if (kSteps) { cand[3 * i] = b0; cand[3 * i + 1] = b1; cand[3 * i + 2] = b2; }
         },
@@ -826,9 +854,16 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       } else if (!took_trial) {
         // rebuild the winning candidate cooperatively: lane i takes control block i
         const double bstep = lane_value(step, best), bpstep = lane_value(pstep, best);
+        int bhop = -1;
+        float bhx = 0.0f, bhy = 0.0f;
+        if (kRiccati && best >= 1 && best <= nhops) {   // (a hop candidate won)
+          bhop = reinterpret_cast<const int*>(TOL + T_HOP_STAGE)[best - 1];
+          bhx = reinterpret_cast<const float*>(TOL + T_HOP_VEC)[2 * (best - 1)];
+          bhy = reinterpret_cast<const float*>(TOL + T_HOP_VEC)[2 * (best - 1) + 1];
+        }
         for (int i = lane; i < n; i += kLanes) {
           double b0, b1, b2;
-          candidate_block<kTame, kRiccati>(a, c, L, best, bstep, bpstep, i, b0, b1, b2);
+          candidate_block<kTame, kRiccati>(a, c, L, best, bstep, bpstep, i, b0, b1, b2, bhop, bhx, bhy);
           u_new[3 * i] = b0; u_new[3 * i + 1] = b1; u_new[3 * i + 2] = b2;
         }
       }

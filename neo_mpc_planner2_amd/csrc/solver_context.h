@@ -18,6 +18,14 @@ enum : int {
   S_LAST = 0, S_OLD_GOAL = 3, S_WAIT = 10, SI_HAS_GOAL = 22, SI_COLLISION = 23, SI_COLL_FP = 24
 };
 
+// The tolerance block of LDS (LdsLayout::tol, doubles): stop tolerances and cold per-instance constants, read once per
+// iteration through an opaque offset so that they do not sit in scalar registers; from T_HOP_STAGE on: the hop
+// candidates of the current iteration (costmap.h edge_hop) -- four stage indices + their count as int32, then four
+// (dvx, dvy) pairs as float32.
+enum : int { T_XTOL, T_EARLY, T_FINAL, T_FTOL, T_STALL, T_WTOL, T_KINK, T_KONST, T_TRUE_YAW, T_MU, T_WTOL_LATE,
+             T_HOP_DROP, T_HOP_RANGE, T_HOP_STAGE = 13 /* int32[6]: stage[4], count, - */, T_HOP_VEC = 16 /* float[8] */,
+             kHopLanes = 4 };
+
 struct Ctx {
   double cx, cy, tyaw, fyaw, c0, s0, X0, Y0, v0, v1, v2, konst, true_yaw;
   int tile_x0, tile_y0;

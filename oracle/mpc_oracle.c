@@ -1028,6 +1028,54 @@ static void orc_candidate(const orc_ctx* c, const orc_active* act, int lane, dou
   }
 }
 
+/* Hop candidates of the stage-wise direction (mirror of costmap.h edge_hop + feasible_set.h).  The costmap term is
+ * piecewise constant: a stage that sits within ORC_HOP_DIST cells of a cell edge behind which the term is LOWER can
+ * gain that step for next to nothing -- a displacement of a few millimetres -- but no descent direction says so (the
+ * term has no gradient), and at a heavy costmap weight one such step is worth more than the whole 1e-3 budget
+ * (found with the G9 fixtures: the node's own defaults, every weight 0.5; SLSQP's line search lands across such
+ * edges by chance).  Lanes 1..ORC_HOP_LANES of the search therefore try: the current point with ONE block changed so
+ * that its stage lands ORC_HOP_MARGIN cells inside the cheaper neighbour cell (all later stages shift with it).
+ * hop[i] = the change of block i's (vx, vy), has[i] = stage i has a cheaper neighbour in range. */
+#define ORC_HOP_DIST 0.25
+#define ORC_HOP_MARGIN 0.02
+#define ORC_HOP_MAX_DV 0.05   /* a hop never changes a velocity by more than this (m/s): hop range <= 0.05 dt */
+#define ORC_HOP_LANES 4
+static int orc_hops_on = 1;
+void orc_set_hops(int on) { orc_hops_on = on; }
+static int orc_hops(const orc_ctx* c, const double* u, double min_drop, double hop[][2], uint8_t* has) {
+  const orc_map* m = c->map;
+  const double range = fmin(ORC_HOP_DIST, ORC_HOP_MAX_DV * c->dt / m->resolution);
+  double x = 0.0, y = 0.0, th = 0.0;
+  int any = 0;
+  for (int i = 0; i < c->n; ++i) {
+    th += u[3 * i + 2] * c->dt;
+    const double cs = cos(th), sn = sin(th);
+    x += (u[3 * i] * cs - u[3 * i + 1] * sn) * c->dt;
+    y += (u[3 * i] * sn + u[3 * i + 1] * cs) * c->dt;
+    const double X = c->X0 + (c->c0 * x - c->s0 * y), Y = c->Y0 + (c->s0 * x + c->c0 * y);
+    int64_t mx, my;
+    orc_world_to_map(m, X, Y, &mx, &my);
+    const double fx = (X - m->origin_x) / m->resolution - (double)mx, fy = (Y - m->origin_y) / m->resolution - (double)my;
+    const double here = orc_term_at(c, mx, my);
+    const int64_t nbx[4] = {mx - 1, mx + 1, mx, mx}, nby[4] = {my, my, my - 1, my + 1};
+    const double dist[4] = {fx, 1.0 - fx, fy, 1.0 - fy}, sign[4] = {-1.0, 1.0, -1.0, 1.0};
+    has[i] = 0; hop[i][0] = 0.0; hop[i][1] = 0.0;
+    double best = min_drop;   /* (a step worth less than a tenth of opt_tolerance is not worth a hop) */
+    for (int k = 0; k < 4; ++k) {
+      const double drop = here - orc_term_at(c, nbx[k], nby[k]);
+      if (!(dist[k] < range && drop > best)) continue;
+      best = drop;
+      const double len = sign[k] * (dist[k] + ORC_HOP_MARGIN) * m->resolution;   /* metres along the world axis */
+      const double wx = k < 2 ? len : 0.0, wy = k < 2 ? 0.0 : len;
+      const double rx = c->c0 * wx + c->s0 * wy, ry = -c->s0 * wx + c->c0 * wy;      /* rollout frame */
+      hop[i][0] = (cs * rx + sn * ry) / c->dt; hop[i][1] = (-sn * rx + cs * ry) / c->dt;  /* block i's frame */
+      has[i] = 1;
+    }
+    any |= has[i];
+  }
+  return any;
+}
+
 /* test hook: the direction of one iteration of the next orc_pg_solve call (single-threaded use) */
 static int orc_capture_it = -1;
 static double* orc_capture_d = NULL;
@@ -1112,6 +1160,11 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
   for (it = 0; it < max_it; ++it) {
     orc_grad_smooth(&c, u, gs);
     orc_reduce(&c, u, gs, gt, gr, &act);
+    double hop[ORC_MAXN][2];
+    uint8_t has_hop[ORC_MAXN];
+    int hop_stage[ORC_HOP_LANES], nhops = 0;
+    if (riccati && orc_hops_on && orc_hops(&c, u, 0.1 * p->opt_tolerance, hop, has_hop))
+      for (int i = 0; i < n && nhops < ORC_HOP_LANES; ++i) if (has_hop[i]) hop_stage[nhops++] = i;
     if (newton) {
       /* a cold start (x0 = 0, the reference's reset state py:359) is far from the minimiser and the
        * Newton step almost never wins there (9 % of the cases): lanes 32-63 walk the reduced
@@ -1129,7 +1182,8 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
         /* (blocks next to the kink are moved by the prox step, which d does not describe -- unless they are at
          * rest on it) */
         for (int i = 0; i < n; ++i) anynear |= act.near[i] && !(orc_rest_rule && act.rest[i]);
-        if (dm < xtol && !anynear) { status = NEO_MPC_STATUS_CONVERGED; break; }
+        /* (with a cheaper cell a hop away the search runs once more: its hop lanes decide) */
+        if (dm < xtol && !anynear && nhops == 0) { status = NEO_MPC_STATUS_CONVERGED; break; }
         /* a full Newton step below opt_tolerance (SLSQP's own step test) is the last one: it is
          * searched and taken like any other, but nothing re-checks the point it lands on (the
          * error left is of the order of the step squared) */
@@ -1197,6 +1251,13 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
     for (int lane = 0; lane < ORC_LANES && !trial_ok; ++lane) {
       orc_candidate(&c, &act, lane, alpha, u, gs, d, cand);
       if (it == 0 && lane == 0) memcpy(cand, u, sizeof(double) * nv); /* the kernel gets f(x0) from this lane */
+      if (lane >= 1 && lane <= nhops) {   /* hop candidate: u with one block moved across a cheaper cell edge */
+        const int i = hop_stage[lane - 1];
+        memcpy(cand, u, sizeof(double) * nv);
+        double b[3] = {u[3 * i] + hop[i][0], u[3 * i + 1] + hop[i][1], u[3 * i + 2]};
+        orc_project(&c, b);
+        cand[3 * i] = b[0]; cand[3 * i + 1] = b[1];
+      }
       double fc = orc_eval(&c, cand);
       if (fc < fb) { fb = fc; best = lane; memcpy(best_c, cand, sizeof(double) * nv); }
       if (lane >= 32 && fc < fb_qn) { fb_qn = fc; best_qn = lane; }

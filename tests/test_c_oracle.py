@@ -34,7 +34,7 @@ def test_g2_yaw():
         assert c_oracle.yaw(*q) == rpy[2]
 
 
-@pytest.mark.parametrize("fixture", ["g4_episodes.npz", "g4_episodes_n8.npz", "g4_episodes_params.npz"])
+@pytest.mark.parametrize("fixture", util.EPISODE_FIXTURES)
 def test_g4_wrapper_episodes_injected(fixture):
     """P5 for the C wrapper: responses and state over the recorded episodes, reference x.x injected."""
     g = util.load(fixture)
@@ -277,11 +277,13 @@ def test_p2_p3_solver_mirror_at_other_parameter_sets(pset, n_steps, method):
         riccati = method == 3 or (method == 0 and (n_steps != 3 or params["w_costmap"] > 0.25 * params["w_trans"]))
         if cells.any() and pset == "turn" and not riccati:
             # w_costmap = 0.3 (six times the README's) and lethal cells next to the path: the dense-Newton and
-            # L-BFGS directions have no wall model (oracle: orc_wall_model; device: costmap.h) -- a search blocked by
-            # a lethal cell creeps up to it and ends there, in 2 of 24 cases at control_steps 3 (3e-3 and 9e-3 above
-            # SLSQP's value, 4e-2 with L-BFGS) and 1 of 12 at 8 (0.68 above); 11 end more than 1e-3 BELOW it.  Gated
-            # as a distribution for these directions; the Riccati direction passes the plain bar.  DESIGN.md section 1.
-            assert (worse <= 1e-3).mean() >= 0.9 and np.median(worse) <= 0.0, (worse.max(), np.median(worse))
+            # L-BFGS directions have no wall model (oracle: orc_wall_model; device: costmap.h) -- FORCED onto this
+            # weight (AUTO never sends them there; G8 "mid" pins its threshold) a search blocked by a lethal cell
+            # creeps up to it and ends there, in 2 of 24 cases at control_steps 3 (3e-3 and 9e-3 above SLSQP's value,
+            # 4e-2 with L-BFGS) and 1 of 12 at 8 (0.68 above); 11 end more than 1e-3 BELOW it.  Hard bounds on the
+            # known outliers; the stage-wise direction passes the plain bar.  DESIGN.md section 1.
+            assert (worse > 1e-3).sum() <= (2 if n_steps == 3 else 1), np.sort(worse)[-3:]
+            assert worse.max() <= (1.0 if n_steps == 8 else 5e-2 if method == 1 else 1.5e-2), worse.max()
         else:
             assert (worse <= 1e-3).all(), worse.max()                                                          # P3
         assert (cmds["status"] == 0).all()
@@ -290,3 +292,105 @@ def test_p2_p3_solver_mirror_at_other_parameter_sets(pset, n_steps, method):
             du0 = np.abs(x[:, :3] - g["x_tight"][mask][:, :3]).max(axis=1)
             assert du0[ok].max() <= 1e-3, du0[ok].max()                                                        # P2
             assert (cmds["cost"] <= g["f_tight"][mask] + 1e-6).all()
+
+
+# ------------------------------------------------------------------ round 3: the remaining pins of the solver
+def _command(params, cmap, probs, x):
+    """the velocity command optimizer() returns for raw solver output x (py:365-395: low-pass + clamp), cold state"""
+    st, warm = synthetic.make_states(probs, params["control_steps"])
+    return c_oracle.postprocess_batch(params, cmap, probs, st, warm, x.copy())[0]["vel"]
+
+
+@pytest.mark.parametrize("fixture,prefix", util.G9_GROUPS)
+@pytest.mark.parametrize("method", [0, 2, 1])
+def test_g9_node_defaults_p2_p3_and_the_literal_command_gate(fixture, prefix, method):
+    """G9: the parameter values the node itself declares (py:49-75: opt_tolerance 1e-5, every weight 0.5, w_footprint
+    2000, limits 0.5, horizon 0.5).  P2 / P3 as for G3 -- P3 against SLSQP as shipped at THIS tolerance (ftol 1e-5) --
+    and the north star's sentence taken literally, on the COMMAND (after low-pass and clamp), zero map:
+      (L1) within 1e-3 of the SciPy path run to convergence (ftol 1e-12), every case;
+      (L2) never further from the SciPy path as shipped (ftol 1e-5) than that path is from its own converged answer,
+           + 1e-4 (SLSQP at 1e-5 still stops up to 0.1 short in u0: the objective is that flat);
+      (L3) within 1e-3 of the path as shipped wherever the path as shipped is itself converged to 1e-4."""
+    g, params, probs, hm = util.solve_group(fixture, prefix)
+    assert params["opt_tolerance"] == 1e-5 and params["w_costmap"] == 0.5 and params["w_footprint"] == 2000
+    params["method"] = method
+    for mask, cells in ((~hm, np.zeros_like(g["cells"])), (hm, g["cells"])):
+        cmap = (cells,) + tuple(g["map_meta"])
+        cmds, x = _cold_solve(params, cmap, probs[mask])
+        assert (cmds["status"] == 0).all()
+        worse = cmds["cost"] - g["f_loose"][mask]
+        if cells.any() and method != 0:
+            # the directions without hop candidates (dense Newton, L-BFGS; AUTO takes the stage-wise one at this costmap
+            # weight): two cases sit a millimetre from a cheaper cell SLSQP's line search happened to land in
+            assert (worse <= 1e-3).sum() >= len(worse) - 2 and worse.max() <= 4e-3, np.sort(worse)[-3:]
+        else:
+            assert (worse <= 1e-3).all(), worse.max()                                                         # P3
+        if not cells.any():
+            ok = g["status_tight"][mask] == 0
+            du0 = np.abs(x[:, :3] - g["x_tight"][mask][:, :3]).max(axis=1)
+            assert du0[ok].max() <= 1e-3 and du0[ok].max() <= 2e-4, du0[ok].max()                            # P2
+            assert (cmds["cost"] <= g["f_tight"][mask] + 1e-5).all()
+            v_build = _command(params, cmap, probs[mask], x)
+            v_loose = _command(params, cmap, probs[mask], g["x_loose"][mask])
+            v_tight = _command(params, cmap, probs[mask], g["x_tight"][mask])
+            d_bt = np.abs(v_build - v_tight).max(axis=1)
+            d_bl = np.abs(v_build - v_loose).max(axis=1)
+            d_lt = np.abs(v_loose - v_tight).max(axis=1)
+            assert d_bt[ok].max() <= 1e-3 and d_bt[ok].max() <= 1e-4, d_bt[ok].max()                          # L1
+            assert (d_bl[ok] <= d_lt[ok] + 1e-4).all(), (d_bl - d_lt)[ok].max()                               # L2
+            settled = ok & (d_lt <= 1e-4)
+            assert settled.sum() >= len(ok) // 2 and d_bl[settled].max() <= 1e-3, d_bl[settled].max()        # L3
+
+
+@pytest.mark.parametrize("fixture,prefix", util.G8_MID_GROUPS)
+@pytest.mark.parametrize("method", [0, 2, 3])
+def test_g8_mid_costmap_weights_across_the_auto_threshold(fixture, prefix, method):
+    """G8 "mid": the README's parameters with w_costmap / w_trans = 0.10 ... 0.30, every case on the costmap: P3 for
+    the dense-Newton direction (AUTO below 1/4) and the stage-wise one (AUTO above) on every case -- the threshold of
+    neo_mpc_capi.cpp derive() keeps neither away from problems it cannot do."""
+    g, params, probs, hm = util.solve_group(fixture, prefix)
+    assert hm.all() and abs(params["w_costmap"] / params["w_trans"] - int(prefix[1:3]) / 100.0) < 1e-12
+    params["method"] = method
+    cmap = (g["cells"],) + tuple(g["map_meta"])
+    cmds, x = _cold_solve(params, cmap, probs)
+    assert (cmds["status"] == 0).all()
+    assert (cmds["cost"] <= g["f_loose"] + 1e-3).all(), (cmds["cost"] - g["f_loose"]).max()
+    assert np.allclose(c_oracle.objective_batch(params, cmap, probs, g["x_tight"]), g["f_tight"], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("method", [0, 1])
+def test_g3_n32_unique_minimisers(method):
+    """G3 at control_steps 32 on the all-free map: 64 problems, SLSQP's maxiter raised until ftol 1e-12 reports
+    status 0 (57 of them): P2 for BASELINE config 5 rests on these."""
+    g, params, probs, _ = util.solve_group("g3_solves_n32_zero.npz", "")
+    assert params["control_steps"] == 32
+    params["method"] = method
+    if method == 1:
+        params["max_iterations"] = 600
+    zero = (np.zeros((200, 200), np.uint8),) + tuple(g["map_meta"])
+    cmds, x = _cold_solve(params, zero, probs)
+    ok = g["status_tight"] == 0
+    assert ok.sum() >= 40
+    du0 = np.abs(x[:, :3] - g["x_tight"][:, :3]).max(axis=1)
+    assert du0[ok].max() <= 1e-3 and du0[ok].max() <= (2e-4 if method == 0 else 5e-4), du0[ok].max()
+    assert (cmds["cost"] <= g["f_tight"] + 1e-6).all() and (cmds["cost"] <= g["f_loose"] + 1e-3).all()
+    assert (cmds["status"] == 0).all()
+    f_at = c_oracle.objective_batch(params, zero, probs, g["x_tight"])
+    assert np.allclose(f_at, g["f_tight"], rtol=1e-12, atol=1e-12)
+
+
+def test_hop_candidates_never_hurt_and_find_the_cheaper_cell():
+    """The hop lanes of the stage-wise direction (orc_hops / costmap.h): switched off, the same problems end at the
+    same or a higher objective -- and the two G9 cases that sit a millimetre from a cheaper cell end 3.5e-3 and 1.7e-3
+    above the reference's SLSQP value."""
+    lib = c_oracle.load()
+    g, params, probs, hm = util.solve_group("g9_solves_pydefaults.npz", "n3_")
+    cmap = (g["cells"],) + tuple(g["map_meta"])
+    on = _cold_solve(params, cmap, probs[hm])[0]
+    lib.orc_set_hops(0)
+    try:
+        off = _cold_solve(params, cmap, probs[hm])[0]
+    finally:
+        lib.orc_set_hops(1)
+    assert ((off["cost"] - g["f_loose"][hm]) > 1e-3).sum() == 2 and ((on["cost"] - g["f_loose"][hm]) <= 1e-3).all()
+    assert (on["cost"] <= off["cost"] + 1e-9).mean() >= 0.95

@@ -43,7 +43,7 @@ def test_objective_kernel_matches_reference_golden(solver_mod, n_steps):
 
 
 # ------------------------------------------------------------------ P5: wrapper episodes
-@pytest.mark.parametrize("fixture", ["g4_episodes.npz", "g4_episodes_n8.npz", "g4_episodes_params.npz"])
+@pytest.mark.parametrize("fixture", util.EPISODE_FIXTURES)
 def test_postprocess_kernel_reproduces_reference_episodes(solver_mod, fixture):
     from oracle import c_oracle
     g = util.load(fixture)
@@ -171,8 +171,8 @@ def test_p2_p3_at_other_parameter_sets(solver_mod, pset, n_steps, method):
     """G8: the reference's SLSQP solves for parameter sets that take the GENERAL kernels (not the README-like
     "tame" specialisations): the vx/vy box cutting the speed disc with v_cur outside the feasible set for many
     requests ("cut"), and a fast-turning robot whose heading leaves [-pi/4, pi/4] within a 1.2 s horizon, with
-    other weights ("turn").  P2 on the zero map, P3 everywhere -- for "turn" on the costmap as a distribution:
-    w_costmap = 0.3 turns cost steps into walls that block either local search somewhere else."""
+    other weights ("turn").  P2 on the zero map, P3 everywhere -- with hard per-case bounds on the known outliers of
+    the dense-Newton / L-BFGS directions when they are FORCED onto "turn"'s heavy costmap weight."""
     g = util.load("g8_solves_params.npz")
     k = "%s_n%d_" % (pset, n_steps)
     params = util.params_from(g["param_keys"], g[k + "params"])
@@ -194,7 +194,12 @@ def test_p2_p3_at_other_parameter_sets(solver_mod, pset, n_steps, method):
         # (the direction with the wall model: no outliers; AUTO picks it at control_steps 3 too when w_costmap > w_trans / 4)
         riccati = method == 3 or (method == 0 and (n_steps != 3 or params["w_costmap"] > 0.25 * params["w_trans"]))
         if cells.any() and pset == "turn" and not riccati:
-            assert (worse <= 1e-3).mean() >= 0.9 and np.median(worse) <= 0.0, (worse.max(), np.median(worse))
+            # FORCED onto a heavy costmap weight (w_costmap / w_trans = 0.37: AUTO never sends them there, G8 "mid"
+            # pins its threshold) the directions without a wall model keep known outliers -- searches that crept up
+            # to a lethal cell: at most 2 of 24 cases (control_steps 3: 3e-3 and 9e-3 above SLSQP with the dense
+            # system, 4e-2 with L-BFGS) and 1 of 12 (control_steps 8: 0.68 above); every other case holds the bar
+            assert (worse > 1e-3).sum() <= (2 if n_steps == 3 else 1), np.sort(worse)[-3:]
+            assert worse.max() <= (1.0 if n_steps == 8 else 5e-2 if method == 1 else 1.5e-2), worse.max()
         else:
             assert (worse <= 1e-3).all(), worse.max()
         xs = x.reshape(len(x), -1, 3)
@@ -209,7 +214,113 @@ def test_p2_p3_at_other_parameter_sets(solver_mod, pset, n_steps, method):
             assert (cmds["cost"] <= g[k + "f_tight"][mask] + 1e-6).all()
 
 
-@pytest.mark.parametrize("fixture", ["g4_episodes.npz", "g4_episodes_n8.npz", "g4_episodes_params.npz"])
+
+# ------------------------------------------------------------------ round 3: the remaining pins of the solver
+def _command(s, probs, x, n_steps):
+    """the velocity command optimizer() returns for raw solver output x (py:365-395: low-pass + clamp), cold state,
+    through K2 on the device"""
+    st, warm = synthetic.make_states(probs, n_steps)
+    return s.postprocess(probs, st, warm, x.copy())["vel"]
+
+
+@pytest.mark.parametrize("fixture,prefix", util.G9_GROUPS)
+@pytest.mark.parametrize("method", [0, 2, 1])
+def test_g9_node_defaults_p2_p3_and_the_literal_command_gate(solver_mod, fixture, prefix, method):
+    """G9: the parameter values the node itself declares (py:49-75: opt_tolerance 1e-5, every weight 0.5, w_footprint
+    2000, limits 0.5, horizon 0.5), cold solves by the reference's SLSQP at control_steps 3 and 8.  P2 / P3 as for
+    G3 -- P3 against SLSQP as shipped at THIS tolerance (ftol 1e-5) -- and the north star's sentence taken literally,
+    on the COMMAND (after low-pass and clamp, K2), zero map:
+      (L1) within 1e-3 of the SciPy path run to convergence (ftol 1e-12), every case;
+      (L2) never further from the SciPy path as shipped (ftol 1e-5) than that path is from its own converged answer,
+           + 1e-4 (SLSQP at 1e-5 still stops up to 0.1 short in u0: the objective is that flat);
+      (L3) within 1e-3 of the path as shipped wherever the path as shipped is itself converged to 1e-4."""
+    g, params, probs, hm = util.solve_group(fixture, prefix)
+    n_steps = params["control_steps"]
+    assert params["opt_tolerance"] == 1e-5 and params["w_costmap"] == 0.5 and params["w_footprint"] == 2000
+    params["method"] = method
+    for mask, cells in ((~hm, np.zeros_like(g["cells"])), (hm, g["cells"])):
+        cmap = (cells,) + tuple(g["map_meta"])
+        pr = probs[mask]
+        st, warm = synthetic.make_states(pr, n_steps)
+        with _solver(solver_mod, params, cmap) as s:
+            cmds, x = s.solve(pr, st, warm)
+            assert np.allclose(s.objective(pr, g["x_tight"][mask]), g["f_tight"][mask], rtol=1e-12, atol=1e-12)
+            if not cells.any():
+                v_build = _command(s, pr, x, n_steps)
+                v_loose = _command(s, pr, g["x_loose"][mask], n_steps)
+                v_tight = _command(s, pr, g["x_tight"][mask], n_steps)
+        assert (cmds["status"] == 0).all()
+        xs = x.reshape(len(x), -1, 3)
+        assert (np.hypot(xs[:, :, 0], xs[:, :, 1]) <= params["max_vel_trans"] + 1e-9).all()
+        assert (np.abs(xs) <= 0.5 + 1e-12).all()
+        worse = cmds["cost"] - g["f_loose"][mask]
+        if cells.any() and method != 0:
+            # the directions without hop candidates (dense Newton, L-BFGS; AUTO takes the stage-wise one at this costmap
+            # weight): two cases sit a millimetre from a cheaper cell SLSQP's line search happened to land in
+            assert (worse <= 1e-3).sum() >= len(worse) - 2 and worse.max() <= 4e-3, np.sort(worse)[-3:]
+        else:
+            assert (worse <= 1e-3).all(), worse.max()                                                         # P3
+        if not cells.any():
+            ok = g["status_tight"][mask] == 0
+            du0 = np.abs(x[:, :3] - g["x_tight"][mask][:, :3]).max(axis=1)
+            assert du0[ok].max() <= 1e-3, du0[ok].max()                                                       # P2
+            assert (cmds["cost"] <= g["f_tight"][mask] + 1e-5).all()
+            d_bt = np.abs(v_build - v_tight).max(axis=1)
+            d_bl = np.abs(v_build - v_loose).max(axis=1)
+            d_lt = np.abs(v_loose - v_tight).max(axis=1)
+            assert d_bt[ok].max() <= 1e-3, d_bt[ok].max()                                                     # L1
+            assert (d_bl[ok] <= d_lt[ok] + 1e-4).all(), (d_bl - d_lt)[ok].max()                               # L2
+            settled = ok & (d_lt <= 1e-4)
+            assert settled.sum() >= len(ok) // 2 and d_bl[settled].max() <= 1e-3, d_bl[settled].max()        # L3
+            print("G9 %s method %d: command vs SLSQP@1e-12 max %.1e; vs SLSQP@1e-5: %d of %d within 1e-3 (the reference "
+                  "itself: %d), max %.1e" % (prefix, method, d_bt[ok].max(), (d_bl <= 1e-3).sum(), len(d_bl),
+                                             (d_lt <= 1e-3).sum(), d_bl.max()))
+
+
+@pytest.mark.parametrize("fixture,prefix", util.G8_MID_GROUPS)
+@pytest.mark.parametrize("method", [0, 2, 3])
+def test_g8_mid_costmap_weights_across_the_auto_threshold(solver_mod, fixture, prefix, method):
+    """G8 "mid": the README's parameters with w_costmap / w_trans = 0.10 ... 0.30, every case on the costmap: P3 on
+    EVERY case for the dense-Newton kernel (AUTO below 1/4, the headline kernel) and the stage-wise one (AUTO above):
+    the threshold in neo_mpc_capi.cpp derive() keeps neither away from problems it cannot do."""
+    g, params, probs, hm = util.solve_group(fixture, prefix)
+    assert hm.all() and abs(params["w_costmap"] / params["w_trans"] - int(prefix[1:3]) / 100.0) < 1e-12
+    params["method"] = method
+    cmap = (g["cells"],) + tuple(g["map_meta"])
+    st, warm = synthetic.make_states(probs, 3)
+    with _solver(solver_mod, params, cmap) as s:
+        cmds, x = s.solve(probs, st, warm)
+        assert np.allclose(s.objective(probs, g["x_tight"]), g["f_tight"], rtol=1e-12, atol=1e-12)
+    assert (cmds["status"] == 0).all()
+    assert (cmds["cost"] <= g["f_loose"] + 1e-3).all(), (cmds["cost"] - g["f_loose"]).max()
+    xs = x.reshape(len(x), -1, 3)
+    assert (np.hypot(xs[:, :, 0], xs[:, :, 1]) <= 0.7 + 1e-9).all() and (np.abs(xs) <= 0.7 + 1e-12).all()
+
+
+@pytest.mark.parametrize("method", [0, 1])
+def test_g3_n32_unique_minimisers(solver_mod, method):
+    """G3 at control_steps 32 (BASELINE config 5) on the all-free map: 64 problems solved by the reference's SLSQP with
+    maxiter raised until ftol 1e-12 reports status 0 (57 of them) -- P2 at 32 control steps on >= 40 problems."""
+    g, params, probs, _ = util.solve_group("g3_solves_n32_zero.npz", "")
+    assert params["control_steps"] == 32
+    params["method"] = method
+    if method == 1:
+        params["max_iterations"] = 600
+    zero = (np.zeros((200, 200), np.uint8),) + tuple(g["map_meta"])
+    st, warm = synthetic.make_states(probs, 32)
+    with _solver(solver_mod, params, zero) as s:
+        cmds, x = s.solve(probs, st, warm)
+        assert np.allclose(s.objective(probs, g["x_tight"]), g["f_tight"], rtol=1e-12, atol=1e-12)
+    ok = g["status_tight"] == 0
+    assert ok.sum() >= 40
+    du0 = np.abs(x[:, :3] - g["x_tight"][:, :3]).max(axis=1)
+    assert du0[ok].max() <= 1e-3, du0[ok].max()
+    assert (cmds["cost"] <= g["f_tight"] + 1e-6).all() and (cmds["cost"] <= g["f_loose"] + 1e-3).all()
+    assert (cmds["status"] == 0).all()
+    print("N=32, %d unique-minimiser problems: max |u0 - u0(SLSQP 1e-12)| = %.2e" % (ok.sum(), du0[ok].max()))
+
+
+@pytest.mark.parametrize("fixture", util.EPISODE_FIXTURES)
 def test_p3_on_the_reference_warm_starts(solver_mod, fixture):
     """G4: every call of the recorded episodes is solved from the REFERENCE's own state (its warm start
     `initial_guess`, `last_control`, goal bookkeeping, real costmap): the kernel's answer must be feasible and
@@ -287,7 +398,7 @@ def test_predicted_path_matches_reference_local_plan(solver_mod, n_steps):
     assert (ref[:, :, 2:4] == 0.0).all()
 
 
-@pytest.mark.parametrize("fixture", ["g4_episodes.npz", "g4_episodes_n8.npz", "g4_episodes_params.npz"])
+@pytest.mark.parametrize("fixture", util.EPISODE_FIXTURES)
 def test_predicted_path_of_the_reference_episodes(solver_mod, fixture):
     """G4 `local_plan`: the Path published inside optimizer() (rollout of the UNFILTERED x.x from the request's
     pose) == K2's predicted_path with the reference's x.x injected, over all 520 calls."""

@@ -76,7 +76,7 @@ def test_g3_slsqp_restated_objective_reproduces_reference_solves():
         assert abs(r.fun - g["f_loose"][j]) <= 1e-8 * max(1.0, abs(r.fun))
 
 
-@pytest.mark.parametrize("fixture", ["g4_episodes.npz", "g4_episodes_n8.npz", "g4_episodes_params.npz"])
+@pytest.mark.parametrize("fixture", util.EPISODE_FIXTURES)
 def test_g4_wrapper_episodes_with_injected_solver_output(fixture):
     """P5: given the reference's raw solver output, the restated optimizer() wrapper
     reproduces responses and state across the recorded episodes (control_steps 3 and 8)."""
@@ -146,7 +146,7 @@ def test_g7_local_plan(n_steps):
             assert np.allclose((qx, qy, qz, w), path[i + 1, 2:], rtol=0, atol=1e-15)
 
 
-@pytest.mark.parametrize("fixture", ["g4_episodes.npz", "g4_episodes_n8.npz", "g4_episodes_params.npz"])
+@pytest.mark.parametrize("fixture", util.EPISODE_FIXTURES)
 def test_g4_local_plan_of_the_episodes(fixture):
     """the Path the reference published inside optimizer() (py:365 -> 271-310, tf = the request's pose):
     rollout of the UNFILTERED solver output."""

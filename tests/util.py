@@ -62,4 +62,22 @@ def load_seam_dump(path):
     return params, tuple(geom), maps, np.frombuffer(raw, dtype=rec, count=int(ticks), offset=off)
 
 
+
+def solve_group(name, prefix):
+    """One `_g3_group` of a cold-solve fixture (oracle/gen_golden.py): (arrays by bare name, params, problems,
+    has_map mask)."""
+    g = load(name)
+    params = params_from(g["param_keys"], g[prefix + "params"])
+    group = {k[len(prefix):]: g[k] for k in g.files if k.startswith(prefix)} if prefix else {k: g[k] for k in g.files}
+    probs = problems_from(group["problems"])
+    hm = group["has_map"].astype(bool) if "has_map" in group else np.zeros(len(probs), dtype=bool)
+    return group, params, probs, hm
+
+
+#: (fixture, prefix) of every cold-solve group made at parameters other than the README's at opt_tolerance 1e-3
+G9_GROUPS = (("g9_solves_pydefaults.npz", "n3_"), ("g9_solves_pydefaults.npz", "n8_"))
+G8_MID_GROUPS = tuple(("g8_mid.npz", "r%02d_" % r) for r in (10, 15, 20, 25, 30))
+EPISODE_FIXTURES = ("g4_episodes.npz", "g4_episodes_n8.npz", "g4_episodes_params.npz", "g9_episodes_pydefaults.npz")
+
+
 orc = orc  # re-export: tests use util.orc.make_params
