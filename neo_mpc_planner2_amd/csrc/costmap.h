@@ -77,7 +77,7 @@ constexpr double kSticky = 100.0, kWall = 1e4, kStickyDist = 0.02, kWallDist = 0
 // across such edges by chance).  hop_x / hop_y: the change of THIS stage's block (vx, vy) that puts the stage
 // kHopMargin cells inside the cheaper neighbour (every later stage shifts with it); lanes 1-4 of the search try the
 // current point with one such block changed (feasible_set.h).
-constexpr double kHopMargin = 0.02;
+constexpr double kHopMargin = 0.01;   // (well inside kStickyDist: a stage that has just hopped must not sit ON the edge of the sticky zone; deeper costs objective)
 __device__ __forceinline__ int edge_stickiness(const SolveArgs& a, const Ctx& c, const double* L, double x, double y,
                                                double cs, double sn, double& wxx, double& wxy, double& wyy, double& lx,
                                                double& ly, bool& hop, float& hop_x, float& hop_y) {

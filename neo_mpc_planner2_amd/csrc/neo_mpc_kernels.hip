@@ -889,14 +889,16 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     creeping = creeping || (wtol > 0.0 && (double)stepmax <= TOL[T_STALL] && gain <= 0.5 * gain1 && gain1 <= 0.5 * gain2);
     gain2 = gain1; gain1 = gain;
     f = fb;
-    if (kRiccati && !(it == 0 && cold)) {   // (an iteration that had a Newton direction)
+    // (a hop that won says nothing about step lengths: damping and proximal step stay as they are)
+    const bool hop_won = kRiccati && best >= 1 && best <= nhops;
+    if (kRiccati && !(it == 0 && cold) && !hop_won) {   // (an iteration that had a Newton direction)
       const float bs = (float)lane_value(step, best);
       const double mu0 = n > 8 ? (double)(n - 8) * 0.125 : 0.0, mu = TOL[T_MU];
       double* mu_slot = L + tol_off + T_MU;
       if (best >= 32 && bs >= 0.8f) { if (lane == 0) *mu_slot = fmax(0.25 * mu, mu0 * 0.0625); }
       else if (best < 32 || bs < 0.3f) { if (lane == 0) *mu_slot = fmin(4.0 * mu, 16.0 * mu0); }
     }
-    if (best < 32) {
+    if (best < 32 && !hop_won) {
       alpha = lane_value(step, best);
       alpha = clampd(alpha, 1e-6, 1e6);
     }

@@ -1037,7 +1037,7 @@ static void orc_candidate(const orc_ctx* c, const orc_active* act, int lane, dou
  * that its stage lands ORC_HOP_MARGIN cells inside the cheaper neighbour cell (all later stages shift with it).
  * hop[i] = the change of block i's (vx, vy), has[i] = stage i has a cheaper neighbour in range. */
 #define ORC_HOP_DIST 0.25
-#define ORC_HOP_MARGIN 0.02
+#define ORC_HOP_MARGIN 0.01   /* (well inside ORC_STICKY_DIST: a stage that has just hopped must not sit ON the edge of the wall model's sticky zone; deeper costs objective -- the control norm charges every mm/s) */
 #define ORC_HOP_MAX_DV 0.05   /* a hop never changes a velocity by more than this (m/s): hop range <= 0.05 dt */
 #define ORC_HOP_LANES 4
 static int orc_hops_on = 1;
@@ -1293,11 +1293,13 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
     memcpy(near_prev, act.near, sizeof(near_prev));
     const double decrease = f - fb;
     f = fb;
-    if (!(it == 0 && cold)) {   /* (an iteration that had a Newton direction) */
+    /* (a hop that won says nothing about step lengths: damping and proximal step stay as they are) */
+    const int hop_won = best >= 1 && best <= nhops;
+    if (!(it == 0 && cold) && !hop_won) {   /* (an iteration that had a Newton direction) */
       if (best >= 32 && orc_lane_scale(best, act.longshots) >= 0.8) mu = fmax(0.25 * mu, mu_lo);
       else if (best < 32 || orc_lane_scale(best, act.longshots) < 0.3) mu = fmin(4.0 * mu, mu_hi);
     }
-    if (best < 32) {
+    if (best < 32 && !hop_won) {
       alpha *= orc_lane_scale(best, act.longshots);
       alpha = orc_clamp(alpha, 1e-6, 1e6);
     }
