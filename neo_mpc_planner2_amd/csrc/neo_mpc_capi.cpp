@@ -194,6 +194,13 @@ void derive(neo_mpc_handle* h) {
   d.wtol_late = p.window_tolerance > 0.0 ? p.window_tolerance
                 : (p.window_tolerance == 0.0 && d.newton) ? 3e-3 * p.opt_tolerance : 0.0;
 
+  // Blocked-run stop rule of the dense Newton direction (neo_mpc_kernels.hip kBlockedRun): three iterations in a row not
+  // won by a decent Newton step that together gain less than 0.1 x opt_tolerance -- 0.03 x when no stage of the rollout
+  // has a costmap term under it -- end the search.  Absolute (a search on its way out of a lethal cell has a huge f);
+  // scaled with the horizon like the stall threshold; part of the window rule (off with it).
+  d.btol_map = (d.newton == 1 && d.wtol > 0.0) ? 0.1 * flat * p.opt_tolerance : 0.0;
+  d.btol_free = (d.newton == 1 && d.wtol > 0.0) ? 0.03 * flat * p.opt_tolerance : 0.0;
+
   // LDS carve-up (shared with the kernel specialisations) + reach tile geometry
   LdsLayout& l = h->lds;
   // the control_steps == 3 specialisations carve LDS at compile time with 4 pair slots; the host

@@ -33,6 +33,8 @@ struct DevParams {
   double wtol;               // three iterations in a row gaining less than this (relative) end the search; 0: off
   double wtol_late;          // ... the same from iteration kLateIteration on (the control_steps-3 window)
   double kink_radius;        // |u_i - v_cur| below which a block is handled by the prox step only
+  double btol_map, btol_free;  // dense Newton direction: kBlockedRun consecutive iterations not won by a decent Newton step that
+                             // together gain less than this end the search (with / without a costmap term under the rollout); 0: off
   double hop_min_drop;       // stage-wise direction: a cheaper neighbour cell is worth a hop candidate when its costmap
                              // term is lower by more than this (0.1 * opt_tolerance)
   double hop_range;          // ... and its edge is closer than this (cells): min(0.25, 0.05 m/s * dt / resolution)
@@ -83,7 +85,7 @@ constexpr LdsLayout make_lds_layout(int n, int mem, bool riccati) {
   int off = 0;
   l.prob = off; off += 32;
   l.state = off; off += 16;
-  l.tol = off; off += 20;   // stop tolerances + two cold per-instance constants (read once per iteration; kept out of the scalar
+  l.tol = off; off += 22;   // stop tolerances + two cold per-instance constants (read once per iteration; kept out of the scalar
                             // registers), then the hop candidates of the current iteration (solver_context.h)
   l.term = off; off += 256;
   l.u = off; off += nv;

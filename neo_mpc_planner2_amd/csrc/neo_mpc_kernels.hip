@@ -52,6 +52,8 @@ namespace {
 // consecutive iterations gaining less than ftol*max(1,|f|) or moving less than stall_step that end
 // the search (creeping along a costmap cell edge gains ~1e-9 per iteration for ever)
 constexpr int kStallIterations = 5;
+constexpr int kBlockedRun = 3;       // dense Newton: this many iterations in a row not won by a decent Newton step ...
+constexpr double kBlockedStep = 0.25;  // ... (a proximal lane, or a Newton step cut below this) arm the blocked-run stop rule
 constexpr int kLateIteration = 20;   // from here on the three-iteration window is the control_steps-3 one (neo_mpc_capi.cpp)
 
 // Study build (make timing -> libneo_mpc_timing.so): shader-clock stamps at the phase boundaries of
@@ -180,6 +182,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     t[T_STALL] = p.stall_step; t[T_WTOL] = p.wtol; t[T_WTOL_LATE] = p.wtol_late; t[T_KINK] = p.kink_radius;
     t[T_KONST] = c.konst; t[T_TRUE_YAW] = c.true_yaw;
     t[T_HOP_DROP] = p.hop_min_drop; t[T_HOP_RANGE] = p.hop_range;
+    t[T_BTOL_MAP] = p.btol_map; t[T_BTOL_FREE] = p.btol_free;
     reinterpret_cast<int*>(t + T_HOP_STAGE)[kHopLanes] = 0;   // no hop candidates yet
   }
   c.konst = 0.0; c.true_yaw = 0.0;
@@ -236,6 +239,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     v_feasible = b0 == c.v0 && b1 == c.v1 && b2 == c.v2;
   }
   int npairs = 0, head = 0, nfev = 1, it = 0, status = NEO_MPC_STATUS_MAX_ITER, stall = 0;
+  int blocked_run = 0;   // dense Newton: consecutive iterations not won by a decent Newton step
   double gain1 = INFINITY, gain2 = INFINITY;  // objective decrease of the previous two iterations
   bool final_step = false;
   const int lane_id = lane;
@@ -772,7 +776,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     // what steps over cost edges and out of lethal cells.)
     constexpr double kTrialRatio = 0.75;
     bool took_trial = false;
-    double fb = INFINITY;
+    double fb = INFINITY, cterm = 0.0;   // (cterm, dense Newton: the costmap terms of this lane's candidate alone)
     int best = 32;
     if (kRiccati && free_path && it > 0) {
       const bool on = lane < n;
@@ -818,7 +822,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         },
         [&](int i, double sn, double cs) {
           if (kSteps && !kNewton) { cand_sn[i] = sn; cand_cs[i] = cs; }
-        });
+        }, kNewton ? &cterm : nullptr);
     NEO_PHASE(5);
     if (!(fc == fc)) fc = INFINITY;
     if (it == 0) f = lane_value(fc, 0);
@@ -887,6 +891,22 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     // ... and so does a step below stall_step whose gain halved twice in a row: the search is closing in on a
     // costmap cell edge (or the kink) geometrically; what is left to gain is less than the last gain
     creeping = creeping || (wtol > 0.0 && (double)stepmax <= TOL[T_STALL] && gain <= 0.5 * gain1 && gain1 <= 0.5 * gain2);
+    // Blocked-run stop rule (dense Newton).  kBlockedRun iterations in a row not won by a decent Newton step that
+    // together gain less than 0.1 x opt_tolerance (0.03 x with no costmap term under the new iterate's rollout): something
+    // the quadratic model does not see is in the way -- a costmap cell edge, or blocks hovering next to the control norm's
+    // kink -- and the search advances 1e-6 of f per iteration (SLSQP stops on ONE iteration gaining less than
+    // opt_tolerance).  In a closed 30 Hz loop of 4096 robots such searches set the duration of every launch: per-tick
+    // maximum 25 -> 13 iterations in the median, 100 -> 16 at worst; cold solves and the zero-map drift check are untouched.
+    bool blocked_stop = false;
+    if (kNewton) {
+      const double bs = lane_value(step, best);
+      blocked_run = (best < 32 || bs < kBlockedStep) ? blocked_run + 1 : 0;
+      if (blocked_run >= kBlockedRun) {
+        const bool free_rollout = lane_value(cterm, best) == 0.0;
+        const double btol = free_rollout ? TOL[T_BTOL_FREE] : TOL[T_BTOL_MAP];
+        blocked_stop = gain + gain1 + gain2 <= btol;   // (btol 0: the rule is off -- a gain is never <= 0 here)
+      }
+    }
     gain2 = gain1; gain1 = gain;
     f = fb;
     // (a hop that won says nothing about step lengths: damping and proximal step stay as they are)
@@ -905,7 +925,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     WAVE_SYNC();
     NEO_PHASE(6);
     NEO_PHASE_DUMP();
-    if ((double)stepmax < TOL[T_XTOL] || stall >= kStallIterations || creeping || final_step) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
+    if ((double)stepmax < TOL[T_XTOL] || stall >= kStallIterations || creeping || final_step || blocked_stop) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
   }
 
   NEO_SEGMENT(1);

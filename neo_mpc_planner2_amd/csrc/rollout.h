@@ -21,12 +21,13 @@ struct NoRecord {
 };
 // kSteps > 0: control_steps known at compile time (loops unroll); Record(i, sin, cos) lets the caller
 // keep the rollout's trigonometry (the winner's is reused by the next adjoint sweep)
+// term_sum (optional): the sum of the costmap terms alone -- 0.0 exactly when every stage sits in a free cell
 template <int kSteps = 0, bool kTame = false, class Block, class Record = NoRecord>
 __device__ __forceinline__ double rollout_cost(const SolveArgs& a, const Ctx& c, const double* L, Block block,
-                                               Record record = Record()) {
+                                               Record record = Record(), double* term_sum = nullptr) {
   const DevParams& p = a.p;
   const int n = kSteps ? kSteps : p.n;
-  double f = 0.0, x = 0.0, y = 0.0, th = 0.0;
+  double f = 0.0, x = 0.0, y = 0.0, th = 0.0, ts = 0.0;
 #pragma unroll
   for (int i = 0; i < n; ++i) {
     double vx, vy, w;
@@ -41,8 +42,11 @@ __device__ __forceinline__ double rollout_cost(const SolveArgs& a, const Ctx& c,
     const double e0 = c.v0 - vx, e1 = c.v1 - vy, e2 = c.v2 - w;
     f += p.wt_n * (dx * dx + dy * dy) + p.wo_n * (et * et);   // py:252
     f += p.wc_n * sqrt_fast(e0 * e0 + e1 * e1 + e2 * e2);      // py:253-254
-    f += step_term(a, c, L, x, y);                             // py:246-247, 257-260
+    const double term = step_term(a, c, L, x, y);              // py:246-247, 257-260
+    f += term;
+    if (term_sum) ts += term;
   }
+  if (term_sum) *term_sum = ts;
   const double et = c.fyaw - th;
   return f + p.wterm_o * (et * et) + c.konst;                  // py:266-268
 }

@@ -24,7 +24,7 @@ enum : int {
 // (dvx, dvy) pairs as float32.
 enum : int { T_XTOL, T_EARLY, T_FINAL, T_FTOL, T_STALL, T_WTOL, T_KINK, T_KONST, T_TRUE_YAW, T_MU, T_WTOL_LATE,
              T_HOP_DROP, T_HOP_RANGE, T_HOP_STAGE = 13 /* int32[6]: stage[4], count, - */, T_HOP_VEC = 16 /* float[8] */,
-             kHopLanes = 4 };
+             T_BTOL_MAP = 20, T_BTOL_FREE = 21, kHopLanes = 4 };
 
 struct Ctx {
   double cx, cy, tyaw, fyaw, c0, s0, X0, Y0, v0, v1, v2, konst, true_yaw;

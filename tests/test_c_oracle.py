@@ -394,3 +394,33 @@ def test_hop_candidates_never_hurt_and_find_the_cheaper_cell():
         lib.orc_set_hops(1)
     assert ((off["cost"] - g["f_loose"][hm]) > 1e-3).sum() == 2 and ((on["cost"] - g["f_loose"][hm]) <= 1e-3).all()
     assert (on["cost"] <= off["cost"] + 1e-9).mean() >= 0.95
+
+
+def test_blocked_run_rule_only_shortens_creeping_searches():
+    """The blocked-run stop rule of the dense Newton direction (three iterations in a row not won by a decent Newton
+    step, gaining < 0.1 x opt_tolerance together -- 0.03 x in free space): cold solves end at the same objective (1e-4)
+    in no more iterations, zero-map first controls stay where a solve run to the end puts them, and the warm ticks of a
+    closed control loop (warm start = the previous solution shifted by one control step, py:397-400) lose the creeping
+    searches that set a launch's duration."""
+    lib = c_oracle.load()
+    cmap = synthetic.make_costmap(500, seed=0)
+    probs = synthetic.make_problems(2048, 500, seed=1000)
+    params = orc.make_params()
+    zero = (np.zeros_like(cmap[0]),) + tuple(cmap[1:])
+    res = {}
+    for on in (0, 1):
+        lib.orc_set_blocked_rule(on)
+        try:
+            res[on] = (_cold_solve(params, cmap, probs)[0], util.closed_loop_on_the_mirror(params, cmap, probs, 24),
+                       _cold_solve(params, zero, probs[:1024])[1])
+        finally:
+            lib.orc_set_blocked_rule(1)
+    (c0, l0, z0), (c1, l1, z1) = res[0], res[1]
+    assert (c1["iterations"] <= c0["iterations"]).all() and (c1["cost"] <= c0["cost"] + 1e-4).all()
+    max0 = np.array([t["iterations"].max() for t in l0[5:]]), np.array([t["iterations"].max() for t in l1[5:]])
+    max0, max1 = max0
+    assert np.median(max1) <= 15 and max1.max() <= 20 and np.median(max0) >= 18, (max0, max1)
+    assert all((t["status"] == 0).all() for t in l1)
+    tight = dict(params, window_tolerance=-1.0, step_tolerance=1e-9, cost_tolerance=1e-12, max_iterations=400)
+    zt = _cold_solve(tight, zero, probs[:1024])[1]
+    assert np.abs(z1[:, :3] - zt[:, :3]).max() <= 1e-3 and np.abs(z1[:, :3] - z0[:, :3]).max() <= 1e-4

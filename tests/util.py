@@ -80,4 +80,39 @@ G8_MID_GROUPS = tuple(("g8_mid.npz", "r%02d_" % r) for r in (10, 15, 20, 25, 30)
 EPISODE_FIXTURES = ("g4_episodes.npz", "g4_episodes_n8.npz", "g4_episodes_params.npz", "g9_episodes_pydefaults.npz")
 
 
+
+def closed_loop_on_the_mirror(params, cmap, probs, ticks, hz=30.0):
+    """The fleet loop of neo_mpc_planner2_amd/fleet.py on the CPU mirror (oracle/mpc_oracle.c part 2): robots moved by
+    their own commands, the carrot kept on its initial world bearing, warm start = the reference's shift.  Returns the
+    per-tick command records."""
+    from neo_mpc_planner2_amd import synthetic
+    from oracle import c_oracle
+
+    def yaw_of(q):
+        return np.arctan2(2 * (q[:, 3] * q[:, 2] + q[:, 0] * q[:, 1]), 1 - 2 * (q[:, 1] ** 2 + q[:, 2] ** 2))
+    probs = probs.copy()
+    st, warm = synthetic.make_states(probs, params["control_steps"])
+    yaw, pos = yaw_of(probs["cur_q"]).copy(), probs["cur_xy"].copy()
+    c, s = np.cos(yaw), np.sin(yaw)
+    off = np.stack([c * probs["carrot_xy"][:, 0] - s * probs["carrot_xy"][:, 1],
+                    s * probs["carrot_xy"][:, 0] + c * probs["carrot_xy"][:, 1]], 1)
+    carrot_yaw_w = yaw + yaw_of(probs["carrot_q"])
+    probs["control_interval"] = 1.0 / hz
+    probs["delta_t"] = 1.0 / hz
+    out = []
+    for _ in range(ticks):
+        cm = c_oracle.solve_batch(params, cmap, probs, st, warm)[0]
+        v = cm["vel"]
+        yaw = yaw + v[:, 2] / hz
+        c, s = np.cos(yaw), np.sin(yaw)
+        pos = pos + np.stack([c * v[:, 0] - s * v[:, 1], s * v[:, 0] + c * v[:, 1]], 1) / hz
+        probs["cur_xy"], probs["cur_q"] = pos, synthetic.yaw_quat(yaw)
+        probs["carrot_xy"][:, 0] = c * off[:, 0] + s * off[:, 1]
+        probs["carrot_xy"][:, 1] = -s * off[:, 0] + c * off[:, 1]
+        probs["carrot_q"] = synthetic.yaw_quat(carrot_yaw_w - yaw)
+        probs["cur_vel"] = v
+        out.append(cm)
+    return out
+
+
 orc = orc  # re-export: tests use util.orc.make_params
