@@ -740,6 +740,8 @@ int neo_mpc_objective_batch(neo_mpc_handle* h, const neo_mpc_problem* problems, 
   a.term_table = (const double*)h->term_buf.ptr;
   a.count = (uint32_t)count;
   a.p = h->dp; a.map = h->map;
+  a.w_trans = h->params.w_trans; a.w_orient = h->params.w_orient; a.w_control = h->params.w_control;
+  a.w_terminal = h->params.w_terminal; a.w_costmap = h->params.w_costmap;
   if ((rc = map_acquire(h, nullptr))) return rc;
   launch_objective(a, nullptr);
   HIP_TRY(hipGetLastError());

@@ -164,6 +164,7 @@ struct ObjectiveArgs {
   uint32_t count;
   DevParams p;
   DevMap map;
+  double w_trans, w_orient, w_control, w_terminal, w_costmap;   // undivided, as the reference uses them (py:252-268)
 };
 
 struct IngestArgs {

@@ -968,24 +968,62 @@ __global__ __launch_bounds__(kLanes) void k_postprocess(const SolveArgs args) {
   postprocess(a, c, L, b, lane, u, success, fcost, flags, f, success ? 0 : 1, 0, 1);
 }
 
-// py:204-269 for given controls, one lane per instance
+// py:204-269 for given controls, one lane per instance -- the PARITY kernel: it follows the reference statement by
+// statement (the solver's own rollout forms the world position as X0 + Rot(psi0) (x, y) from the base-frame rollout;
+// this one accumulates odom_yaw, pos_x and pos_y step by step like py:234-236, takes the square root of the distance and
+// squares it again like py:250-252, and divides by control_steps where the reference does), so that it differs from the
+// reference only in the last bits of sin / cos / atan2.
 __global__ __launch_bounds__(256) void k_objective(const ObjectiveArgs a) {
-  __shared__ double term[256];
-  term[threadIdx.x] = a.term_table[threadIdx.x];
+  __shared__ double cost_of[256];   // getCost by raw cell value: occupancy / 100 (the build's costmap contract)
+  cost_of[threadIdx.x] = raw_cost((int)threadIdx.x);
   __syncthreads();
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= a.count) return;
-  SolveArgs sa = {};
-  sa.p = a.p; sa.map = a.map;
-  sa.lds.term = 0; sa.lds.tile = 0; sa.lds.tile_w = 0; sa.lds.tile_h = 0;
+  DevMap map = a.map;
   const double* P = reinterpret_cast<const double*>(a.problems + b);
-  select_map<false>(sa.map, P);
-  Ctx c;
-  make_ctx(a.p, sa.map, P, P[P_FOOTPRINT], c);
-  const double* u = a.u + (size_t)b * 3 * a.p.n;
-  a.cost[b] = rollout_cost(sa, c, term, [&](int i, double& b0, double& b1, double& b2) {
-    b0 = u[3 * i]; b1 = u[3 * i + 1]; b2 = u[3 * i + 2];
-  });
+  select_map<false>(map, P);
+  const int n = a.p.n;
+  const double dt = a.p.dt, w_trans = a.w_trans, w_orient = a.w_orient, w_control = a.w_control;
+  const double target_yaw = yaw_of(P + P_CARROT_Q);                       // py:211
+  const double final_yaw = yaw_of(P + P_GOAL_Q);                          // py:212
+  const double q0[4] = {P[P_CUR_Q], P[P_CUR_Q + 1], P[P_CUR_Q + 2],
+                        (a.p.compat & NEO_MPC_COMPAT_ODOM_YAW_GOAL_W) ? P[P_GOAL_Q + 3] : P[P_CUR_Q + 3]};
+  double odom_yaw = yaw_of(q0);                                           // py:213 (the goal's w: reference quirk)
+  const double* u = a.u + (size_t)b * 3 * n;
+  const double footprint = P[P_FOOTPRINT];
+  double total = 0.0, x = 0.0, y = 0.0, z = 0.0;
+  double pos_x = P[P_CUR_X], pos_y = P[P_CUR_Y];                          // py:220-221
+  for (int i = 0; i < n; ++i) {
+    const double vx = u[3 * i], vy = u[3 * i + 1], wz = u[3 * i + 2];
+    z += wz * dt;                                                         // py:230
+    double sz, cz;
+    sincos(z, &sz, &cz);
+    x += (vx * cz * dt - vy * sz * dt);                                   // py:231
+    y += (vx * sz * dt + vy * cz * dt);                                   // py:232
+    odom_yaw += wz * dt;                                                  // py:234
+    double so, co;
+    sincos(odom_yaw, &so, &co);
+    pos_x += vx * co * dt - vy * so * dt;                                 // py:235
+    pos_y += vx * so * dt + vy * co * dt;                                 // py:236
+    const int mx = cell_of(pos_x, map.origin_x, map.resolution, map.inv_resolution);   // py:246
+    const int my = cell_of(pos_y, map.origin_y, map.resolution, map.inv_resolution);
+    const double c = cost_of[map_raw(map, mx, my)];
+    const double costmap_cost = c * c;                                    // py:247
+    const double ddx = P[P_CARROT_X] - x, ddy = P[P_CARROT_Y] - y;
+    const double dist = sqrt(ddx * ddx + ddy * ddy);                      // py:250
+    const double eth = target_yaw - z;                                    // py:251
+    total += ((w_trans * (dist * dist)) + (w_orient * (eth * eth))) / n;  // py:252
+    const double e0 = P[P_VEL] - vx, e1 = P[P_VEL + 1] - vy, e2 = P[P_VEL + 2] - wz;
+    total += w_control * sqrt(e0 * e0 + e1 * e1 + e2 * e2) / n;           // py:253-254
+    if (c == 1.0) total += costmap_cost * 1000 / n;                       // py:257-258
+    else total += a.w_costmap * costmap_cost / n;                         // py:260
+    if (footprint == 1.0) total += (footprint * footprint) * a.p.w_footprint / n;   // py:262-263
+  }
+  const double gdx = P[P_CARROT_X] - P[P_GOAL], gdy = P[P_CARROT_Y] - P[P_GOAL + 1];
+  const double gdist = sqrt(gdx * gdx + gdy * gdy);                       // py:266
+  const double eth = final_yaw - z;                                       // py:267
+  total += ((w_trans * (gdist * gdist)) + (w_orient * (eth * eth))) * a.w_terminal;   // py:268
+  a.cost[b] = total;
 }
 
 // K3: raw nav2 costmap -> bordered, pitched device map.  One 16-byte store per lane.

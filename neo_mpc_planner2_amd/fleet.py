@@ -31,14 +31,19 @@ def closed_loop(solver, batch, ticks, hz=30.0, before_tick=None, after_tick=None
                                      1 - 2 * (cq[:, 1] ** 2 + cq[:, 2] ** 2))
     P[:, 22] = 1.0 / hz
     P[:, 23] = 1.0 / hz
+    # one event pair per tick, stamped by the dispatch of K1 itself (neo_mpc_solve_batch_device_timed): separate
+    # event records around the launch would add their own barrier packets (~20 us) to what is read as kernel time
+    stream = torch.cuda.current_stream()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(ticks)]
+    for e0, e1 in evs:
+        e0.record(stream)
+        e1.record(stream)
+    torch.cuda.synchronize()
     out = {"kernel_ms": [], "mean_iterations": [], "max_iterations": [], "stopped_fraction": []}
     for t in range(ticks):
         if before_tick is not None:
             before_tick(t, pos)
-        evs[t][0].record()
-        solver.solve_device(b.problems, b.states, b.warm, b.commands, velocities=b.vel)
-        evs[t][1].record()
+        solver.solve_device(b.problems, b.states, b.warm, b.commands, velocities=b.vel, events=evs[t])
         cmd = b.vel
         yaw = yaw + cmd[:, 2] / hz
         c, sn = torch.cos(yaw), torch.sin(yaw)

@@ -28,6 +28,7 @@ class BatchSolver:
             raise _lib.NeoMpcError(-1, (self._lib.neo_mpc_last_error() or b"").decode())
         self._handle = C.c_void_p(h)
         self._keep = None
+        self._last_call = None
 
     # -- lifecycle ------------------------------------------------------------------
     def close(self):
@@ -132,9 +133,18 @@ class BatchSolver:
         updated in place.  Returns (commands, solution[, path]).  `out` = (commands, solution) arrays to fill
         instead of fresh ones -- page-locked ones (with page-locked inputs) make every transfer of the call a DMA."""
         count = len(problems)
+        if out is not None and not want_path and footprints is None:
+            # a caller that owns its arrays (a fleet server's request arena) passes the same ones every tick: the
+            # marshalled batch of the previous call is reused as long as every array is the same object
+            key = (id(problems), id(states), id(warm), id(out[0]), id(out[1]))
+            if self._last_call is not None and self._last_call[0] == key:
+                _lib.check(self._lib.neo_mpc_solve_batch(self._handle, self._last_call[1]))
+                return out
         commands, solution = out if out is not None else (None, np.zeros((count, 3 * self.control_steps)))
         assert solution.dtype == np.float64 and solution.shape == (count, 3 * self.control_steps) and solution.flags.c_contiguous
         b, commands, path = self._host_batch(problems, states, warm, solution, want_path, footprints, commands)
+        if out is not None and not want_path and footprints is None and self._keep[0] is problems:
+            self._last_call = (key, C.byref(b), b, (problems, states, warm, out))   # (keeps the arrays and the struct alive)
         _lib.check(self._lib.neo_mpc_solve_batch(self._handle, C.byref(b)))
         return (commands, solution, path) if want_path else (commands, solution)
 
