@@ -51,6 +51,7 @@ __device__ __forceinline__ int cell_raw(const SolveArgs& a, const Ctx& c, const 
 }
 
 __device__ __forceinline__ double step_term(const SolveArgs& a, const Ctx& c, const double* L, double x, double y) {
+  if (c.tile_geom & kTileFree) return L[a.lds.term];   // free neighbourhood (load_tile): the term of a free cell, no lookup
   const double X = c.X0 + (c.c0 * x - c.s0 * y), Y = c.Y0 + (c.s0 * x + c.c0 * y);
   const int mx = cell_of(X, a.map.origin_x, a.map.resolution, a.map.inv_resolution);
   const int my = cell_of(Y, a.map.origin_y, a.map.resolution, a.map.inv_resolution);
@@ -81,15 +82,17 @@ constexpr double kHopMargin = 0.01;   // (well inside kStickyDist: a stage that 
 __device__ __forceinline__ int edge_stickiness(const SolveArgs& a, const Ctx& c, const double* L, double x, double y,
                                                double cs, double sn, double& wxx, double& wxy, double& wyy, double& lx,
                                                double& ly, bool& hop, float& hop_x, float& hop_y) {
+  wxx = 0.0; wxy = 0.0; wyy = 0.0; lx = 0.0; ly = 0.0;
+  hop = false; hop_x = 0.0f; hop_y = 0.0f;
+  if (c.tile_geom & kTileFree) return 0;   // free neighbourhood (load_tile): no cost step anywhere near
   const double X = c.X0 + (c.c0 * x - c.s0 * y), Y = c.Y0 + (c.s0 * x + c.c0 * y);
   const int mx = cell_of(X, a.map.origin_x, a.map.resolution, a.map.inv_resolution);
   const int my = cell_of(Y, a.map.origin_y, a.map.resolution, a.map.inv_resolution);
-  const double fx = (X - a.map.origin_x) / a.map.resolution - (double)mx;
-  const double fy = (Y - a.map.origin_y) / a.map.resolution - (double)my;
+  // (position inside the cell, in cells: by the reciprocal -- distances to an edge are compared with 0.01 ... 0.25)
+  const double fx = (X - a.map.origin_x) * a.map.inv_resolution - (double)mx;
+  const double fy = (Y - a.map.origin_y) * a.map.inv_resolution - (double)my;
   const int raw_here = cell_raw(a, c, L, mx, my);
   const double here = L[a.lds.term + raw_here];
-  wxx = 0.0; wxy = 0.0; wyy = 0.0; lx = 0.0; ly = 0.0;
-  hop = false; hop_x = 0.0f; hop_y = 0.0f;
   // (saturated cell indices -- positions far outside every map -- wrap in mx +- 1; such cells read lethal
   // on both sides, so no edge is sticky there)
   const bool far = mx <= -2147483647 || mx >= 2147483646 || my <= -2147483647 || my >= 2147483646;

@@ -26,10 +26,12 @@ enum : int { T_XTOL, T_EARLY, T_FINAL, T_FTOL, T_STALL, T_WTOL, T_KINK, T_KONST,
              T_HOP_DROP, T_HOP_RANGE, T_HOP_STAGE = 13 /* int32[6]: stage[4], count, - */, T_HOP_VEC = 16 /* float[8] */,
              T_BTOL_MAP = 20, T_BTOL_FREE = 21, kHopLanes = 4 };
 
+constexpr int kTileFree = 0x80;   // Ctx::tile_geom: every cell of the reach tile is free (raw cost 0)
+
 struct Ctx {
   double cx, cy, tyaw, fyaw, c0, s0, X0, Y0, v0, v1, v2, konst, true_yaw;
   int tile_x0, tile_y0;
-  int tile_geom;  // reach tile in LDS: rows << 8 | log2(row stride in bytes); 0: no tile
+  int tile_geom;  // reach tile in LDS: rows << 8 | kTileFree | log2(row stride in bytes); 0: no tile
 };
 
 }  // namespace

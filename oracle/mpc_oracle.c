@@ -632,7 +632,7 @@ static void orc_wall_model(const orc_ctx* c, double x, double y, double* W, doub
   const orc_map* m = c->map;
   int64_t mx, my;
   orc_world_to_map(m, X, Y, &mx, &my);
-  const double fx = (X - m->origin_x) / m->resolution - (double)mx, fy = (Y - m->origin_y) / m->resolution - (double)my;
+  const double fx = (X - m->origin_x) * (1.0 / m->resolution) - (double)mx, fy = (Y - m->origin_y) * (1.0 / m->resolution) - (double)my;
   const double here = orc_term_at(c, mx, my), lethal = c->term[254];
   const int64_t nbx[4] = {mx - 1, mx + 1, mx, mx}, nby[4] = {my, my, my - 1, my + 1};
   const double dist[4] = {fx, 1.0 - fx, fy, 1.0 - fy}, sign[4] = {1.0, -1.0, 1.0, -1.0};
@@ -1055,7 +1055,7 @@ static int orc_hops(const orc_ctx* c, const double* u, double min_drop, double h
     const double X = c->X0 + (c->c0 * x - c->s0 * y), Y = c->Y0 + (c->s0 * x + c->c0 * y);
     int64_t mx, my;
     orc_world_to_map(m, X, Y, &mx, &my);
-    const double fx = (X - m->origin_x) / m->resolution - (double)mx, fy = (Y - m->origin_y) / m->resolution - (double)my;
+    const double fx = (X - m->origin_x) * (1.0 / m->resolution) - (double)mx, fy = (Y - m->origin_y) * (1.0 / m->resolution) - (double)my;
     const double here = orc_term_at(c, mx, my);
     const int64_t nbx[4] = {mx - 1, mx + 1, mx, mx}, nby[4] = {my, my, my - 1, my + 1};
     const double dist[4] = {fx, 1.0 - fx, fy, 1.0 - fy}, sign[4] = {-1.0, 1.0, -1.0, 1.0};

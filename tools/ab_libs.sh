@@ -4,7 +4,7 @@
 A=$1; B=$2; R=${3:-2}
 run() {  # lib, label, bench args...
   local lib=$1 label=$2; shift 2
-  NEO_MPC_LIB=$lib timeout 300 python bench.py --no-cpu-baseline "$@" 2>/dev/null | tail -1 | \
+  NEO_MPC_LIB=$lib timeout 300 python bench.py --no-cpu-baseline --no-pcie --no-others "$@" 2>/dev/null | tail -1 | \
     python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$label %-28s %.4g solves/s kernel_ms %.4f it %.2f' % ('$(basename $lib)', d['value'], d['roofline']['kernel_ms'], d['solver']['mean_iterations']))"
 }
 for r in $(seq $R); do
