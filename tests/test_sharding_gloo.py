@@ -52,11 +52,12 @@ def _worker(rank, world, port, count, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("count", [64, 37])
-def test_sharded_solve_equals_unsharded(tmp_path, count):
+@pytest.mark.parametrize("world,count", [(2, 64), (2, 37), (4, 37), (4, 3)])
+def test_sharded_solve_equals_unsharded(tmp_path, world, count):
+    """world 4 with 37 instances: unequal shards (10, 10, 10, 7); with 3 instances one rank has nothing to solve and
+    still takes part in the all-gather."""
     import torch.multiprocessing as mp
     from oracle import c_oracle, mpc_oracle as orc
-    world = 2
     mp.spawn(_worker, args=(world, _free_port(), count, str(tmp_path)), nprocs=world, join=True)
     params = orc.make_params()
     cmap = synthetic.make_costmap(200, seed=21)
