@@ -1214,7 +1214,9 @@ void launch_solve(const SolveArgs& a, void* stream, void* ev_start, void* ev_sto
   {  // any control_steps: Newton direction by the Riccati sweep (riccati.h)
     // the 128-VGPR build (4 waves/SIMD) wherever LDS lets a CU hold more than 12 workgroups -- 13 need <= 12.3 KB
     // each -- else the 168-VGPR build (measured: control_steps 8, 16 workgroups/CU: +17 %; control_steps 32 at
-    // 11.3 KB = 14 workgroups/CU: +9 %; with 12 workgroups/CU the 4-wave build's spills make it 4 % slower)
+    // 11.3 KB = 14 workgroups/CU: +9 %; with 12 workgroups/CU the 4-wave build's spills make it 4 % slower; the general
+    // variant's 10 spilled VGPRs at 4 waves/SIMD cost nothing measurable: "turn" parameter set, 65 536 instances, same
+    // box: 34.9 M solves/s against 30.6 M at 3 waves/SIMD, tools/ab_general.py)
     const int w = solve_variant(lds <= 12600 ? 4 : 3);
     if (disc) NEO_LAUNCH_W(w, 0, 2, true);
     else NEO_LAUNCH_W(w, 0, 2);
@@ -1223,7 +1225,10 @@ void launch_solve(const SolveArgs& a, void* stream, void* ev_start, void* ev_sto
 #else
   if (a.p.newton == 2) { launch_solve_riccati(a, stream, ev_start, ev_stop); return; }
   if (a.p.n == 3 && a.p.newton == 1) {  // projected Newton, dense 9 x 9 system (its layout does not depend on lbfgs_memory)
-    const int w = solve_variant(disc ? 4 : 3);
+    // (the general variant at 4 waves/SIMD spills 7 VGPRs -- 32 bytes of scratch -- and is still the faster one: measured
+    // on the "cut" parameter set, same box, tools/ab_general.py: 0.123 ms against 0.133 ms per 4096 instances at 3
+    // waves/SIMD -- 4096 waves are one residency round at 4 --, 55.9 M against 51.3 M solves/s at 65 536)
+    const int w = solve_variant(4);
     if (disc && w == 4 && small_tile) NEO_LAUNCH_LDS(0, 4, 3, 1, true, 1024);   // (the static variant takes no dynamic LDS)
     else if (disc) NEO_LAUNCH_W(w, 3, 1, true);
     else NEO_LAUNCH_W(w, 3, 1);
