@@ -28,6 +28,14 @@ extern "C" {
 #endif
 
 #define NEO_MPC_ABI_VERSION 1
+/* Behaviour history behind one ABI version (no signature or record layout has changed):
+ *   round 1  AUTO = dense Newton up to 8 control steps, L-BFGS beyond.
+ *   round 2  AUTO = dense Newton at control_steps 3, the stage-wise (Riccati) direction everywhere else -- and at 3 when
+ *            w_costmap > w_trans / 4; stop thresholds beyond 3 control steps scaled with (3 / control_steps)^2.
+ *   round 3  hop candidates in the stage-wise direction; blocked-run stop rule in the dense direction; page-locked host
+ *            batches are worked on in place (neo_mpc_solve_batch); neo_mpc_pin_host_memory, neo_mpc_set_host_path.
+ * Iterates and iteration counts differ between rounds, results stay inside the parity protocol of DESIGN.md section 1;
+ * method = NEO_MPC_METHOD_NEWTON / _LBFGS / _RICCATI pins a direction. */
 
 /* return codes */
 #define NEO_MPC_OK 0

@@ -474,6 +474,41 @@ def test_device_resident_batch_matches_host_batch(solver_mod):
         assert (x2 == x).all()
 
 
+def test_page_locked_host_batches_are_worked_on_in_place(solver_mod):
+    """neo_mpc_solve_batch on page-locked arrays (neo_mpc_pin_host_memory: what a caller built without the HIP headers
+    uses) copies nothing -- K1 reads the records from the caller's arrays and writes the results into them over PCIe:
+    commands, raw solution, state, warm start and predicted path are bit-identical with the staged paths and with
+    pageable arrays, for the three host-path variants (neo_mpc_set_host_path) and a second, warm-started tick."""
+    import ctypes as C
+    from neo_mpc_planner2_amd import _lib
+    lib = _lib.load()
+    cfg, cmap, probs, st0, warm0 = synthetic.make_workload("C2", seed=5, batch=1000)
+    params = util.orc.make_params()
+    with _solver(solver_mod, params, cmap) as s:
+        ref_st, ref_warm = st0.copy(), warm0.copy()
+        ref = [s.solve(probs, ref_st, ref_warm, want_path=True) for _ in range(2)]       # pageable, two ticks
+        ref = [(c.copy(), x.copy(), p.copy()) for c, x, p in ref]
+        for mode in ("zerocopy", "zerocopy_out", "staged"):
+            s.set_host_path(mode)
+            arrays = [np.ascontiguousarray(probs).copy(), st0.copy(), warm0.copy(),
+                      np.zeros(len(probs), dtype=abi.COMMAND_DTYPE), np.zeros((len(probs), 9)), np.zeros((len(probs), 3, 3))]
+            for a in arrays:
+                assert lib.neo_mpc_pin_host_memory(C.c_void_p(a.ctypes.data), a.nbytes) == 0, lib.neo_mpc_last_error()
+            try:
+                p_probs, p_st, p_warm, p_cmd, p_sol, p_path = arrays
+                for tick in range(2):
+                    b = abi.batch_struct(p_probs, p_st, p_warm, p_cmd, p_sol, p_path)
+                    _lib.check(lib.neo_mpc_solve_batch(s._handle, C.byref(b)))
+                    assert p_cmd.tobytes() == ref[tick][0].tobytes(), (mode, tick)
+                    assert (p_sol == ref[tick][1]).all() and (p_path == ref[tick][2]).all(), (mode, tick)
+                assert p_st.tobytes() == ref_st.tobytes() and (p_warm == ref_warm).all(), mode
+            finally:
+                for a in arrays:
+                    assert lib.neo_mpc_unpin_host_memory(C.c_void_p(a.ctypes.data)) == 0
+        s.set_host_path("auto")
+        assert lib.neo_mpc_set_host_path(s._handle, 7) == -1 and lib.neo_mpc_pin_host_memory(None, 16) == -1
+
+
 def test_errors_are_reported_not_thrown(solver_mod):
     from neo_mpc_planner2_amd import _lib
     s = solver_mod.BatchSolver(util.orc.make_params())
