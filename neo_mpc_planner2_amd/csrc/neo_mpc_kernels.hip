@@ -1026,41 +1026,60 @@ __global__ __launch_bounds__(256) void k_objective(const ObjectiveArgs a) {
   a.cost[b] = total;
 }
 
-// K3: raw nav2 costmap -> bordered, pitched device map.  One 16-byte store per lane.
+// K3: raw nav2 costmap -> bordered, pitched device map.  One 16-byte store per lane and chunk; kIngestUnroll chunks per
+// thread with every load issued before the first store (memory-level parallelism: the kernel is a pure stream).
+constexpr int kIngestUnroll = 4;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 ingest_chunk(const IngestArgs& a, unsigned idx, unsigned chunks_per_row) {
+  const int row = (int)(idx / chunks_per_row), chunk = (int)(idx - (unsigned)row * chunks_per_row);
+  const int my = row - a.border;
+  const int mx0 = chunk * 16 - a.border;
+  u32x4 v = {0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu};
+  if (my >= 0 && my < a.size_y && mx0 >= 0 && mx0 + 16 <= a.size_x && (a.size_x & 7) == 0) {
+    // interior chunk of a map whose rows are 8-byte aligned (mx0 is a multiple of 16): two 8-byte loads
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2* src8 = reinterpret_cast<const u32x2*>(a.src + (long)my * a.size_x + mx0);
+    const u32x2 lo = __builtin_nontemporal_load(src8), hi = __builtin_nontemporal_load(src8 + 1);
+    v = u32x4{lo.x, lo.y, hi.x, hi.y};
+  } else if (my >= 0 && my < a.size_y && mx0 >= 0 && mx0 + 16 <= a.size_x && (a.size_x & 3) == 0) {
+    const uint32_t* src4 = reinterpret_cast<const uint32_t*>(a.src + (long)my * a.size_x + mx0);
+    v = u32x4{src4[0], src4[1], src4[2], src4[3]};
+  } else if (my >= 0 && my < a.size_y && mx0 >= 0 && mx0 < a.size_x && (a.size_x & 3) == 0) {
+    // the chunk that straddles the right edge of a map whose width is a multiple of 4 (200-cell windows: 8 of its 16
+    // bytes): whole dwords, lethal beyond the edge
+    const uint32_t* src4 = reinterpret_cast<const uint32_t*>(a.src + (long)my * a.size_x + mx0);
+    const int valid = (a.size_x - mx0) >> 2;   // 1..3 dwords
+    v = u32x4{src4[0], valid > 1 ? src4[1] : 0xFEFEFEFEu, valid > 2 ? src4[2] : 0xFEFEFEFEu, 0xFEFEFEFEu};
+  } else if (my >= 0 && my < a.size_y && mx0 + 16 > 0 && mx0 < a.size_x) {
+    uint8_t bytes[16];
+    const uint8_t* src = a.src + (long)my * a.size_x;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int mx = mx0 + k;
+      bytes[k] = (mx >= 0 && mx < a.size_x) ? src[mx] : (uint8_t)254;
+    }
+    v = *reinterpret_cast<const u32x4*>(bytes);
+  }
+  return v;
+}
 __global__ __launch_bounds__(256) void k_ingest(const IngestArgs args) {
   IngestArgs a = args;   // blockIdx.y: which map of a pool
   a.src += (long)blockIdx.y * a.size_x * a.size_y;
   a.dst += (long)blockIdx.y * a.dst_stride;
   const unsigned chunks_per_row = (unsigned)a.pitch >> 4;
   const unsigned total = (unsigned)a.rows * chunks_per_row;   // (< 2^31: rows, pitch <= 2^20 + 256 and pitch/16 per row)
-  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    const int row = (int)(idx / chunks_per_row), chunk = (int)(idx - (unsigned)row * chunks_per_row);
-    const int my = row - a.border;
-    const int mx0 = chunk * 16 - a.border;
-    uint4 v = make_uint4(0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu);
-    if (my >= 0 && my < a.size_y && mx0 >= 0 && mx0 + 16 <= a.size_x && (a.size_x & 7) == 0) {
-      // interior chunk of a map whose rows are 8-byte aligned (mx0 is a multiple of 16): two 8-byte loads
-      const uint2* src8 = reinterpret_cast<const uint2*>(a.src + (long)my * a.size_x + mx0);
-      const uint2 lo = src8[0], hi = src8[1];
-      v = make_uint4(lo.x, lo.y, hi.x, hi.y);
-    } else if (my >= 0 && my < a.size_y && mx0 >= 0 && mx0 + 16 <= a.size_x && (a.size_x & 3) == 0) {
-      const uint32_t* src4 = reinterpret_cast<const uint32_t*>(a.src + (long)my * a.size_x + mx0);
-      v = make_uint4(src4[0], src4[1], src4[2], src4[3]);
-    } else if (my >= 0 && my < a.size_y && mx0 + 16 > 0 && mx0 < a.size_x) {
-      uint8_t bytes[16];
-      const uint8_t* src = a.src + (long)my * a.size_x;
+  const unsigned stride = gridDim.x * blockDim.x;
+  for (unsigned base = blockIdx.x * blockDim.x + threadIdx.x; base < total; base += kIngestUnroll * stride) {
+    u32x4 v[kIngestUnroll];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int mx = mx0 + k;
-        bytes[k] = (mx >= 0 && mx < a.size_x) ? src[mx] : (uint8_t)254;
-      }
-      v = *reinterpret_cast<const uint4*>(bytes);
-    }
+    for (int k = 0; k < kIngestUnroll; ++k)
+      if (base + k * stride < total) v[k] = ingest_chunk(a, base + k * stride, chunks_per_row);
     // streamed once, read back sparsely (reach tiles): non-temporal, so the stream does not wait for
     // L2 lines to be allocated (measured: 3.0 -> 4.3 TB/s over a pool of 4096 windows)
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 out = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(out, reinterpret_cast<u32x4*>(a.dst + (long)row * a.pitch + chunk * 16));
+#pragma unroll
+    for (int k = 0; k < kIngestUnroll; ++k)
+      if (base + k * stride < total)
+        __builtin_nontemporal_store(v[k], reinterpret_cast<u32x4*>(a.dst) + (base + k * stride));
   }
 }
 
@@ -1266,7 +1285,7 @@ void launch_objective(const ObjectiveArgs& a, void* stream) {
 void launch_ingest(const IngestArgs& a, void* stream) {
   const long total = (long)a.rows * (a.pitch >> 4);
   // a few 16-byte chunks per thread: one-chunk threads make the launch dispatch-bound for pools of small maps
-  const int per_thread = getenv("NEO_MPC_INGEST_CHUNKS") ? atoi(getenv("NEO_MPC_INGEST_CHUNKS")) : 2;
+  const int per_thread = getenv("NEO_MPC_INGEST_CHUNKS") ? atoi(getenv("NEO_MPC_INGEST_CHUNKS")) : kIngestUnroll;
   int blocks = (int)((total + 256L * per_thread - 1) / (256L * per_thread));
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(k_ingest, dim3(blocks, a.maps > 0 ? a.maps : 1), dim3(256), 0, (hipStream_t)stream, a);
