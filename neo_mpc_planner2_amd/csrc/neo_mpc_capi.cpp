@@ -162,7 +162,7 @@ void derive(neo_mpc_handle* h) {
   d.hop_range = h->has_map ? fmin(0.25, 0.05 * d.dt / h->map.resolution) : 0.25;
   d.max_it = p.max_iterations > 0 ? p.max_iterations : 100;
   d.mem = p.lbfgs_memory > 0 ? p.lbfgs_memory : 4;
-  d.compat = p.compat_flags;
+  d.compat = (p.compat_flags & 0xffff) | (getenv("NEO_MPC_NO_UNSHIFT") ? kCompatNoUnshift : 0);
   d.disc_in_box = (p.min_vel_x <= -p.max_vel_trans && p.max_vel_x >= p.max_vel_trans &&
                    p.min_vel_y <= -p.max_vel_trans && p.max_vel_y >= p.max_vel_trans) ? 1 : 0;
   d.tame = (d.disc_in_box && fmax(fabs(p.min_vel_theta), fabs(p.max_vel_theta)) * p.prediction_horizon <= 0.78) ? 1 : 0;

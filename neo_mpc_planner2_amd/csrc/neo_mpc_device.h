@@ -11,6 +11,7 @@ constexpr int kLanes = 64;          // one CDNA4 wavefront per MPC instance
 constexpr int kMapBorder = 64;      // lethal border (cells) K3 adds around a single costmap
 constexpr int kPoolBorder = 16;     // ... around each map of a pool (every lookup is bounds-checked anyway)
 constexpr int kMaxTileWidth = 128;  // widest reach tile staged in LDS (bytes per row)
+constexpr int kCompatNoUnshift = 0x10000;   // DevParams.compat (internal bit): searches always start at the warm start (A/B: NEO_MPC_NO_UNSHIFT)
 constexpr int kDumpGradient = 0x40000000;  // DevParams.max_it value of the gradient test hook (neo_mpc_gradient_batch)
 
 // Constants of one solver configuration, precomputed on the host in float64 exactly as

@@ -222,6 +222,38 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   bool cold = true;  // x0 == 0 (wave-uniform: every lane scans the same LDS values)
   for (int k = 0; k < nv; ++k) cold = cold && (u[k] == 0.0);
 
+  // The warm start is the previous solution shifted by a WHOLE control step (py:198-202: block i <- block i + 1, the
+  // filtered first control last) although only one control interval -- an eighth of a step at 30 Hz and the README's
+  // horizon -- has passed: the previous solution itself, i.e. the shift undone, [w_{N-1}, w_0, ..., w_{N-2}], is usually
+  // much closer to this tick's minimiser.  In free space (no costmap term under either rollout: one basin) the search
+  // starts from whichever of the two has the lower objective (lane 0 rolls out the warm start, lane 1 the unshifted
+  // one); on the costmap it starts where the reference starts.  The warm start handed BACK is the reference's shift as
+  // ever (K2).  Closed loop of 4096 robots: 6.2 -> 4.2 iterations per warm tick.
+  if (!cold && n > 1 && !(p.compat & kCompatNoUnshift) && p.max_it < kDumpGradient) {   // (not in the test hooks: they dump AT the given point)
+    double ts = 0.0;
+    const double fs = rollout_cost<kSteps, kTame>(
+        a, c, L,
+        [&](int i, double& b0, double& b1, double& b2) {
+          const int src = lane == 1 ? (i == 0 ? n - 1 : i - 1) : i;
+          b0 = u[3 * src]; b1 = u[3 * src + 1]; b2 = u[3 * src + 2];
+        },
+        NoRecord(), &ts);
+    const double f_warm = lane_value(fs, 0), f_alt = lane_value(fs, 1);
+    const bool free_both = lane_value(ts, 0) == 0.0 && lane_value(ts, 1) == 0.0;
+    if (f_alt < f_warm && free_both) {
+      double v0 = 0.0, v1 = 0.0, v2 = 0.0;   // (nv <= 192: up to three elements per lane)
+      const int k0 = lane, k1 = lane + kLanes, k2 = lane + 2 * kLanes;
+      if (k0 < nv) v0 = u[k0 >= 3 ? k0 - 3 : k0 + nv - 3];
+      if (k1 < nv) v1 = u[k1 - 3];
+      if (k2 < nv) v2 = u[k2 - 3];
+      WAVE_SYNC();
+      if (k0 < nv) u[k0] = v0;
+      if (k1 < nv) u[k1] = v1;
+      if (k2 < nv) u[k2] = v2;
+    }
+    WAVE_SYNC();
+  }
+
   for (int i = lane; i < n; i += kLanes) { AMODE[4 * i + 2] = 0; AMODE[4 * i + 3] = 0; }
   // Long horizons (Riccati direction): the curvature of a block falls with 1/N^2, so the proximal step starts
   // longer; and the Newton step is long along the valleys in which neighbouring blocks trade displacement and
