@@ -674,6 +674,31 @@ def test_plugin_seam_ticks_replayed_through_the_oracle(tmp_path):
     print("seam vs oracle over %d ticks: max |d command| %.2e, %d stopped ticks" % (len(ticks), worst, stopped.sum()))
 
 
+def test_closed_loop_warm_ticks_have_no_creeping_tail(solver_mod):
+    """The deployed mode: 4096 robots in a closed 30 Hz loop on the device (neo_mpc_planner2_amd/fleet.py), every tick
+    warm-started the reference's way (py:397-400).  A launch lasts as long as its slowest wave: every search converges
+    (status 0 -- no tick runs into the iteration cap), the per-tick maximum stays at 15 iterations in the median (it was
+    25, and 100 at worst, before the blocked-run rule), the mean below a cold tick's -- and the same loop on the CPU
+    mirror takes the same number of iterations."""
+    import torch
+    from neo_mpc_planner2_amd import fleet
+    cfg, cmap, probs, st, warm = synthetic.make_workload("C2", seed=0)
+    params = util.orc.make_params()
+    status = []
+    with _solver(solver_mod, params, cmap) as s:
+        b = solver_mod.DeviceBatch(probs, st, warm, "cuda:0", want_solution=False)
+        loop = fleet.closed_loop(s, b, 30, after_tick=lambda t, cm: status.append(int((cm["status"] != 0).sum())))
+        torch.cuda.synchronize()
+    summary = fleet.summary(loop)
+    assert sum(status) == 0
+    assert summary["max_iterations_median"] <= 15 and summary["max_iterations_max"] <= 20, summary
+    assert summary["mean_iterations"] <= summary["cold_tick_mean_iterations"], summary
+    mirror = util.closed_loop_on_the_mirror(params, cmap, probs, 12)
+    for t in range(12):
+        assert abs(mirror[t]["iterations"].mean() - loop["mean_iterations"][t]) <= 0.05, t
+    print(summary)
+
+
 def test_bench_emits_the_contract_line():
     """`python bench.py --gpus 1 --steps K --warmup W` prints ONE JSON line, last on stdout, with the
     driver's keys, BASELINE.json's metric, the roofline object of the dominant kernel and (without
@@ -701,6 +726,14 @@ def test_bench_emits_the_contract_line():
     # the PCIe-inclusive leg (host-buffer entry point, same instances) rides in the same line, never as `value`
     pc = rec["pcie_inclusive"]
     assert pc["unit"] == "solves/s" and 1e5 < pc["value"] < rec["value"]
+    # page-locked arrays are worked on in place: faster than staging the same arrays, bit-identical commands
+    assert pc["pinned"]["commands_identical"] and pc["pinned_staged"]["commands_identical"]
+    assert pc["pinned"]["value"] > pc["pinned_staged"]["value"] > 0.8 * pc["value"]
+    # the other BASELINE configs and the deployed mode ride in the default line
+    names = [o["workload"] for o in rec["other_workloads"]]
+    assert names[:3] == ["C3", "C5", "C4 per-GPU shard"] and all("error" not in o for o in rec["other_workloads"])
+    assert all(o["solver"]["status_max_iter"] == 0 and o["value"] > 1e6 for o in rec["other_workloads"])
+    assert rec["warm_tick"]["ticks"] >= 50 and rec["warm_tick"]["max_iterations_max"] < 100
     # HBM traffic from the PMC passes is reported only for the build it was measured on
     assert r["traffic"] is not None or any(w in r["traffic_note"] for w in ("stale", "no PMC", "batch"))
 

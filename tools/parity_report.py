@@ -99,7 +99,7 @@ def other_parameter_sets():
 
 def warm_starts():
     print("\n# warm starts: every call of the reference's recorded episodes (G4) solved from the reference's own state")
-    for fixture in ("g4_episodes.npz", "g4_episodes_n8.npz", "g4_episodes_params.npz"):
+    for fixture in util.EPISODE_FIXTURES:
         g = util.load(fixture)
         params = util.params_from(g["param_keys"], g["params"])
         n = params["control_steps"]
@@ -124,7 +124,7 @@ def warm_starts():
                 its.append(cmds["iterations"])
                 s.postprocess(rows, states, warm, g["raw_x"][:, k], g["success"][:, k])
         df, dcmd, its = np.array(df), np.array(dcmd), np.array(its)
-        print("\n## control_steps %d: %d calls" % (n, df.size))
+        print("\n## %s, control_steps %d: %d calls" % (fixture, n, df.size))
         print("P3  f(build) - f(reference raw x.x)      : max %.3e  median %.3e  (bar: <= 1e-3)" % (df.max(), np.median(df)))
         print("P4  |command - reference command|_inf    : %s   (calls not stopped by the collision latch)" % pct(dcmd.ravel()))
         print("    iterations: mean %.1f max %d" % (its.mean(), its.max()))
@@ -154,8 +154,101 @@ def flat_problem_drift():
                                          c0["iterations"].mean(), c1["iterations"].mean()))
 
 
+def node_defaults():
+    """G9: the node's own declared defaults (py:49-75, opt_tolerance 1e-5): P2 / P3 and the literal command gates."""
+    print("\n# G9: the node's declared defaults (opt_tolerance 1e-5, every weight 0.5, w_footprint 2000, limits 0.5, horizon 0.5)")
+    for fixture, prefix in util.G9_GROUPS:
+        g, params, probs, hm = util.solve_group(fixture, prefix)
+        n = params["control_steps"]
+        for name, mask, cells in (("zero costmap", ~hm, np.zeros_like(g["cells"])), ("costmap", hm, g["cells"])):
+            cmap = (cells,) + tuple(g["map_meta"])
+            pr = probs[mask]
+            st, warm = synthetic.make_states(pr, n)
+            with BatchSolver(params) as s:
+                s.set_costmap(*cmap)
+                cmds, x = s.solve(pr, st, warm)
+            ok = g["status_tight"][mask] == 0
+            du = np.abs(x[:, :3] - g["x_tight"][mask][:, :3]).max(axis=1)
+            worse = cmds["cost"] - g["f_loose"][mask]
+            v_b, v_l, v_t = (command_of(params, cmap, pr, x), command_of(params, cmap, pr, g["x_loose"][mask]),
+                             command_of(params, cmap, pr, g["x_tight"][mask]))
+            d_bt, d_bl, d_lt = (np.abs(v_b - v_t).max(axis=1), np.abs(v_b - v_l).max(axis=1), np.abs(v_l - v_t).max(axis=1))
+            print("\n## control_steps %d, %s, %d cases (SLSQP 1e-12 status 0 on %d); SLSQP as shipped (ftol 1e-5): %.1f iterations"
+                  % (n, name, mask.sum(), ok.sum(), g["nit_loose"][mask].mean()))
+            print("P2  |u0 - u0(SLSQP 1e-12)|_inf           : %s" % pct(du))
+            print("P3  f - f(SLSQP as shipped, 1e-5)         : max %.3e  above 1e-3: %d   f - f(SLSQP 1e-12): max %.3e"
+                  % (worse.max(), (worse > 1e-3).sum(), (cmds["cost"] - g["f_tight"][mask]).max()))
+            print("L1  |command - command(SLSQP 1e-12)|      : %s" % pct(d_bt))
+            print("L2  |command - command(SLSQP as shipped)| : %s ; within 1e-3: %d of %d" % (pct(d_bl), (d_bl <= 1e-3).sum(), len(d_bl)))
+            print("    the reference as shipped vs its own converged answer: %s ; within 1e-3: %d of %d ; max(L2 - this) %.2e"
+                  % (pct(d_lt), (d_lt <= 1e-3).sum(), len(d_lt), (d_bl - d_lt).max()))
+            settled = d_lt <= 1e-4
+            print("L3  where the reference as shipped is settled to 1e-4 (%d cases): max |command difference| %.2e; iterations %.1f"
+                  % (settled.sum(), d_bl[settled].max() if settled.any() else float("nan"), cmds["iterations"].mean()))
+
+
+def costmap_weight_sweep():
+    print("\n# G8 mid: README parameters, w_costmap / w_trans = 0.10 ... 0.30, every case on the costmap (32 each)")
+    for fixture, prefix in util.G8_MID_GROUPS:
+        g, params, probs, hm = util.solve_group(fixture, prefix)
+        cmap = (g["cells"],) + tuple(g["map_meta"])
+        for method, tag in ((2, "dense Newton"), (3, "stage-wise")):
+            st, warm = synthetic.make_states(probs, 3)
+            with BatchSolver(dict(params, method=method)) as s:
+                s.set_costmap(*cmap)
+                cmds, x = s.solve(probs, st, warm)
+            worse = cmds["cost"] - g["f_loose"]
+            print("ratio %.2f %-12s: P3 f - f(SLSQP 1e-3): max %.3e above 1e-3: %d of %d | f - f(SLSQP 1e-12): max %.2e median %.1e | iterations %.1f"
+                  % (int(prefix[1:3]) / 100.0, tag, worse.max(), (worse > 1e-3).sum(), len(worse),
+                     (cmds["cost"] - g["f_tight"]).max(), np.median(cmds["cost"] - g["f_tight"]), cmds["iterations"].mean()))
+
+
+def long_horizon_unique_minimisers():
+    g, params, probs, _ = util.solve_group("g3_solves_n32_zero.npz", "")
+    zero = (np.zeros((200, 200), np.uint8),) + tuple(g["map_meta"])
+    st, warm = synthetic.make_states(probs, 32)
+    with BatchSolver(params) as s:
+        s.set_costmap(*zero)
+        cmds, x = s.solve(probs, st, warm)
+    ok = g["status_tight"] == 0
+    du = np.abs(x[:, :3] - g["x_tight"][:, :3]).max(axis=1)
+    print("\n# G3 n32: 64 all-free-map problems at control_steps 32, SLSQP maxiter raised to 8000 (status 0 on %d; its iterations: "
+          "median %d max %d)" % (ok.sum(), np.median(g["nit_tight"]), g["nit_tight"].max()))
+    print("P2  |u0 - u0(SLSQP 1e-12)|_inf on the %d    : %s" % (ok.sum(), pct(du[ok])))
+    print("P3  f - f(SLSQP 1e-3): max %.3e ; f - f(SLSQP 1e-12): max %.3e ; iterations %.1f max %d"
+          % ((cmds["cost"] - g["f_loose"]).max(), (cmds["cost"] - g["f_tight"]).max(), cmds["iterations"].mean(), cmds["iterations"].max()))
+
+
+def warm_drift():
+    """Warm-started searches on an all-free map against the same kernel run to the end from the same state: 4096 robots
+    after 12 closed-loop ticks (pose fixed, velocity = the previous command)."""
+    print("\n# warm starts on an all-free map vs the same kernel run to the end (4096 robots after 12 ticks)")
+    cmap = synthetic.make_costmap(500, seed=0)
+    zero = (np.zeros_like(cmap[0]),) + cmap[1:]
+    p = synthetic.make_problems(4096, 500, seed=77)
+    st, warm = synthetic.make_states(p, 3)
+    params = util.orc.make_params()
+    with BatchSolver(params) as s:
+        s.set_costmap(*zero)
+        for _ in range(12):
+            cm, _ = s.solve(p, st, warm)
+            p["cur_vel"] = cm["vel"]
+        c1, x1 = s.solve(p, st.copy(), warm.copy())
+    with BatchSolver(dict(params, window_tolerance=-1.0, step_tolerance=1e-9, cost_tolerance=1e-12, max_iterations=400)) as s:
+        s.set_costmap(*zero)
+        c2, x2 = s.solve(p, st.copy(), warm.copy())
+    du, dv, df = np.abs(x1[:, :3] - x2[:, :3]).max(axis=1), np.abs(c1["vel"] - c2["vel"]).max(axis=1), c1["cost"] - c2["cost"]
+    print("|u0 - u0(run to the end)|: %s ; above 1e-3: %d of 4096" % (pct(du), (du > 1e-3).sum()))
+    print("|command difference|     : %s ; above 1e-3: %d" % (pct(dv), (dv > 1e-3).sum()))
+    print("f - f(run to the end)    : max %.2e median %.1e ; iterations %.1f vs %.1f" % (df.max(), np.median(df), c1["iterations"].mean(), c2["iterations"].mean()))
+
+
 if __name__ == "__main__":
     cold_starts()
+    long_horizon_unique_minimisers()
     other_parameter_sets()
+    costmap_weight_sweep()
+    node_defaults()
     warm_starts()
     flat_problem_drift()
+    warm_drift()
