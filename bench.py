@@ -229,16 +229,25 @@ def pmc_entry(workload, batch):
         return None, None, "stale: PMC passes ran on source_sha %s, this build is %s" % (entry.get("source_sha"), source_sha())
     if entry.get("batch") != batch:
         return None, None, "PMC passes ran at batch %s" % entry.get("batch")
-    return entry.get("hbm_bytes"), entry.get("valu_insts"), entry.get("note")
+    valu = entry.get("valu_insts")
+    if valu and entry.get("valu_f32_fma_add_mul") is not None:
+        valu = (valu, entry["valu_f32_fma_add_mul"])   # (all vector instructions, the plain float32 fma/add/mul among them)
+    return entry.get("hbm_bytes"), valu, entry.get("note")
 
 
 def valu_issue(valu, k_ms):
-    """what actually bounds K1: VALU issue.  SQ_INSTS_VALU of the committed PMC pass x 4 cycles
-    (a wave64 instruction on a 16-lane SIMD) over 1024 SIMDs x this run's kernel time"""
+    """what actually bounds K1: VALU issue.  SQ_INSTS_VALU of the committed PMC pass priced in
+    issue cycles -- 4 per wave64 instruction, 2 for plain float32 fma / add / mul (measured: tools/mb_valu_rates.hip;
+    their count comes from the type-mix PMC pass) -- over 1024 SIMDs x this run's kernel time at the nominal clock.
+    `frac_at_4_cycles` prices every instruction at 4 cycles (the figure of rounds 1-2)."""
     if not valu:
         return None
-    return {"insts_per_launch": valu, "cycles_per_inst": 4, "simds": 1024, "clock_ghz": SIMD_CLOCK_GHZ,
-            "frac": valu * 4 / (1024 * k_ms * 1e-3 * SIMD_CLOCK_GHZ * 1e9)}
+    total, fast = valu if isinstance(valu, tuple) else (valu, None)
+    simd_cycles = 1024 * k_ms * 1e-3 * SIMD_CLOCK_GHZ * 1e9
+    out = {"insts_per_launch": total, "f32_fma_add_mul_per_launch": fast, "simds": 1024, "clock_ghz": SIMD_CLOCK_GHZ,
+           "frac_at_4_cycles": total * 4 / simd_cycles}
+    out["frac"] = (total * 4 - (fast or 0) * 2) / simd_cycles
+    return out
 
 
 def other_workload(name, dev, local_rank, steps=3, warmup=1, params_over=None, label=None):

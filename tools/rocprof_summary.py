@@ -57,8 +57,13 @@ def traffic(directory, workload, match="k_solve"):
         for k, v in agg.items():
             vals[k] = sum(v) / len(v)
     waves = int(vals.get("SQ_WAVES", 0))
+    # plain float32 fma / add / mul issue at twice the rate of everything else on gfx950 (tools/mb_valu_rates.hip):
+    # their count, when the type-mix pass ran, lets bench.py price the instruction stream in cycles
+    fast = [vals.get("SQ_INSTS_VALU_%s_F32" % k) for k in ("FMA", "ADD", "MUL")]
+    mix = {k: vals[k] for k in sorted(vals) if k.startswith("SQ_INSTS_VALU_")}
     print(json.dumps({workload: {
         "hbm_bytes": (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024, "valu_insts": vals.get("SQ_INSTS_VALU"),
+        "valu_f32_fma_add_mul": sum(fast) if all(v is not None for v in fast) else None, "valu_mix": mix or None,
         "batch": waves, "source_sha": bench.source_sha(),
         "note": "(FETCH_SIZE %.1f KB + WRITE_SIZE %.1f KB) * 1024 per %s launch (%d instances), rocprofv3 --pmc in "
                 "separate passes (tools/profile_all.sh), raw counters" % (vals["FETCH_SIZE"], vals["WRITE_SIZE"], name, waves)}}))
