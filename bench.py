@@ -120,6 +120,34 @@ def pcie_inclusive(solver, probs, st, warm, n, seconds=3.0):
             else:
                 res["pinned_" + mode] = rec
         solver.set_host_path("auto")
+        # Two batches in flight (neo_mpc_solve_batch_begin / _wait = the reference's async_send_request / result.get(),
+        # cpp:248-250): the same instances as two page-locked copies, A and B; while one is on the GPU the host resets and
+        # resubmits the other.  Host clock around the whole loop, the resets of the cold-start state inside it.
+        q_probs, q_st, q_warm = pinned(np.ascontiguousarray(probs)), pinned(st), pinned(warm)
+        q_cmd, q_sol = pinned(np.zeros(count, dtype=abi.COMMAND_DTYPE)), pinned(np.zeros((count, 3 * n)))
+        sets = [(p_probs, p_st, p_warm, p_cmd, p_sol), (q_probs, q_st, q_warm, q_cmd, q_sol)]
+        tickets = [None, None]
+        for k, a in enumerate(sets):
+            a[1][...] = st
+            a[2][...] = warm
+            tickets[k] = solver.solve_begin(a[0], a[1], a[2], out=(a[3], a[4]))
+        calls, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds / 2 and calls < 400:
+            k = calls & 1
+            solver.solve_wait(tickets[k])
+            a = sets[k]
+            a[1][...] = st
+            a[2][...] = warm
+            tickets[k] = solver.solve_begin(a[0], a[1], a[2], out=(a[3], a[4]))
+            calls += 1
+        for t in tickets:
+            solver.solve_wait(t)
+        t_all = time.perf_counter() - t0
+        res["pinned_two_in_flight"] = {
+            "value": count * (calls + 2) / t_all, "unit": "solves/s", "ms_per_call": 1e3 * t_all / (calls + 2), "calls": calls + 2,
+            "commands_identical": bool((p_cmd["vel"] == ref_cmd).all() and (q_cmd["vel"] == ref_cmd).all()),
+            "what": "neo_mpc_solve_batch_begin / _wait, two page-locked batches of the same instances alternating: one on the "
+                    "GPU (worked on in place) while the host resets and resubmits the other; resets inside the timed loop"}
     except Exception as e:   # (the pageable figure stands on its own)
         res["pinned"] = {"error": str(e)}
     return res

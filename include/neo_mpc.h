@@ -33,7 +33,8 @@ extern "C" {
  *   round 2  AUTO = dense Newton at control_steps 3, the stage-wise (Riccati) direction everywhere else -- and at 3 when
  *            w_costmap > w_trans / 4; stop thresholds beyond 3 control steps scaled with (3 / control_steps)^2.
  *   round 3  hop candidates in the stage-wise direction; blocked-run stop rule in the dense direction; page-locked host
- *            batches are worked on in place (neo_mpc_solve_batch); neo_mpc_pin_host_memory, neo_mpc_set_host_path.
+ *            batches are worked on in place (neo_mpc_solve_batch); neo_mpc_pin_host_memory, neo_mpc_set_host_path;
+ *            neo_mpc_solve_batch_begin / _wait (new entry points, nothing else changed).
  * Iterates and iteration counts differ between rounds, results stay inside the parity protocol of DESIGN.md section 1;
  * method = NEO_MPC_METHOD_NEWTON / _LBFGS / _RICCATI pins a direction. */
 
@@ -263,6 +264,16 @@ int neo_mpc_set_costmap_pool_device(neo_mpc_handle* handle, const uint8_t* d_cel
  * pin_memory) nothing is copied: the kernel reads the records from the caller's arrays and writes the results into
  * them over PCIe while other instances compute -- one launch and one wait per call. */
 int neo_mpc_solve_batch(neo_mpc_handle* handle, const neo_mpc_batch* batch);
+/* The same call in its two halves -- `client->async_send_request(request)` and `result.get()` (cpp:248-250) -- for
+ * callers that keep more than one batch moving (a server of several fleets; double-buffered ticks): `begin` enqueues
+ * the batch on a stream of its own and returns a ticket, `wait` blocks until that batch's results are in its arrays.
+ * Every array of the batch must be page-locked (it is worked on in place, see above; NEO_MPC_ERR_UNSUPPORTED
+ * otherwise) and must not be touched between the two calls.  Up to NEO_MPC_MAX_BATCHES_IN_FLIGHT tickets at a time;
+ * ticket 0 (an empty batch) needs no wait.  neo_mpc_set_costmap between begin and wait is ordered behind the batches in
+ * flight.  Not thread-safe per handle, like every other call. */
+#define NEO_MPC_MAX_BATCHES_IN_FLIGHT 4
+int neo_mpc_solve_batch_begin(neo_mpc_handle* handle, const neo_mpc_batch* batch, uint32_t* ticket);
+int neo_mpc_solve_batch_wait(neo_mpc_handle* handle, uint32_t ticket);
 /* Page-locks `bytes` of host memory at `ptr` for the device (hipHostRegister) / releases it: lets a caller built
  * without HIP headers -- the nav2 plugin is plain g++ -- keep its request arena where neo_mpc_solve_batch can work on
  * it in place.  The caller unpins before it frees the memory. */

@@ -19,7 +19,7 @@ EXPORTS = (
     "neo_mpc_abi_version", "neo_mpc_last_error", "neo_mpc_default_params", "neo_mpc_create",
     "neo_mpc_destroy", "neo_mpc_set_params", "neo_mpc_get_params", "neo_mpc_set_costmap",
     "neo_mpc_set_costmap_device", "neo_mpc_set_costmap_pool", "neo_mpc_set_costmap_pool_device", "neo_mpc_solve_batch", "neo_mpc_solve_batch_device",
-    "neo_mpc_solve_batch_device_timed",
+    "neo_mpc_solve_batch_device_timed", "neo_mpc_solve_batch_begin", "neo_mpc_solve_batch_wait",
     "neo_mpc_postprocess_batch", "neo_mpc_objective_batch", "neo_mpc_gradient_batch", "neo_mpc_direction_batch",
     "neo_mpc_kernel_info", "neo_mpc_pin_host_memory", "neo_mpc_unpin_host_memory", "neo_mpc_set_host_path",
     "neo_mpc_select_carrots", "neo_mpc_select_carrots_device",
@@ -81,6 +81,8 @@ def load():
     lib.neo_mpc_select_carrots.argtypes = [C.c_void_p, P(abi.NeoMpcLookaheadParams), P(abi.NeoMpcPlanBatch)]
     lib.neo_mpc_select_carrots_device.argtypes = [C.c_void_p, P(abi.NeoMpcLookaheadParams),
                                                   P(abi.NeoMpcPlanBatch), C.c_void_p]
+    lib.neo_mpc_solve_batch_begin.argtypes = [C.c_void_p, P(abi.NeoMpcBatch), P(C.c_uint32)]
+    lib.neo_mpc_solve_batch_wait.argtypes = [C.c_void_p, C.c_uint32]
     lib.neo_mpc_pin_host_memory.argtypes = [C.c_void_p, C.c_size_t]
     lib.neo_mpc_unpin_host_memory.argtypes = [C.c_void_p]
     lib.neo_mpc_set_host_path.argtypes = [C.c_void_p, C.c_int]

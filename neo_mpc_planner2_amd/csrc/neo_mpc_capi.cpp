@@ -98,6 +98,9 @@ struct neo_mpc_handle {
   struct MapUser { hipStream_t stream; hipEvent_t done; bool pending; };
   std::vector<MapUser> map_users;
   int host_path = NEO_MPC_HOST_PATH_AUTO;   // neo_mpc_set_host_path
+  // neo_mpc_solve_batch_begin / _wait: page-locked batches in flight, each on a stream of its own
+  struct InFlight { hipStream_t stream = nullptr; hipEvent_t done = nullptr; bool busy = false; };
+  InFlight in_flight[NEO_MPC_MAX_BATCHES_IN_FLIGHT];
 };
 constexpr size_t kMaxMapUsers = 64;   // distinct streams with a launch in flight between two ingests
 constexpr size_t kLatencyPathMaxCount = 64;
@@ -466,6 +469,11 @@ void neo_mpc_destroy(neo_mpc_handle* h) {
   if (h->pin) (void)hipHostFree(h->pin);
   if (h->map_ready) (void)hipEventDestroy(h->map_ready);
   for (auto& u : h->map_users) (void)hipEventDestroy(u.done);
+  for (auto& f : h->in_flight) {
+    if (f.busy) (void)hipEventSynchronize(f.done);
+    if (f.done) (void)hipEventDestroy(f.done);
+    if (f.stream) (void)hipStreamDestroy(f.stream);
+  }
   delete h;
 }
 
@@ -643,6 +651,18 @@ static int solve_batch_zero_copy(neo_mpc_handle* h, const neo_mpc_batch* b, cons
   return NEO_MPC_OK;
 }
 
+// Is every array of the host batch page-locked?  -> `dv`: the batch with the device-side addresses of the arrays.
+static bool batch_page_locked(const neo_mpc_batch* batch, neo_mpc_batch& dv) {
+  dv = *batch;
+  bool all = pinned_host(batch->problems, (void**)&dv.problems) && pinned_host(batch->states, (void**)&dv.states) &&
+             pinned_host(batch->warm_start, (void**)&dv.warm_start) && pinned_host(batch->commands, (void**)&dv.commands);
+  if (all && batch->solution) all = pinned_host(batch->solution, (void**)&dv.solution);
+  if (all && batch->predicted_path) all = pinned_host(batch->predicted_path, (void**)&dv.predicted_path);
+  if (all && batch->velocities) all = pinned_host(batch->velocities, (void**)&dv.velocities);
+  if (all && batch->footprints && batch->footprint_points) all = pinned_host(batch->footprints, (void**)&dv.footprints);
+  return all;
+}
+
 int neo_mpc_solve_batch(neo_mpc_handle* h, const neo_mpc_batch* batch) {
   SolveArgs a;
   int rc = fill_args(h, batch, a);  // validates
@@ -653,14 +673,8 @@ int neo_mpc_solve_batch(neo_mpc_handle* h, const neo_mpc_batch* batch) {
     return solve_batch_latency_path(h, batch);
   if (host_path_mode(h) != kStaged) {
     // page-locked arrays throughout (a fleet server's request arena): K1 works on them in place
-    neo_mpc_batch dv = *batch;
-    bool all = pinned_host(batch->problems, (void**)&dv.problems) && pinned_host(batch->states, (void**)&dv.states) &&
-               pinned_host(batch->warm_start, (void**)&dv.warm_start) && pinned_host(batch->commands, (void**)&dv.commands);
-    if (all && batch->solution) all = pinned_host(batch->solution, (void**)&dv.solution);
-    if (all && batch->predicted_path) all = pinned_host(batch->predicted_path, (void**)&dv.predicted_path);
-    if (all && batch->velocities) all = pinned_host(batch->velocities, (void**)&dv.velocities);
-    if (all && batch->footprints && batch->footprint_points) all = pinned_host(batch->footprints, (void**)&dv.footprints);
-    if (all) return solve_batch_zero_copy(h, batch, dv, host_path_mode(h));
+    neo_mpc_batch dv;
+    if (batch_page_locked(batch, dv)) return solve_batch_zero_copy(h, batch, dv, host_path_mode(h));
   }
   neo_mpc_batch d;
   // (the staging copies are asynchronous: no way out of here while one may still be reading the caller's buffers)
@@ -672,6 +686,53 @@ int neo_mpc_solve_batch(neo_mpc_handle* h, const neo_mpc_batch* batch) {
   if (hipGetLastError() != hipSuccess) return bail(fail(NEO_MPC_ERR_DEVICE, "kernel launch failed"));
   if ((rc = map_release(h, nullptr))) return bail(rc);
   return bail(stage_out(h, batch, true));   // (queued behind the kernel on the null stream, one wait at the end)
+}
+
+// The two halves of the reference's `async_send_request(request)` ... `result.get()` (cpp:248-250) for a batch: begin
+// enqueues K1 on a stream of its own -- the batch's arrays are page-locked and worked on in place, as in
+// neo_mpc_solve_batch -- and returns; wait blocks until that batch's results are in the caller's arrays.  With two
+// batches in flight the launch latency, the wait for the records over PCIe and the host's own work between calls
+// hide under the other batch's kernel.
+int neo_mpc_solve_batch_begin(neo_mpc_handle* h, const neo_mpc_batch* batch, uint32_t* ticket) {
+  if (!ticket) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "null ticket");
+  *ticket = 0;
+  SolveArgs a;
+  int rc = fill_args(h, batch, a);  // validates
+  if (rc) return rc;
+  if (batch->count == 0) return NEO_MPC_OK;   // (ticket 0: nothing to wait for)
+  HIP_TRY(hipSetDevice(h->device));
+  neo_mpc_batch dv;
+  if (!batch_page_locked(batch, dv))
+    return fail(NEO_MPC_ERR_UNSUPPORTED, "neo_mpc_solve_batch_begin works on page-locked arrays in place: pin the batch's "
+                "arrays (neo_mpc_pin_host_memory) or call neo_mpc_solve_batch");
+  neo_mpc_handle::InFlight* slot = nullptr;
+  uint32_t index = 0;
+  for (uint32_t k = 0; k < NEO_MPC_MAX_BATCHES_IN_FLIGHT; ++k)
+    if (!h->in_flight[k].busy) { slot = &h->in_flight[k]; index = k; break; }
+  if (!slot) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "%d batches in flight already: wait for one", NEO_MPC_MAX_BATCHES_IN_FLIGHT);
+  if (!slot->stream) HIP_TRY(hipStreamCreateWithFlags(&slot->stream, hipStreamNonBlocking));
+  if (!slot->done) HIP_TRY(hipEventCreateWithFlags(&slot->done, hipEventDisableTiming));
+  if ((rc = fill_args(h, &dv, a))) return rc;
+  a.states_out = dv.states; a.warm_out = dv.warm_start;
+  if ((rc = map_acquire(h, slot->stream))) return rc;
+  launch_solve(a, slot->stream);
+  HIP_TRY(hipGetLastError());
+  if ((rc = map_release(h, slot->stream))) { (void)hipStreamSynchronize(slot->stream); return rc; }
+  HIP_TRY(hipEventRecord(slot->done, slot->stream));
+  slot->busy = true;
+  *ticket = index + 1;
+  return NEO_MPC_OK;
+}
+
+int neo_mpc_solve_batch_wait(neo_mpc_handle* h, uint32_t ticket) {
+  if (!h) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "null handle");
+  if (ticket == 0) return NEO_MPC_OK;
+  if (ticket > NEO_MPC_MAX_BATCHES_IN_FLIGHT || !h->in_flight[ticket - 1].busy)
+    return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "ticket %u names no batch in flight", ticket);
+  neo_mpc_handle::InFlight& f = h->in_flight[ticket - 1];
+  f.busy = false;
+  HIP_TRY(hipEventSynchronize(f.done));   // kernel end = system-scope release: the results are in the caller's arrays
+  return NEO_MPC_OK;
 }
 
 int neo_mpc_set_host_path(neo_mpc_handle* h, int mode) {

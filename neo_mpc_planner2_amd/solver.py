@@ -29,6 +29,7 @@ class BatchSolver:
         self._handle = C.c_void_p(h)
         self._keep = None
         self._last_call = None
+        self._in_flight = {}    # ticket -> (batch struct, arrays): kept alive until solve_wait
 
     # -- lifecycle ------------------------------------------------------------------
     def close(self):
@@ -147,6 +148,23 @@ class BatchSolver:
             self._last_call = (key, C.byref(b), b, (problems, states, warm, out))   # (keeps the arrays and the struct alive)
         _lib.check(self._lib.neo_mpc_solve_batch(self._handle, C.byref(b)))
         return (commands, solution, path) if want_path else (commands, solution)
+
+    def solve_begin(self, problems, states, warm, out):
+        """First half of `solve` for page-locked arrays (`client->async_send_request(request)`, cpp:248): enqueues the
+        batch -- it is worked on in place -- and returns a ticket for `solve_wait`.  `out` = (commands, solution).  The
+        arrays must stay untouched (and alive) until the wait; up to four batches may be in flight."""
+        assert problems.dtype == abi.PROBLEM_DTYPE and problems.flags.c_contiguous
+        b, _, _ = self._host_batch(problems, states, warm, out[1], False, None, out[0])
+        ticket = C.c_uint32(0)
+        _lib.check(self._lib.neo_mpc_solve_batch_begin(self._handle, C.byref(b), C.byref(ticket)))
+        self._in_flight[ticket.value] = (b, problems, states, warm, out)
+        return ticket.value
+
+    def solve_wait(self, ticket):
+        """Second half (`result.get()`, cpp:250): blocks until the batch of `ticket` is done; its results are then in the
+        arrays handed to `solve_begin`, which are returned."""
+        _lib.check(self._lib.neo_mpc_solve_batch_wait(self._handle, C.c_uint32(ticket)))
+        return self._in_flight.pop(ticket)[4]
 
     def postprocess(self, problems, states, warm, solution, success=None, want_path=False, footprints=None):
         """Everything of `optimizer()` after the solve (py:365-403) with `solution` = x.x."""

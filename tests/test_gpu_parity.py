@@ -509,6 +509,68 @@ def test_page_locked_host_batches_are_worked_on_in_place(solver_mod):
         assert lib.neo_mpc_set_host_path(s._handle, 7) == -1 and lib.neo_mpc_pin_host_memory(None, 16) == -1
 
 
+def test_batches_in_flight_begin_and_wait(solver_mod):
+    """neo_mpc_solve_batch_begin / _wait, the two halves of `async_send_request(request)` ... `result.get()`
+    (cpp:248-250): four page-locked batches in flight at once end with exactly the commands, raw solutions, states and
+    warm starts of four synchronous calls -- over two ticks, with the costmap replaced between the ticks while nothing
+    has been waited for yet (the ingest is ordered behind the batches in flight); pageable arrays, a fifth batch and a
+    stale ticket are refused."""
+    import ctypes as C
+    from neo_mpc_planner2_amd import _lib
+    lib = _lib.load()
+    params = util.orc.make_params()
+    cmap = synthetic.make_costmap(500, seed=0)
+    cmap2 = synthetic.make_costmap(500, seed=3)
+    fleets = []
+    for k in range(4):
+        probs = np.ascontiguousarray(synthetic.make_problems(700 + 100 * k, 500, seed=40 + k))
+        st, warm = synthetic.make_states(probs, 3)
+        fleets.append((probs, st, warm))
+    with _solver(solver_mod, params, cmap) as s:
+        ref = []
+        for probs, st, warm in fleets:                      # the synchronous calls, pageable arrays
+            r_st, r_warm = st.copy(), warm.copy()
+            c1, x1 = s.solve(probs, r_st, r_warm)
+            ref.append([(c1.copy(), x1.copy())])
+            ref[-1].append((r_st, r_warm))
+        s.set_costmap(*cmap2)
+        for (probs, st, warm), r in zip(fleets, ref):
+            c2, x2 = s.solve(probs, r[1][0], r[1][1])
+            r.append((c2.copy(), x2.copy()))
+        s.set_costmap(*cmap)
+        pinned = []
+        try:
+            for probs, st, warm in fleets:
+                arrays = [probs.copy(), st.copy(), warm.copy(), np.zeros(len(probs), dtype=abi.COMMAND_DTYPE),
+                          np.zeros((len(probs), 9))]
+                for a in arrays:
+                    assert lib.neo_mpc_pin_host_memory(C.c_void_p(a.ctypes.data), a.nbytes) == 0, lib.neo_mpc_last_error()
+                pinned.append(arrays)
+            tickets = [s.solve_begin(a[0], a[1], a[2], out=(a[3], a[4])) for a in pinned]
+            assert sorted(tickets) == [1, 2, 3, 4]
+            with pytest.raises(_lib.NeoMpcError):            # a fifth batch
+                s.solve_begin(pinned[0][0], pinned[0][1], pinned[0][2], out=(pinned[0][3], pinned[0][4]))
+            s.set_costmap(*cmap2)                            # ... behind the four batches still in flight
+            for t, a, r in zip(tickets, pinned, ref):
+                cmd, sol = s.solve_wait(t)
+                assert cmd.tobytes() == r[0][0].tobytes() and (sol == r[0][1]).all()
+            with pytest.raises(_lib.NeoMpcError):            # a ticket that has been waited for
+                s.solve_wait(tickets[0])
+            tickets = [s.solve_begin(a[0], a[1], a[2], out=(a[3], a[4])) for a in reversed(pinned)]   # tick 2, new map
+            for t, a, r in zip(tickets, reversed(pinned), reversed(ref)):
+                cmd, sol = s.solve_wait(t)
+                assert cmd.tobytes() == r[2][0].tobytes() and (sol == r[2][1]).all()
+                assert a[1].tobytes() == r[1][0].tobytes() and (a[2] == r[1][1]).all()
+            probs, st, warm = fleets[0]                      # pageable arrays: refused, not staged behind the caller's back
+            with pytest.raises(_lib.NeoMpcError) as e:
+                s.solve_begin(probs, st.copy(), warm.copy(), out=(np.zeros(len(probs), dtype=abi.COMMAND_DTYPE), np.zeros((len(probs), 9))))
+            assert e.value.code == -5, e.value.code   # NEO_MPC_ERR_UNSUPPORTED
+        finally:
+            for arrays in pinned:
+                for a in arrays:
+                    lib.neo_mpc_unpin_host_memory(C.c_void_p(a.ctypes.data))
+
+
 def test_errors_are_reported_not_thrown(solver_mod):
     from neo_mpc_planner2_amd import _lib
     s = solver_mod.BatchSolver(util.orc.make_params())
@@ -729,6 +791,7 @@ def test_bench_emits_the_contract_line():
     # page-locked arrays are worked on in place: faster than staging the same arrays, bit-identical commands
     assert pc["pinned"]["commands_identical"] and pc["pinned_staged"]["commands_identical"]
     assert pc["pinned"]["value"] > pc["pinned_staged"]["value"] > 0.8 * pc["value"]
+    assert pc["pinned_two_in_flight"]["commands_identical"] and pc["pinned_two_in_flight"]["value"] > pc["pinned"]["value"]
     # the other BASELINE configs and the deployed mode ride in the default line
     names = [o["workload"] for o in rec["other_workloads"]]
     assert names[:3] == ["C3", "C5", "C4 per-GPU shard"] and all("error" not in o for o in rec["other_workloads"])

@@ -18,7 +18,7 @@ d = json.load(open("$O/bench_c2.json"))
 print("C2 %.4g solves/s  ms/step %.4f  kernel %.4f ms  it %.2f max %d" % (d["value"], d["ms_per_step"], d["roofline"]["kernel_ms"], d["solver"]["mean_iterations"], d["solver"]["max_iterations_seen"]))
 pc = d.get("pcie_inclusive", {})
 print("pcie pageable %.4g (%.3f ms)" % (pc.get("value", 0), pc.get("ms_per_call", 0)))
-for k in ("pinned", "pinned_zerocopy_out", "pinned_staged"):
+for k in ("pinned", "pinned_zerocopy_out", "pinned_staged", "pinned_two_in_flight"):
     r = pc.get(k, {})
     print(" ", k, r.get("value"), r.get("ms_per_call"), r.get("commands_identical"), r.get("error"))
 for o in d.get("other_workloads", []):
