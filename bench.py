@@ -105,15 +105,22 @@ def pcie_inclusive(solver, probs, st, warm, n, seconds=3.0):
             if ref_cmd is None:
                 ref_cmd = p_cmd["vel"].copy()
             same = bool((p_cmd["vel"] == ref_cmd).all())     # (one kernel, three ways of feeding it)
-            reps, t_all = 0, 0.0
-            while t_all < seconds / 2 and reps < 200:
-                p_st[...] = st
-                p_warm[...] = warm
-                t0 = time.perf_counter()
-                solver.solve(p_probs, p_st, p_warm, out=(p_cmd, p_sol))
-                t_all += time.perf_counter() - t0
-                reps += 1
-            rec = {"value": count * reps / t_all, "unit": "solves/s", "ms_per_call": 1e3 * t_all / reps, "calls": reps,
+            # three rounds, the median round reported (a synchronous host call is exposed to whatever else the host does:
+            # one run of r03 had a single round at 0.36 ms per call between rounds at 0.155)
+            rounds = []
+            for _ in range(3):
+                reps, t_all = 0, 0.0
+                while t_all < seconds / 6 and reps < 100:
+                    p_st[...] = st
+                    p_warm[...] = warm
+                    t0 = time.perf_counter()
+                    solver.solve(p_probs, p_st, p_warm, out=(p_cmd, p_sol))
+                    t_all += time.perf_counter() - t0
+                    reps += 1
+                rounds.append((t_all / reps, reps))
+            per_call, reps = sorted(rounds)[1]
+            rec = {"value": count / per_call, "unit": "solves/s", "ms_per_call": 1e3 * per_call, "calls": reps,
+                   "rounds_ms_per_call": [1e3 * r[0] for r in rounds],
                    "commands_identical": same, "what": what[mode]}
             if mode == "zerocopy":
                 res["pinned"] = rec          # the default path of page-locked batches
@@ -131,20 +138,25 @@ def pcie_inclusive(solver, probs, st, warm, n, seconds=3.0):
             a[1][...] = st
             a[2][...] = warm
             tickets[k] = solver.solve_begin(a[0], a[1], a[2], out=(a[3], a[4]))
-        calls, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < seconds / 2 and calls < 400:
-            k = calls & 1
-            solver.solve_wait(tickets[k])
-            a = sets[k]
-            a[1][...] = st
-            a[2][...] = warm
-            tickets[k] = solver.solve_begin(a[0], a[1], a[2], out=(a[3], a[4]))
-            calls += 1
+        rounds, total = [], 0
+        for _ in range(3):   # (three rounds, the median one reported, as above)
+            calls, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < seconds / 6 and calls < 200:
+                k = (total + calls) & 1
+                solver.solve_wait(tickets[k])
+                a = sets[k]
+                a[1][...] = st
+                a[2][...] = warm
+                tickets[k] = solver.solve_begin(a[0], a[1], a[2], out=(a[3], a[4]))
+                calls += 1
+            rounds.append(((time.perf_counter() - t0) / calls, calls))
+            total += calls
         for t in tickets:
             solver.solve_wait(t)
-        t_all = time.perf_counter() - t0
+        per_call, calls = sorted(rounds)[1]
         res["pinned_two_in_flight"] = {
-            "value": count * (calls + 2) / t_all, "unit": "solves/s", "ms_per_call": 1e3 * t_all / (calls + 2), "calls": calls + 2,
+            "value": count / per_call, "unit": "solves/s", "ms_per_call": 1e3 * per_call, "calls": calls,
+            "rounds_ms_per_call": [1e3 * r[0] for r in rounds],
             "commands_identical": bool((p_cmd["vel"] == ref_cmd).all() and (q_cmd["vel"] == ref_cmd).all()),
             "what": "neo_mpc_solve_batch_begin / _wait, two page-locked batches of the same instances alternating: one on the "
                     "GPU (worked on in place) while the host resets and resubmits the other; resets inside the timed loop"}
