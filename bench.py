@@ -515,17 +515,10 @@ def main():
         ev.record(stream)
         exchange(0, warm_sets[0] if warm_sets else sets[0], ev)
         drain()
-    for i in range(args.warmup):
-        b = warm_sets[i % len(warm_sets)]
-        solver.solve_device(base.problems, b.states, b.warm, b.commands, velocities=b.vel)
-        if use_dist:
-            ev = torch.cuda.Event()
-            ev.record(stream)
-            exchange(i, b, ev)
-    drain()
     # HIP events per launch, stamped by the dispatch itself (hipExtLaunchKernel through
     # neo_mpc_solve_batch_device_timed): separate event records would put two barrier packets between
-    # consecutive K1 launches.  (Recorded once here so that the handles exist.)
+    # consecutive K1 launches.  (Recorded once here, ahead of the warm-up, so that the handles exist and
+    # nothing but the synchronisation lies between the warm-up steps and the timed ones.)
     # Single GPU: every `stamp`-th launch carries a pair -- a stamped launch costs the stream ~7 us more than a plain one
     # (measured: 0.096-0.100 against 0.089-0.091 ms per step with all / none of 40 launches stamped), and the timed region
     # is the job, not its instrumentation; the kernel's duration is the mean over the stamped launches.
@@ -536,11 +529,19 @@ def main():
         if pair is not None:
             pair[0].record(stream)
             pair[1].record(stream)
+    for i in range(args.warmup):
+        b = warm_sets[i % len(warm_sets)]
+        solver.solve_device(base.problems, b.states, b.warm, b.commands, velocities=b.vel)
+        if use_dist:
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            exchange(i, b, ev)
+    drain()
+    extra_streams = [torch.cuda.Stream(device=dev) for _ in range(max(0, args.streams - 1))]
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
-    extra_streams = [torch.cuda.Stream(device=dev) for _ in range(max(0, args.streams - 1))]
     for i in range(args.steps):
         b = sets[i]
         st_i = None if args.streams <= 1 or i % args.streams == 0 else extra_streams[i % args.streams - 1].cuda_stream
