@@ -259,7 +259,8 @@ int neo_mpc_set_costmap_pool_device(neo_mpc_handle* handle, const uint8_t* d_cel
 
 /* Replaces `client->async_send_request(request); result.get()` (cpp:248-250), i.e. the whole of
  * `MpcOptimizationServer.optimizer` (py:349-403), for `count` independent instances.  Synchronous.
- * Pageable host arrays are staged through device memory (copies queued around the kernel, one wait).  When EVERY
+ * Pageable host arrays are staged through device memory (copies queued around the kernel, one wait; batches of
+ * 65 536 instances or more in four pieces on two streams, so that copies and kernels overlap).  When EVERY
  * array of the batch is page-locked (hipHostMalloc, hipHostRegister, neo_mpc_pin_host_memory below, torch
  * pin_memory) nothing is copied: the kernel reads the records from the caller's arrays and writes the results into
  * them over PCIe while other instances compute -- one launch and one wait per call. */

@@ -101,9 +101,14 @@ struct neo_mpc_handle {
   // neo_mpc_solve_batch_begin / _wait: page-locked batches in flight, each on a stream of its own
   struct InFlight { hipStream_t stream = nullptr; hipEvent_t done = nullptr; bool busy = false; };
   InFlight in_flight[NEO_MPC_MAX_BATCHES_IN_FLIGHT];
+  hipStream_t chunk_streams[2] = {nullptr, nullptr};   // staged host batches of >= kChunkedMinCount instances: copy / solve pipeline
 };
 constexpr size_t kMaxMapUsers = 64;   // distinct streams with a launch in flight between two ingests
 constexpr size_t kLatencyPathMaxCount = 64;
+constexpr size_t kChunkedMinCount = 65536;   // staged host batches from here on go through in kChunks pieces on two streams
+                                             // (measured: pageable 32 768 instances 24.0 M solves/s in pieces against 28.6 M in one,
+                                             // 65 536: 38.9 / 31.6, 131 072: 42.6 / 32.5, 262 144: 45.3 / 33.2)
+constexpr size_t kChunks = 4;
 constexpr size_t kLatencyPathBytes = kLatencyPathMaxCount * (sizeof(neo_mpc_problem) + sizeof(neo_mpc_state) +
                                                             sizeof(neo_mpc_command) + 24 +
                                                             3 * 3 * NEO_MPC_MAX_CONTROL_STEPS * 8);
@@ -469,6 +474,7 @@ void neo_mpc_destroy(neo_mpc_handle* h) {
   if (h->pin) (void)hipHostFree(h->pin);
   if (h->map_ready) (void)hipEventDestroy(h->map_ready);
   for (auto& u : h->map_users) (void)hipEventDestroy(u.done);
+  for (hipStream_t cs : h->chunk_streams) if (cs) (void)hipStreamDestroy(cs);
   for (auto& f : h->in_flight) {
     if (f.busy) (void)hipEventSynchronize(f.done);
     if (f.done) (void)hipEventDestroy(f.done);
@@ -663,6 +669,80 @@ static bool batch_page_locked(const neo_mpc_batch* batch, neo_mpc_batch& dv) {
   return all;
 }
 
+// A staged host batch of kChunkedMinCount instances or more goes through in kChunks pieces on two streams: piece c + 1
+// is copied up and launched before piece c's results are copied back, so copies and kernels of neighbouring pieces
+// overlap (with pageable arrays the runtime's bounce copies block the host, the kernels run behind them; with
+// page-locked arrays everything is asynchronous).  The instances are independent: the pieces' results are the batch's.
+static int solve_batch_staged_chunks(neo_mpc_handle* h, const neo_mpc_batch* b) {
+  const size_t n = b->count, nv = 3 * (size_t)h->params.control_steps;
+  int rc;
+  if ((rc = h->problems.reserve(n * sizeof(neo_mpc_problem)))) return rc;
+  if ((rc = h->states.reserve(n * sizeof(neo_mpc_state)))) return rc;
+  if ((rc = h->warm.reserve(n * nv * 8))) return rc;
+  if ((rc = h->commands.reserve(n * sizeof(neo_mpc_command)))) return rc;
+  if (b->solution && (rc = h->solution.reserve(n * nv * 8))) return rc;
+  if (b->predicted_path && (rc = h->path.reserve(n * nv * 8))) return rc;
+  if (b->velocities && (rc = h->vel.reserve(n * 24))) return rc;
+  for (hipStream_t& cs : h->chunk_streams)
+    if (!cs) HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+  auto bail = [&](int code) {
+    for (hipStream_t cs : h->chunk_streams) (void)hipStreamSynchronize(cs);
+    return code;
+  };
+  const size_t per = ((n + kChunks - 1) / kChunks + 63) & ~(size_t)63;
+  auto piece = [&](size_t c, size_t& off, size_t& m) { off = c * per; m = off < n ? (n - off < per ? n - off : per) : 0; };
+  auto up_and_launch = [&](size_t c) -> int {
+    size_t off, m;
+    piece(c, off, m);
+    if (!m) return NEO_MPC_OK;
+    hipStream_t st = h->chunk_streams[c & 1];
+    char* d_prob = (char*)h->problems.ptr + off * sizeof(neo_mpc_problem);
+    char* d_state = (char*)h->states.ptr + off * sizeof(neo_mpc_state);
+    double* d_warm = (double*)h->warm.ptr + off * nv;
+    HIP_TRY(hipMemcpyAsync(d_prob, b->problems + off, m * sizeof(neo_mpc_problem), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_state, b->states + off, m * sizeof(neo_mpc_state), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_warm, b->warm_start + off * nv, m * nv * 8, hipMemcpyHostToDevice, st));
+    neo_mpc_batch d = *b;
+    d.count = m;
+    d.problems = (const neo_mpc_problem*)d_prob;
+    d.states = (neo_mpc_state*)d_state;
+    d.warm_start = d_warm;
+    d.commands = (neo_mpc_command*)h->commands.ptr + off;
+    d.solution = b->solution ? (double*)h->solution.ptr + off * nv : nullptr;
+    d.predicted_path = b->predicted_path ? (double*)h->path.ptr + off * nv : nullptr;
+    d.velocities = b->velocities ? (double*)h->vel.ptr + off * 3 : nullptr;
+    d.footprints = nullptr; d.footprint_points = 0;
+    SolveArgs a;
+    int r = fill_args(h, &d, a);
+    if (r) return r;
+    if ((r = map_acquire(h, st))) return r;
+    launch_solve(a, st);
+    if (hipGetLastError() != hipSuccess) return fail(NEO_MPC_ERR_DEVICE, "kernel launch failed");
+    return map_release(h, st);
+  };
+  auto down = [&](size_t c) -> int {
+    size_t off, m;
+    piece(c, off, m);
+    if (!m) return NEO_MPC_OK;
+    hipStream_t st = h->chunk_streams[c & 1];
+    HIP_TRY(hipMemcpyAsync(b->commands + off, (neo_mpc_command*)h->commands.ptr + off, m * sizeof(neo_mpc_command), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(b->states + off, (neo_mpc_state*)h->states.ptr + off, m * sizeof(neo_mpc_state), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(b->warm_start + off * nv, (double*)h->warm.ptr + off * nv, m * nv * 8, hipMemcpyDeviceToHost, st));
+    if (b->solution) HIP_TRY(hipMemcpyAsync(b->solution + off * nv, (double*)h->solution.ptr + off * nv, m * nv * 8, hipMemcpyDeviceToHost, st));
+    if (b->predicted_path)
+      HIP_TRY(hipMemcpyAsync(b->predicted_path + off * nv, (double*)h->path.ptr + off * nv, m * nv * 8, hipMemcpyDeviceToHost, st));
+    if (b->velocities) HIP_TRY(hipMemcpyAsync(b->velocities + off * 3, (double*)h->vel.ptr + off * 3, m * 24, hipMemcpyDeviceToHost, st));
+    return NEO_MPC_OK;
+  };
+  if ((rc = up_and_launch(0))) return bail(rc);
+  for (size_t c = 0; c < kChunks; ++c) {
+    if (c + 1 < kChunks && (rc = up_and_launch(c + 1))) return bail(rc);
+    if ((rc = down(c))) return bail(rc);
+  }
+  for (hipStream_t cs : h->chunk_streams) HIP_TRY(hipStreamSynchronize(cs));
+  return NEO_MPC_OK;
+}
+
 int neo_mpc_solve_batch(neo_mpc_handle* h, const neo_mpc_batch* batch) {
   SolveArgs a;
   int rc = fill_args(h, batch, a);  // validates
@@ -676,6 +756,8 @@ int neo_mpc_solve_batch(neo_mpc_handle* h, const neo_mpc_batch* batch) {
     neo_mpc_batch dv;
     if (batch_page_locked(batch, dv)) return solve_batch_zero_copy(h, batch, dv, host_path_mode(h));
   }
+  if (batch->count >= kChunkedMinCount && !(batch->footprints && batch->footprint_points) && !getenv("NEO_MPC_NO_CHUNKS"))
+    return solve_batch_staged_chunks(h, batch);
   neo_mpc_batch d;
   // (the staging copies are asynchronous: no way out of here while one may still be reading the caller's buffers)
   auto bail = [](int code) { (void)hipStreamSynchronize(nullptr); return code; };

@@ -509,6 +509,26 @@ def test_page_locked_host_batches_are_worked_on_in_place(solver_mod):
         assert lib.neo_mpc_set_host_path(s._handle, 7) == -1 and lib.neo_mpc_pin_host_memory(None, 16) == -1
 
 
+def test_large_staged_host_batches_go_through_in_pieces(solver_mod, monkeypatch):
+    """A host batch of 65 536 instances or more that has to be staged (pageable arrays) is copied, solved and copied back
+    in four pieces on two streams; the instances are independent, so commands, raw solution, state, warm start and
+    predicted path are bit-identical with the one-piece path (NEO_MPC_NO_CHUNKS) -- at a count that is no multiple of
+    anything, over two ticks."""
+    cfg, cmap, probs, st0, warm0 = synthetic.make_workload("C2", seed=9, batch=70001)
+    params = util.orc.make_params()
+    with _solver(solver_mod, params, cmap) as s:
+        monkeypatch.setenv("NEO_MPC_NO_CHUNKS", "1")
+        r_st, r_warm = st0.copy(), warm0.copy()
+        ref = [tuple(x.copy() for x in s.solve(probs, r_st, r_warm, want_path=True)) for _ in range(2)]
+        monkeypatch.delenv("NEO_MPC_NO_CHUNKS")
+        c_st, c_warm = st0.copy(), warm0.copy()
+        for tick in range(2):
+            cmd, sol, path = s.solve(probs, c_st, c_warm, want_path=True)
+            assert cmd.tobytes() == ref[tick][0].tobytes(), tick
+            assert (sol == ref[tick][1]).all() and (path == ref[tick][2]).all(), tick
+        assert c_st.tobytes() == r_st.tobytes() and (c_warm == r_warm).all()
+
+
 def test_batches_in_flight_begin_and_wait(solver_mod):
     """neo_mpc_solve_batch_begin / _wait, the two halves of `async_send_request(request)` ... `result.get()`
     (cpp:248-250): four page-locked batches in flight at once end with exactly the commands, raw solutions, states and

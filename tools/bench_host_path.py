@@ -46,7 +46,7 @@ cmap = synthetic.make_costmap(500, seed=0)
 out = {"entry_point": "neo_mpc_solve_batch (host arrays), C2 problem, cold start", "batches": {}}
 with BatchSolver(README_PARAMS) as s:
     s.set_costmap(*cmap)
-    for count in (4096, 32768, 262144):
+    for count in [int(x) for x in os.environ.get("NEO_MPC_HOST_PATH_COUNTS", "4096,32768,65536,262144").split(",")]:
         probs = synthetic.make_problems(count, 500, seed=1000)
         st, warm = synthetic.make_states(probs, 3)
         res = {}
@@ -57,6 +57,10 @@ with BatchSolver(README_PARAMS) as s:
             g_st[...] = st
             g_warm[...] = warm
         res["pageable"] = rate(lambda: s.solve(probs, g_st, g_warm), count, prep=reset_pageable)
+        if count >= 65536:   # (staged batches this large go through in four pieces on two streams: the one-piece path beside it)
+            os.environ["NEO_MPC_NO_CHUNKS"] = "1"
+            res["pageable_one_piece"] = rate(lambda: s.solve(probs, g_st, g_warm), count, prep=reset_pageable)
+            del os.environ["NEO_MPC_NO_CHUNKS"]
         p_probs, p_st, p_warm = pinned(np.ascontiguousarray(probs)), pinned(st), pinned(warm)
         p_cmd, p_sol = pinned(np.zeros(count, dtype=abi.COMMAND_DTYPE)), pinned(np.zeros((count, 9)))
 
