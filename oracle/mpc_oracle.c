@@ -225,6 +225,8 @@ typedef struct orc_ctx {
   const orc_map* map;
 } orc_ctx;
 
+static double orc_kink_radius_stagewise = 1e-4;
+void orc_set_kink_radius_stagewise(double r) { orc_kink_radius_stagewise = r; }
 static void orc_ctx_init(orc_ctx* c, const neo_mpc_params* p, const orc_map* m,
                          const neo_mpc_problem* q, double footprint_cost) {
   const int n = p->control_steps;
@@ -255,7 +257,14 @@ static void orc_ctx_init(orc_ctx* c, const neo_mpc_params* p, const orc_map* m,
   c->lo[1] = p->min_vel_y; c->hi[1] = p->max_vel_y;
   c->lo[2] = p->min_vel_theta; c->hi[2] = p->max_vel_theta;
   c->r = p->max_vel_trans;
-  c->kink_radius = p->kink_radius > 0.0 ? p->kink_radius : 3e-3;
+  {
+    /* (round 4) the stage-wise direction predicts landings on the kink inside its sweep (orc_riccati_direction_disp_tau:
+     * tokink), so the zone in which a block is left to the proximal step alone is small; the dense direction has no such
+     * prediction and keeps round 1's radius */
+    const int stagewise = p->method == NEO_MPC_METHOD_RICCATI ||
+                          (p->method == NEO_MPC_METHOD_AUTO && (p->control_steps != 3 || p->w_costmap > 0.25 * p->w_trans));
+    c->kink_radius = p->kink_radius > 0.0 ? p->kink_radius : stagewise ? orc_kink_radius_stagewise : 3e-3;
+  }
   c->map = m;
 }
 
@@ -378,14 +387,86 @@ typedef struct orc_active {
 } orc_active;
 
 
-static void orc_reduce(const orc_ctx* c, const double* u, const double* gs, double* gt, double* gr,
+/* Tangent-cone reduction of a block's gradient g at u_i: omega frozen at a bound the descent direction -g pushes into;
+ * (vx, vy) free, sliding along one active constraint (longest slide that keeps the others satisfied) or pinned.
+ * Out: the reduced gradient gr[3] and the face (wfroz, mode 0/1/2, outward normal, disc flag, multiplier). */
+static int orc_near_reduced = 1;
+void orc_set_near_reduced(int m) { orc_near_reduced = m; }
+static void orc_tangent(const orc_ctx* c, const double* ui, const double* gi, double* gr, uint8_t* wfroz, uint8_t* mode,
+                        double* nxo, double* nyo, uint8_t* disc, double* lambda) {
+  gr[0] = gi[0]; gr[1] = gi[1]; gr[2] = gi[2];
+  /* omega: plain bound */
+  *wfroz = (ui[2] <= c->lo[2] && gi[2] > 0.0) || (ui[2] >= c->hi[2] && gi[2] < 0.0);
+  if (*wfroz) gr[2] = 0.0;
+  /* (vx, vy): outward normals of the constraints active at u */
+  double nx[3], ny[3];
+  int isdisc[3] = {0, 0, 0};
+  int na = 0;
+  if (ui[0] <= c->lo[0]) { nx[na] = -1.0; ny[na] = 0.0; ++na; }
+  else if (ui[0] >= c->hi[0]) { nx[na] = 1.0; ny[na] = 0.0; ++na; }
+  if (ui[1] <= c->lo[1]) { nx[na] = 0.0; ny[na] = -1.0; ++na; }
+  else if (ui[1] >= c->hi[1]) { nx[na] = 0.0; ny[na] = 1.0; ++na; }
+  double nv = sqrt(ui[0] * ui[0] + ui[1] * ui[1]);
+  if (nv > 0.0 && nv >= c->r * (1.0 - 1e-12)) { nx[na] = ui[0] / nv; ny[na] = ui[1] / nv; isdisc[na] = 1; ++na; }
+  const double dx = -gi[0], dy = -gi[1]; /* steepest descent */
+  *mode = 0; *nxo = 0.0; *nyo = 0.0; *disc = 0; *lambda = 0.0;
+  int violated = 0;
+  for (int k = 0; k < na; ++k) if (nx[k] * dx + ny[k] * dy > 0.0) violated = 1;
+  if (violated) {
+    double bestn = -1.0;
+    int bestk = -1;
+    for (int k = 0; k < na; ++k) {
+      double dn = nx[k] * dx + ny[k] * dy;
+      if (!(dn > 0.0)) continue;
+      double px = dx - dn * nx[k], py = dy - dn * ny[k];
+      int ok = 1;
+      for (int j = 0; j < na; ++j)
+        if (j != k && nx[j] * px + ny[j] * py > 1e-14 * (fabs(px) + fabs(py))) ok = 0;
+      double pn = px * px + py * py;
+      if (ok && pn > bestn) { bestn = pn; bestk = k; }
+    }
+    if (bestk >= 0) {
+      double dn = nx[bestk] * dx + ny[bestk] * dy;
+      *mode = 1; *nxo = nx[bestk]; *nyo = ny[bestk];
+      *disc = (uint8_t)isdisc[bestk]; *lambda = dn;
+      gr[0] = -(dx - dn * nx[bestk]);
+      gr[1] = -(dy - dn * ny[bestk]);
+    } else {
+      *mode = 2;
+      gr[0] = 0.0; gr[1] = 0.0;
+    }
+  }
+}
+
+/* (round 4) gs is rewritten for blocks next to the kink: their SMOOTH gradient reduced on the tangent cone -- the
+ * proximal step of such a block is taken on its face (a component that pushes omega into its bound, or the velocity out
+ * of the disc, used to dominate the step's shrink factor and keep the block from landing on the kink; projection and
+ * prox do not commute), and a block ON the kink is at rest when the REDUCED smooth gradient lies inside the norm's
+ * subdifferential. */
+static void orc_reduce(const orc_ctx* c, const double* u, double* gs, double* gt, double* gr,
                        orc_active* a) {
   for (int i = 0; i < c->n; ++i) {
     const double* ui = u + 3 * i;
-    const double* gsi = gs + 3 * i;
+    double* gsi = gs + 3 * i;
     a->tokink[i] = 0;
     double e[3] = {ui[0] - c->v[0], ui[1] - c->v[1], ui[2] - c->v[2]};
     double ne = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    a->near[i] = ne < c->kink_radius;
+    if (a->near[i]) {
+      if (orc_near_reduced) {
+        double gsr[3], nxo, nyo, lam;
+        uint8_t wf, md, dc;
+        orc_tangent(c, ui, gsi, gsr, &wf, &md, &nxo, &nyo, &dc, &lam);
+        gsi[0] = gsr[0]; gsi[1] = gsr[1]; gsi[2] = gsr[2];
+      }
+      /* a block sitting exactly ON the kink with a smooth gradient inside the norm's subdifferential
+       * (|g_s| <= w_control/N) stays there under every proximal step: it is at rest */
+      a->rest[i] = ne == 0.0 && gsi[0] * gsi[0] + gsi[1] * gsi[1] + gsi[2] * gsi[2] <= c->wc_n * c->wc_n;
+      for (int k = 0; k < 3; ++k) { gt[3 * i + k] = 0.0; gr[3 * i + k] = 0.0; }
+      a->wfroz[i] = 0; a->mode[i] = 0; a->nx[i] = 0.0; a->ny[i] = 0.0; a->disc[i] = 0; a->lambda[i] = 0.0;
+      continue;
+    }
+    a->rest[i] = 0;
     double gi[3];
     if (ne > 0.0) {
       for (int k = 0; k < 3; ++k) gi[k] = gsi[k] + c->wc_n * (e[k] / ne);
@@ -394,58 +475,8 @@ static void orc_reduce(const orc_ctx* c, const double* u, const double* gs, doub
       double sh = (ng > c->wc_n) ? 1.0 - c->wc_n / ng : 0.0;
       for (int k = 0; k < 3; ++k) gi[k] = gsi[k] * sh;
     }
-    for (int k = 0; k < 3; ++k) { gt[3 * i + k] = gi[k]; gr[3 * i + k] = gi[k]; }
-    a->near[i] = ne < c->kink_radius;
-    /* a block sitting exactly ON the kink with a smooth gradient inside the norm's subdifferential
-     * (|g_s| <= w_control/N) stays there under every proximal step: it is at rest */
-    a->rest[i] = a->near[i] && ne == 0.0 &&
-                 gsi[0] * gsi[0] + gsi[1] * gsi[1] + gsi[2] * gsi[2] <= c->wc_n * c->wc_n;
-    if (a->near[i]) {
-      for (int k = 0; k < 3; ++k) { gt[3 * i + k] = 0.0; gr[3 * i + k] = 0.0; }
-      a->wfroz[i] = 0; a->mode[i] = 0; a->nx[i] = 0.0; a->ny[i] = 0.0; a->disc[i] = 0; a->lambda[i] = 0.0;
-      continue;
-    }
-    /* omega: plain bound */
-    a->wfroz[i] = (ui[2] <= c->lo[2] && gi[2] > 0.0) || (ui[2] >= c->hi[2] && gi[2] < 0.0);
-    if (a->wfroz[i]) gr[3 * i + 2] = 0.0;
-    /* (vx, vy): outward normals of the constraints active at u */
-    double nx[3], ny[3];
-    int isdisc[3] = {0, 0, 0};
-    int na = 0;
-    if (ui[0] <= c->lo[0]) { nx[na] = -1.0; ny[na] = 0.0; ++na; }
-    else if (ui[0] >= c->hi[0]) { nx[na] = 1.0; ny[na] = 0.0; ++na; }
-    if (ui[1] <= c->lo[1]) { nx[na] = 0.0; ny[na] = -1.0; ++na; }
-    else if (ui[1] >= c->hi[1]) { nx[na] = 0.0; ny[na] = 1.0; ++na; }
-    double nv = sqrt(ui[0] * ui[0] + ui[1] * ui[1]);
-    if (nv > 0.0 && nv >= c->r * (1.0 - 1e-12)) { nx[na] = ui[0] / nv; ny[na] = ui[1] / nv; isdisc[na] = 1; ++na; }
-    const double dx = -gi[0], dy = -gi[1]; /* steepest descent */
-    a->mode[i] = 0; a->nx[i] = 0.0; a->ny[i] = 0.0; a->disc[i] = 0; a->lambda[i] = 0.0;
-    int violated = 0;
-    for (int k = 0; k < na; ++k) if (nx[k] * dx + ny[k] * dy > 0.0) violated = 1;
-    if (violated) {
-      double bestn = -1.0;
-      int bestk = -1;
-      for (int k = 0; k < na; ++k) {
-        double dn = nx[k] * dx + ny[k] * dy;
-        if (!(dn > 0.0)) continue;
-        double px = dx - dn * nx[k], py = dy - dn * ny[k];
-        int ok = 1;
-        for (int j = 0; j < na; ++j)
-          if (j != k && nx[j] * px + ny[j] * py > 1e-14 * (fabs(px) + fabs(py))) ok = 0;
-        double pn = px * px + py * py;
-        if (ok && pn > bestn) { bestn = pn; bestk = k; }
-      }
-      if (bestk >= 0) {
-        double dn = nx[bestk] * dx + ny[bestk] * dy;
-        a->mode[i] = 1; a->nx[i] = nx[bestk]; a->ny[i] = ny[bestk];
-        a->disc[i] = (uint8_t)isdisc[bestk]; a->lambda[i] = dn;
-        gr[3 * i] = -(dx - dn * nx[bestk]);
-        gr[3 * i + 1] = -(dy - dn * ny[bestk]);
-      } else {
-        a->mode[i] = 2;
-        gr[3 * i] = 0.0; gr[3 * i + 1] = 0.0;
-      }
-    }
+    for (int k = 0; k < 3; ++k) gt[3 * i + k] = gi[k];
+    orc_tangent(c, ui, gi, gr + 3 * i, &a->wfroz[i], &a->mode[i], &a->nx[i], &a->ny[i], &a->disc[i], &a->lambda[i]);
   }
 }
 
@@ -1004,15 +1035,38 @@ static double orc_lane_scale(int lane, int longshots) {
   return (lane & 1) ? s * 1.4142135623730951 : s;
 }
 
+/* (round 4) A block sliding along a box bound stops where the bound meets the speed disc: the Euclidean projection of a
+ * point beyond that corner slides DOWN the disc, away from the bound, so a Newton step along the bound was cut to the
+ * fraction that reaches the corner and every other block's step with it (held-out set "a", control_steps 12: searches
+ * jammed at the corner for 20 iterations).  A/B hook: orc_set_corner_stop(0). */
+static int orc_corner_stop = 1;
+void orc_set_corner_stop(int m) { orc_corner_stop = m; }
+#define ORC_EXIT_HOPS 1
+static int orc_exit_hops = 1;
+void orc_set_exit_hops(int m) { orc_exit_hops = m; }
+static int orc_land_mode = 0;
+void orc_set_land_mode(int m) { orc_land_mode = m; }
+static int orc_near_mode = 1;
+void orc_set_near_mode(int m) { orc_near_mode = m; }
 static void orc_candidate(const orc_ctx* c, const orc_active* act, int lane, double alpha, const double* u,
                           const double* gs, const double* d, double* cand) {
   const double sc = orc_lane_scale(lane, act->longshots);
   for (int i = 0; i < c->n; ++i) {
     double b[3];
-    if (lane < 32 || act->near[i]) {
+    if ((orc_near_mode == 1 || orc_near_mode == 3) && lane >= 32 && (lane & 1) && act->near[i]) {
+      for (int k = 0; k < 3; ++k) b[k] = u[3 * i + k];
+    } else if (orc_near_mode == 2 && lane >= 32 && act->near[i]) {
+      for (int k = 0; k < 3; ++k) b[k] = u[3 * i + k];
+    } else if (lane < 32 || act->near[i]) {
       /* per-block step: the curvature of block i's own tracking terms is proportional to the number
        * of stages it still moves, N - i (diagonal of the Gauss-Newton Hessian: 2 w_trans/N dt^2 (N - i)) */
-      const double a = alpha * sc * (act->riccati ? (double)c->n / (double)(c->n - i) : 1.0);
+      double a = alpha * sc * (act->riccati ? (double)c->n / (double)(c->n - i) : 1.0);
+      if (orc_near_mode == 3 && lane >= 32) {
+        /* the block's own curvature bound: 2 dt^2 ((N - i)/N (max(w_trans, w_orient) + w_trans (r H)^2) + w_terminal w_orient) */
+        const double wt = c->wt_n * c->n, wo = c->wo_n * c->n, reach = c->r * c->dt * c->n;
+        const double L = 2.0 * c->dt * c->dt * ((double)(c->n - i) / c->n * (fmax(wt, wo) + wt * reach * reach) + c->wterm_o);
+        a = 1.0 / L;
+      }
       double e[3], ne2 = 0.0;
       for (int k = 0; k < 3; ++k) { e[k] = (u[3 * i + k] - a * gs[3 * i + k]) - c->v[k]; ne2 += e[k] * e[k]; }
       double ne = sqrt(ne2);
@@ -1022,6 +1076,22 @@ static void orc_candidate(const orc_ctx* c, const orc_active* act, int lane, dou
       const double t = act->tokink[i] ? fmin(sc, 1.0) : sc;
       for (int k = 0; k < 3; ++k) b[k] = u[3 * i + k] + t * d[3 * i + k];
       if (act->tokink[i] && t == 1.0) for (int k = 0; k < 3; ++k) b[k] = c->v[k];
+      if (orc_land_mode && !act->riccati && !act->tokink[i]) {
+        /* a Newton step that carries the block THROUGH the kink (radially inward by more than its distance) ends on it */
+        double e[3] = {u[3 * i] - c->v[0], u[3 * i + 1] - c->v[1], u[3 * i + 2] - c->v[2]};
+        const double rho2 = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+        const double inward = -(t * (d[3 * i] * e[0] + d[3 * i + 1] * e[1] + d[3 * i + 2] * e[2]));
+        if (rho2 > 0.0 && inward >= rho2) for (int k = 0; k < 3; ++k) b[k] = c->v[k];
+      }
+      if (orc_corner_stop && act->mode[i] == 1 && !act->disc[i] && !act->tokink[i]) {
+        /* a block sliding along a box bound stops where the bound meets the speed disc (the Euclidean projection of a
+         * point beyond the corner slides down the disc instead, away from the bound) */
+        const int free_axis = act->nx[i] != 0.0 ? 1 : 0, fixed_axis = 1 - free_axis;
+        const double fixed = u[3 * i + fixed_axis];
+        const double lim2 = c->r * c->r - fixed * fixed, lim = lim2 > 0.0 ? sqrt(lim2) * (1.0 - 1e-15) : 0.0;
+        b[fixed_axis] = fixed;
+        b[free_axis] = orc_clamp(b[free_axis], -lim, lim);
+      }
     }
     orc_project(c, b);
     for (int k = 0; k < 3; ++k) cand[3 * i + k] = b[k];
@@ -1123,6 +1193,18 @@ static int orc_blocked_rule = 1;
 void orc_set_blocked_rule(int on) { orc_blocked_rule = on; }
 
 /* Returns status; x_out = minimiser estimate, *f_out its objective. */
+/* (round 4) A/B hooks.  orc_tau_mode 1 (default): the stage-wise direction carries the second-order terms of the rollout
+ * step (lambda . d2F: the exact Hessian, quadratic convergence); 0: Gauss-Newton (rounds 2-3: linear convergence wherever
+ * the tracking residuals are large -- held-out parameter sets "a" and "c": first controls 1.4e-3 ... 3.2e-3 from SLSQP's
+ * converged ones when the window rule cut in).  orc_rule_mode 1 (default): the gain thresholds are relative to the part
+ * of the objective that depends on u (the constant terminal distance term, py:266, can be 20x that), and with the
+ * stage-wise direction the three-iteration window and the closing-in rule only judge runs of BLOCKED iterations
+ * (iterations won by a decent Newton step end through the Newton step test); 0: rounds 2-3. */
+static double orc_final_frac = 0.3;   /* a Gauss-Newton (not exact) full step has to be this much shorter than opt_tolerance to be the last */
+void orc_set_final_frac(double f) { orc_final_frac = f; }
+static int orc_tau_mode = 1, orc_rule_mode = 1;
+void orc_set_tau_mode(int m) { orc_tau_mode = m; }
+void orc_set_rule_mode(int m) { orc_rule_mode = m; }
 int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_problem* q,
                  double footprint_cost, const double* x0, double* x_out, double* f_out,
                  int32_t* nit_out, int32_t* nfev_out) {
@@ -1208,6 +1290,9 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
   const double final_tol = p->step_tolerance > 0.0 ? p->step_tolerance : p->opt_tolerance;
   int final = 0;
   int blocked_run = 0;   /* consecutive iterations not won by a decent Newton step */
+  int exit_hops = 0;     /* dense direction: hops taken at the point where the search was about to end */
+  int exact_step = 0;    /* this iteration's stage-wise direction carries the second-order terms */
+  int nblocked = 1;      /* consecutive iterations not won by a Newton step of at least half its length */
   for (it = 0; it < max_it; ++it) {
     orc_grad_smooth(&c, u, gs);
     orc_reduce(&c, u, gs, gt, gr, &act);
@@ -1221,7 +1306,16 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
        * Newton step almost never wins there (9 % of the cases): lanes 32-63 walk the reduced
        * steepest-descent direction in that first iteration instead */
       if (it == 0 && cold) for (int k = 0; k < nv; ++k) d[k] = -gr[k];
-      else if (riccati && orc_disp) { orc_mu = mu; orc_riccati_direction_disp(&c, u, gs, gt, &act, d); orc_mu = 0.0; }
+      else if (riccati && orc_disp) {
+        orc_mu = mu;
+        /* second-order terms only behind an iteration won by a decent Newton step (the model held there): far from the
+         * minimiser -- a search blocked by a wall, the first steps of a cold start -- the exact Hessian is indefinite
+         * and the Gauss-Newton direction is the safer one */
+        const double tau = orc_tau_mode == 1 ? (nblocked == 0 ? 1.0 : 0.0) : orc_tau_mode == 2 ? 1.0 : 0.0;
+        exact_step = tau != 0.0;
+        orc_riccati_direction_disp_tau(&c, u, gs, gt, &act, d, tau);
+        orc_mu = 0.0;
+      }
       else if (riccati) orc_riccati_direction(&c, u, gs, gt, &act, d);
       else orc_newton_direction(&c, u, gs, gr, &act, d);
       orc_apply_active(&c, &act, d);
@@ -1234,11 +1328,12 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
          * rest on it) */
         for (int i = 0; i < n; ++i) anynear |= act.near[i] && !(orc_rest_rule && act.rest[i]);
         /* (with a cheaper cell a hop away the search runs once more: its hop lanes decide) */
-        if (dm < xtol && !anynear && nhops == 0) { status = NEO_MPC_STATUS_CONVERGED; break; }
+        if (dm < xtol && !anynear && nhops == 0) { status = NEO_MPC_STATUS_CONVERGED; goto exit_check; }
         /* a full Newton step below opt_tolerance (SLSQP's own step test) is the last one: it is
          * searched and taken like any other, but nothing re-checks the point it lands on (the
          * error left is of the order of the step squared) */
-        if (dm < final_tol && !anynear) final = 1;
+        /* (a Gauss-Newton step converges linearly: it has to be shorter to be the last) */
+        if (dm < (riccati && !exact_step ? orc_final_frac : 1.0) * final_tol && !anynear) final = 1;
       }
     }
     if (!newton && it > 0) {
@@ -1331,10 +1426,13 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
       for (int k = 0; k < nv; ++k) gn = fmax(gn, fabs(gr[k]));
       int nact = 0, nnear = 0;
       for (int i = 0; i < n; ++i) { nact += act.mode[i] != 0 || act.wfroz[i]; nnear += act.near[i]; }
-      fprintf(stderr, "it %3d f %.15g fb-f %.3e best %2d alpha %.3e |gr|inf %.3e npairs %d | qn best %2d df %.3e active %d near %d\n",
+      fprintf(stderr, "it %3d f %.15g fb-f %.3e best %2d alpha %.3e |gr|inf %.3e npairs %d | qn best %2d df %.3e active %d near %d |",
               it, f, fb - f, best, alpha, gn, npairs, best_qn, fb_qn - f, nact, nnear);
+      for (int i = 0; i < n; ++i) fprintf(stderr, " %d%s%s", act.mode[i], act.wfroz[i] ? "w" : "", act.near[i] ? "k" : "");
+      fprintf(stderr, "\n");
+      if (orc_trace > 2) { for (int i = 0; i < n; ++i) fprintf(stderr, "      u[%d] % .6f % .6f % .6f  d % .3e % .3e % .3e  gt % .3e % .3e % .3e\n", i, u[3*i], u[3*i+1], u[3*i+2], d[3*i], d[3*i+1], d[3*i+2], gt[3*i], gt[3*i+1], gt[3*i+2]); }
     }
-    if (!(fb < f)) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
+    if (!(fb < f)) { status = NEO_MPC_STATUS_CONVERGED; ++it; goto exit_check; }
     double step = 0.0;
     for (int k = 0; k < nv; ++k) {
       double ad = fabs(best_c[k] - u[k]);
@@ -1358,21 +1456,61 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
     /* iterations that gain next to nothing or barely move (creeping along a costmap cell edge, the
      * slow tail next to the control-norm kink) end the search once ORC_STALL_ITERATIONS of them
      * are in a row */
-    stall = (decrease <= ftol * fmax(1.0, fabs(fb)) || step <= stall_step) ? stall + 1 : 0;
+    /* (gain thresholds are relative to the u-dependent part of the objective: f without the constant terms) */
+    const double fsc = orc_rule_mode >= 1 ? fmax(1.0, fabs(fb - c.konst)) : fmax(1.0, fabs(fb));
+    stall = (decrease <= ftol * fsc || step <= stall_step) ? stall + 1 : 0;
     /* (from ORC_LATE_ITERATION on the window is the control_steps-3 one again: a long-horizon search that has run
      * twice its usual length is creeping, gaining 1e-8 of f per iteration up to the iteration cap -- a handful per
      * 65 536 solves, but a launch lasts as long as its slowest wave) */
     const double wnow = it >= ORC_LATE_ITERATION ? wtol_late : wtol;
-    const int creeping = wnow > 0.0 && decrease + gain1 + gain2 <= wnow * fmax(1.0, fabs(fb));
+    /* stage-wise direction: the window and closing-in rules only judge runs of BLOCKED iterations (none of the three won
+     * by a Newton step of at least half its length); iterations won by the Newton step end through the step test */
+    nblocked = (best < 32 || orc_lane_scale(best, act.longshots) < 0.5 || hop_won) ? nblocked + 1 : 0;
+    const int creeping = wnow > 0.0 && decrease + gain1 + gain2 <= wnow * fsc && (orc_rule_mode < 1 || !riccati || nblocked >= 3);
     /* ... and so does a step below stall_step whose gain halved twice in a row: the search is closing in on a
      * costmap cell edge (or the kink) geometrically, what is left to gain is less than the last gain (part of the
      * window rule: off with it).  -3 % iterations at control_steps 3 and 32, no command moves by 1e-3. */
-    const int closing_in = wtol > 0.0 && step <= stall_step && decrease <= 0.5 * gain1 && gain1 <= 0.5 * gain2;
+    const int closing_in = wtol > 0.0 && step <= stall_step && decrease <= 0.5 * gain1 && gain1 <= 0.5 * gain2 && (orc_rule_mode < 1 || !riccati || nblocked >= 3);
     int blocked_stop = 0;
     if (newton && !riccati && orc_blocked_rule && wtol > 0.0 && blocked_run >= ORC_BLOCKED_RUN)
       blocked_stop = decrease + gain1 + gain2 <= (orc_term_sum(&c, u) == 0.0 ? ORC_BLOCKED_TOL_FREE : ORC_BLOCKED_TOL_MAP) * flat * p->opt_tolerance;
     gain2 = gain1; gain1 = decrease;
-    if (step < xtol || stall >= ORC_STALL_ITERATIONS || creeping || closing_in || final || blocked_stop) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
+    if (step < xtol || stall >= ORC_STALL_ITERATIONS || creeping || closing_in || final || blocked_stop) { status = NEO_MPC_STATUS_CONVERGED; ++it; goto exit_check; }
+    continue;
+  exit_check:
+    /* (round 4) Dense direction: a search about to end looks once for a cheaper costmap cell a hop away (the hop
+     * candidates the stage-wise direction tries in every iteration, orc_hops): a search that closed in on a cell edge
+     * from the expensive side ends a millimetre short of a cost step no descent direction sees (held-out set "a",
+     * w_costmap / w_trans = 0.08: one such step is worth 2e-3).  A hop that lowers the objective is taken and the
+     * search goes on from there (at most ORC_EXIT_HOPS times per solve: each restart lengthens the slowest search of a launch). */
+    if (newton && !riccati && orc_hops_on && orc_exit_hops && exit_hops < ORC_EXIT_HOPS && it < max_it) {
+      double hop2[ORC_MAXN][2];
+      uint8_t has2[ORC_MAXN];
+      if (orc_hops(&c, u, 0.1 * p->opt_tolerance, hop2, has2)) {
+        double fbest = f;
+        int ibest = -1;
+        double bb[3] = {0, 0, 0};
+        for (int i = 0, k = 0; i < n && k < ORC_HOP_LANES; ++i) {
+          if (!has2[i]) continue;
+          ++k;
+          memcpy(cand, u, sizeof(double) * nv);
+          double b[3] = {u[3 * i] + hop2[i][0], u[3 * i + 1] + hop2[i][1], u[3 * i + 2]};
+          orc_project(&c, b);
+          cand[3 * i] = b[0]; cand[3 * i + 1] = b[1];
+          const double fc = orc_eval(&c, cand);
+          if (fc < fbest) { fbest = fc; ibest = i; bb[0] = b[0]; bb[1] = b[1]; }
+        }
+        ++nfev;
+        if (ibest >= 0) {
+          u[3 * ibest] = bb[0]; u[3 * ibest + 1] = bb[1];
+          f = fbest;
+          ++exit_hops;
+          status = NEO_MPC_STATUS_MAX_ITER; stall = 0; blocked_run = 0; final = 0; gain1 = INFINITY; gain2 = INFINITY;
+          continue;   /* (the for statement's ++it is skipped by the exits above having counted this iteration) */
+        }
+      }
+    }
+    break;
   }
   memcpy(x_out, u, sizeof(double) * nv);
   *f_out = f;
