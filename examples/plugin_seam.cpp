@@ -123,7 +123,7 @@ struct NeoMpcPlannerSeam {
     // footprintCostAtPose (cpp:218-219) is already computed by the plugin on nav2's 0..255 scale;
     // 254 (lethal) is what the Python node saw as getFootprintCost(...) == 1.0 (py:343)
     req.footprint_cost = footprint_cost_raw >= 254.0 ? 1.0 : 0.0;
-    req.switch_opt = 0;                        // cpp:245 closer_to_goal (stored by the node, py:354, never read)
+    req.switch_opt = closer_to_goal ? 1 : 0;   // cpp:245 request->switch_opt = closer_to_goal (stored by the node, py:354, never read)
 
     last_request_ = req;
     neo_mpc_command out{};

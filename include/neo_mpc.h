@@ -27,16 +27,27 @@
 extern "C" {
 #endif
 
-#define NEO_MPC_ABI_VERSION 1
-/* Behaviour history behind one ABI version (no signature or record layout has changed):
- *   round 1  AUTO = dense Newton up to 8 control steps, L-BFGS beyond.
- *   round 2  AUTO = dense Newton at control_steps 3, the stage-wise (Riccati) direction everywhere else -- and at 3 when
- *            w_costmap > w_trans / 4; stop thresholds beyond 3 control steps scaled with (3 / control_steps)^2.
- *   round 3  hop candidates in the stage-wise direction; blocked-run stop rule in the dense direction; page-locked host
- *            batches are worked on in place (neo_mpc_solve_batch); neo_mpc_pin_host_memory, neo_mpc_set_host_path;
- *            neo_mpc_solve_batch_begin / _wait (new entry points, nothing else changed).
- * Iterates and iteration counts differ between rounds, results stay inside the parity protocol of DESIGN.md section 1;
+#define NEO_MPC_ABI_VERSION 2
+/* ABI 2 (round 4): neo_mpc_behaviour_version(); NEO_MPC_COMPAT_REFERENCE_START; unknown compat bits and the forced
+ * directions without a wall model at a heavy costmap weight are refused; neo_mpc_problem.skip (was reserved[0]) and
+ * NEO_MPC_FLAG_SKIPPED; neo_mpc_carrot.status 3.  No record changed its size or the offset of a field that existed.
+ *
+ * Behaviour history (iterates and iteration counts differ between versions, results stay inside the parity protocol of
+ * DESIGN.md section 1; neo_mpc_behaviour_version() returns the number of the build that answers):
+ *   1  AUTO = dense Newton up to 8 control steps, L-BFGS beyond.
+ *   2  AUTO = dense Newton at control_steps 3, the stage-wise (Riccati) direction everywhere else -- and at 3 when
+ *      w_costmap > w_trans / 4; stop thresholds beyond 3 control steps scaled with (3 / control_steps)^2.
+ *   3  hop candidates in the stage-wise direction; blocked-run stop rule in the dense direction; searches on free space
+ *      start from the better of the warm start and the warm start un-shifted; page-locked host batches are worked on in
+ *      place (neo_mpc_solve_batch); neo_mpc_pin_host_memory, neo_mpc_set_host_path; neo_mpc_solve_batch_begin / _wait.
+ *   4  the stage-wise direction carries the second-order terms of the rollout step (exact Hessian) behind an iteration
+ *      won by a Newton step; its window rules judge runs of blocked iterations only; gain thresholds relative to the
+ *      u-dependent part of the objective; blocks next to the control norm's kink take their proximal step on their face
+ *      and sit every other Newton candidate out; a block sliding along a box bound stops at the disc corner; the dense
+ *      direction tries a hop to a cheaper costmap cell where its search is about to end; state records are written back
+ *      field by field (old_goal only when it changed).
  * method = NEO_MPC_METHOD_NEWTON / _LBFGS / _RICCATI pins a direction. */
+#define NEO_MPC_BEHAVIOUR_VERSION 4
 
 /* return codes */
 #define NEO_MPC_OK 0
@@ -53,9 +64,18 @@ extern "C" {
 /* neo_mpc_command.flags */
 #define NEO_MPC_FLAG_RESET 1   /* new goal: warm start / last_control / waiting_time reset (py:358-361) */
 #define NEO_MPC_FLAG_STOPPED 2 /* zero twist because of the collision latch (py:374-377) */
+#define NEO_MPC_FLAG_SKIPPED 4 /* neo_mpc_problem.skip was set: no request was made for this robot this tick (cpp:234-236);
+                                  nothing but this flag has been written: state, warm start and the command's other fields
+                                  are what they were */
 
 /* neo_mpc_params.compat_flags */
 #define NEO_MPC_COMPAT_ODOM_YAW_GOAL_W 1 /* py:213: odom_yaw takes quaternion w from the goal pose */
+#define NEO_MPC_COMPAT_REFERENCE_START 2 /* every search starts at the reference's starting point: the warm start as
+                                            py:397-400 / 198-202 left it (projected onto the feasible set, like SciPy clips
+                                            x0).  Without it (default) a search on free space starts from the better of that
+                                            and the same sequence with the whole-step shift undone -- fewer iterations per
+                                            warm tick, same objective */
+#define NEO_MPC_COMPAT_ALL (NEO_MPC_COMPAT_ODOM_YAW_GOAL_W | NEO_MPC_COMPAT_REFERENCE_START) /* any other bit: INVALID_ARGUMENT */
 
 /* neo_mpc_params.method */
 #define NEO_MPC_METHOD_AUTO 0   /* dense Newton at control_steps == 3 (the register-resident 9 x 9 kernel),
@@ -65,6 +85,9 @@ extern "C" {
 #define NEO_MPC_METHOD_LBFGS 1  /* projected L-BFGS, any control_steps */
 #define NEO_MPC_METHOD_NEWTON 2 /* projected Newton (finite-difference Hessian of the analytic
                                    gradient, one column per lane); control_steps <= 8 */
+/* (LBFGS and NEWTON have no wall model for costmap steps: with w_costmap > w_trans / 4 -- where AUTO hands every
+ * control_steps to the stage-wise direction -- they end above the reference's SLSQP on a few percent of the costmap cases
+ * (G8 "turn", G9), so neo_mpc_create / neo_mpc_set_params refuse that combination with NEO_MPC_ERR_UNSUPPORTED) */
 #define NEO_MPC_METHOD_RICCATI 3 /* projected Gauss-Newton, solved stage by stage (Riccati recursion over the
                                    rollout chain, 3x3 blocks, float32): any control_steps, O(control_steps)
                                    per iteration; beyond 8 control steps with adaptive Levenberg-Marquardt
@@ -92,7 +115,8 @@ typedef struct neo_mpc_params {
   /* --- build-specific --- */
   int32_t max_iterations; /* <=0: 100, SciPy SLSQP's maxiter */
   int32_t lbfgs_memory;   /* <=0: 4 */
-  int32_t compat_flags;   /* NEO_MPC_COMPAT_*; neo_mpc_default_params sets all (parity mode) */
+  int32_t compat_flags;   /* NEO_MPC_COMPAT_*; neo_mpc_default_params sets NEO_MPC_COMPAT_ODOM_YAW_GOAL_W (the reference's
+                             objective); bits outside NEO_MPC_COMPAT_ALL are refused */
   double step_tolerance;  /* stop when max|du| < this; <=0: 1e-3 * opt_tolerance, and (Newton) a full step
                              shorter than opt_tolerance -- SLSQP's step test -- is taken as the last one */
   double cost_tolerance;  /* an iteration is "stalled" when it lowers the objective by less than
@@ -127,7 +151,11 @@ typedef struct neo_mpc_problem {
                               ignored with a single costmap */
   int32_t switch_opt;      /* request.switch_opt = closer_to_goal (cpp:245); the reference stores it (py:354)
                               and never reads it -- carried so that the record is the request field for field */
-  double reserved[6];
+  int32_t skip;            /* != 0: this robot makes NO request this tick -- the plugin threw before its service call
+                              (footprint cost 255, cpp:234-236; neo_mpc_select_carrots sets it with carrot status 3): the
+                              solver leaves the robot's state and warm start alone and writes NEO_MPC_FLAG_SKIPPED only */
+  int32_t reserved_i;
+  double reserved[5];      /* (never read by the device: a request is 216 bytes on the wire) */
 } neo_mpc_problem;
 
 /* State the reference node keeps between requests (py:115-152).  128 bytes.  The warm
@@ -192,7 +220,10 @@ typedef struct neo_mpc_carrot {
                              [0, begin) like cpp:126 */
   int32_t closer_to_goal; /* cpp:95-100 (-> request.switch_opt, cpp:245) */
   int32_t slow_down;      /* slow_down_ after cpp:221-232 */
-  int32_t status;         /* 0 ok; 1 plan with zero length (cpp:69-71); 2 nothing left (cpp:130-132) */
+  int32_t status;         /* 0 ok; 1 plan with zero length (cpp:69-71); 2 nothing left (cpp:130-132); 3 the robot's
+                             footprint cost is 255 (cpp:234-236: the plugin throws, no optimizer request is made --
+                             carrot and look-ahead distance are filled in as for status 0, slow_down is updated like
+                             cpp:221-232 did before the throw, problems[i].skip is set) */
   int32_t reserved;
 } neo_mpc_carrot;
 
@@ -214,13 +245,19 @@ typedef struct neo_mpc_handle neo_mpc_handle;
 
 /* library / ABI */
 int neo_mpc_abi_version(void);
+int neo_mpc_behaviour_version(void);   /* NEO_MPC_BEHAVIOUR_VERSION of the library that answers */
 const char* neo_mpc_last_error(void);
 
 /* Fills the defaults the reference node declares (py:49-75) and this build's solver options. */
 int neo_mpc_default_params(neo_mpc_params* params);
 
 /* Replaces `MpcOptimizationServer.__init__` (py:45-152) + the service client creation at
- * cpp:308.  `device` is the HIP device ordinal.  NULL on failure. */
+ * cpp:308.  `device` is the HIP device ordinal.  NULL on failure.
+ * The A/B switches of the measurement tools are environment variables READ HERE, ONCE (never on the solve path; a tool
+ * that flips one re-creates its handle): NEO_MPC_SOLVE_WAVES=2|3|4, NEO_MPC_GENERIC_STEPS, NEO_MPC_NO_TAME_SPECIALISATION,
+ * NEO_MPC_DYNAMIC_LDS (kernel variant), NEO_MPC_NO_EARLY (Newton step tests off), NEO_MPC_INGEST_CHUNKS=n (K3),
+ * NEO_MPC_NO_CHUNKS (large staged host batches in one piece), NEO_MPC_HOST_PATH=staged|zerocopy|zerocopy_out (what
+ * NEO_MPC_HOST_PATH_AUTO means).  None changes a result beyond rounding. */
 neo_mpc_handle* neo_mpc_create(const neo_mpc_params* params, int device);
 void neo_mpc_destroy(neo_mpc_handle* handle);
 
@@ -281,8 +318,8 @@ int neo_mpc_solve_batch_wait(neo_mpc_handle* handle, uint32_t ticket);
 int neo_mpc_pin_host_memory(void* ptr, size_t bytes);
 int neo_mpc_unpin_host_memory(void* ptr);
 /* How neo_mpc_solve_batch moves a batch whose arrays are all page-locked (pageable arrays are always staged). */
-#define NEO_MPC_HOST_PATH_AUTO 0          /* = ZEROCOPY (the environment variable NEO_MPC_HOST_PATH=staged|zerocopy|
-                                             zerocopy_out overrides AUTO, for A/B runs) */
+#define NEO_MPC_HOST_PATH_AUTO 0          /* = ZEROCOPY (NEO_MPC_HOST_PATH=staged|zerocopy|zerocopy_out in the environment
+                                             of neo_mpc_create overrides what AUTO means, for A/B runs) */
 #define NEO_MPC_HOST_PATH_STAGED 1        /* copies into device staging and back (DMA), as for pageable arrays */
 #define NEO_MPC_HOST_PATH_ZEROCOPY 2      /* the kernel reads and writes the caller's arrays in place */
 #define NEO_MPC_HOST_PATH_ZEROCOPY_OUT 3  /* inputs copied up by DMA, results written in place by the kernel */

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("NEO_MPC_LIB") or os.path.join(HERE, "libneo_mpc.so")
 
 #: every symbol include/neo_mpc.h declares
 EXPORTS = (
-    "neo_mpc_abi_version", "neo_mpc_last_error", "neo_mpc_default_params", "neo_mpc_create",
+    "neo_mpc_abi_version", "neo_mpc_behaviour_version", "neo_mpc_last_error", "neo_mpc_default_params", "neo_mpc_create",
     "neo_mpc_destroy", "neo_mpc_set_params", "neo_mpc_get_params", "neo_mpc_set_costmap",
     "neo_mpc_set_costmap_device", "neo_mpc_set_costmap_pool", "neo_mpc_set_costmap_pool_device", "neo_mpc_solve_batch", "neo_mpc_solve_batch_device",
     "neo_mpc_solve_batch_device_timed", "neo_mpc_solve_batch_begin", "neo_mpc_solve_batch_wait",
@@ -87,10 +87,17 @@ def load():
     lib.neo_mpc_unpin_host_memory.argtypes = [C.c_void_p]
     lib.neo_mpc_set_host_path.argtypes = [C.c_void_p, C.c_int]
     lib.neo_mpc_kernel_info.argtypes = [C.c_void_p, P(C.c_uint32), P(C.c_uint32), P(C.c_uint32)]
-    for name in EXPORTS:
-        getattr(lib, name)     # AttributeError here = the .so is older than include/neo_mpc.h
-    if lib.neo_mpc_abi_version() != 1:
-        raise ImportError("libneo_mpc.so ABI version mismatch")
+    if os.environ.get("NEO_MPC_LIB"):
+        # development A/B against an older build of the same library (tools/ab_libs.sh): the record layouts have not
+        # changed since ABI 1, so only the entry points a tool actually calls have to exist
+        if lib.neo_mpc_abi_version() not in (1, abi.ABI_VERSION):
+            raise ImportError("%s: ABI version %d" % (LIB_PATH, lib.neo_mpc_abi_version()))
+    else:
+        for name in EXPORTS:
+            getattr(lib, name)     # AttributeError here = the .so is older than include/neo_mpc.h
+        if lib.neo_mpc_abi_version() != abi.ABI_VERSION:
+            raise ImportError("libneo_mpc.so ABI version %d, this package binds %d" % (lib.neo_mpc_abi_version(), abi.ABI_VERSION))
+        lib.neo_mpc_behaviour_version.restype = C.c_int
     _lib = lib
     return lib
 

@@ -23,7 +23,9 @@ PROBLEM_DTYPE = np.dtype([
                                     # no polygon is supplied (py:262, 343)
     ("map_index", "<i4"),           # which costmap of a pool (BatchSolver.set_costmap_pool); else ignored
     ("switch_opt", "<i4"),          # request.switch_opt (cpp:245; stored py:354, never read)
-    ("reserved", "<f8", (6,)),
+    ("skip", "<i4"),                # != 0: no request is made for this robot this tick (cpp:234-236); state untouched
+    ("reserved_i", "<i4"),
+    ("reserved", "<f8", (5,)),
 ], align=False)
 assert PROBLEM_DTYPE.itemsize == 256
 
@@ -66,6 +68,11 @@ STATUS_MAX_ITER = 1
 
 FLAG_RESET = 1
 FLAG_STOPPED = 2
+FLAG_SKIPPED = 4
+
+ABI_VERSION = 2          # NEO_MPC_ABI_VERSION of include/neo_mpc.h
+COMPAT_ODOM_YAW_GOAL_W = 1
+COMPAT_REFERENCE_START = 2
 
 
 def new_states(count, control_steps, waiting_time=3.0):

@@ -98,6 +98,11 @@ struct neo_mpc_handle {
   struct MapUser { hipStream_t stream; hipEvent_t done; bool pending; };
   std::vector<MapUser> map_users;
   int host_path = NEO_MPC_HOST_PATH_AUTO;   // neo_mpc_set_host_path
+  // the environment's A/B switches, read once by neo_mpc_create (include/neo_mpc.h)
+  LaunchTuning tuning;
+  bool no_early = false;      // NEO_MPC_NO_EARLY: the Newton step tests of K1 are off
+  bool no_chunks = false;     // NEO_MPC_NO_CHUNKS: large staged host batches go through in one piece
+  int auto_host_path = NEO_MPC_HOST_PATH_ZEROCOPY;   // what NEO_MPC_HOST_PATH_AUTO means (NEO_MPC_HOST_PATH)
   // neo_mpc_solve_batch_begin / _wait: page-locked batches in flight, each on a stream of its own
   struct InFlight { hipStream_t stream = nullptr; hipEvent_t done = nullptr; bool busy = false; };
   InFlight in_flight[NEO_MPC_MAX_BATCHES_IN_FLIGHT];
@@ -134,6 +139,15 @@ int validate(const neo_mpc_params& p) {
                 p.control_steps);
   if (p.lbfgs_memory > NEO_MPC_MAX_LBFGS_MEMORY)
     return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "lbfgs_memory > %d", NEO_MPC_MAX_LBFGS_MEMORY);
+  if (p.compat_flags & ~NEO_MPC_COMPAT_ALL)
+    return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "unknown compat_flags bits 0x%x (known: 0x%x)", p.compat_flags & ~NEO_MPC_COMPAT_ALL,
+                NEO_MPC_COMPAT_ALL);
+  // no selectable configuration is knowingly worse than the reference: the L-BFGS and the dense Newton direction have no
+  // wall model for costmap steps, and forced onto a heavy costmap weight they end above SLSQP on a few percent of the
+  // costmap cases (G8 "turn": up to 1.0 at control_steps 8; G9: 2 of 48 up to 4e-3) -- AUTO never sends them there
+  if ((p.method == NEO_MPC_METHOD_LBFGS || p.method == NEO_MPC_METHOD_NEWTON) && p.w_costmap > 0.25 * p.w_trans)
+    return fail(NEO_MPC_ERR_UNSUPPORTED, "method %d has no wall model for costmap steps: not offered with w_costmap > w_trans / 4 "
+                "(%g > %g); use NEO_MPC_METHOD_AUTO or NEO_MPC_METHOD_RICCATI", p.method, p.w_costmap, 0.25 * p.w_trans);
   return NEO_MPC_OK;
 }
 
@@ -164,13 +178,14 @@ void derive(neo_mpc_handle* h) {
   d.acc[0] = p.acc_x_limit; d.acc[1] = p.acc_y_limit; d.acc[2] = p.acc_theta_limit;
   d.low_pass_gain = p.low_pass_gain;
   d.xtol = p.step_tolerance > 0.0 ? p.step_tolerance : 1e-3 * p.opt_tolerance;
-  d.kink_radius = p.kink_radius > 0.0 ? p.kink_radius : 3e-3;
+  // (set below, once the search direction is known)
   d.stall_step = p.stall_step > 0.0 ? p.stall_step : 0.3 * p.opt_tolerance;
   d.hop_min_drop = 0.1 * p.opt_tolerance;
   d.hop_range = h->has_map ? fmin(0.25, 0.05 * d.dt / h->map.resolution) : 0.25;
   d.max_it = p.max_iterations > 0 ? p.max_iterations : 100;
   d.mem = p.lbfgs_memory > 0 ? p.lbfgs_memory : 4;
-  d.compat = (p.compat_flags & 0xffff) | (getenv("NEO_MPC_NO_UNSHIFT") ? kCompatNoUnshift : 0);
+  d.compat = (p.compat_flags & NEO_MPC_COMPAT_ODOM_YAW_GOAL_W) |
+             ((p.compat_flags & NEO_MPC_COMPAT_REFERENCE_START) ? kCompatNoUnshift : 0);
   d.disc_in_box = (p.min_vel_x <= -p.max_vel_trans && p.max_vel_x >= p.max_vel_trans &&
                    p.min_vel_y <= -p.max_vel_trans && p.max_vel_y >= p.max_vel_trans) ? 1 : 0;
   d.tame = (d.disc_in_box && fmax(fabs(p.min_vel_theta), fabs(p.max_vel_theta)) * p.prediction_horizon <= 0.78) ? 1 : 0;
@@ -185,8 +200,13 @@ void derive(neo_mpc_handle* h) {
              : p.method == NEO_MPC_METHOD_NEWTON ? 1
              : p.method == NEO_MPC_METHOD_RICCATI ? 2
              : (n == 3 && !heavy_costmap ? 1 : 2);
-  d.early_tol = getenv("NEO_MPC_NO_EARLY") ? 0.0 : d.xtol;
-  d.final_tol = getenv("NEO_MPC_NO_EARLY") ? 0.0 : (p.step_tolerance > 0.0 ? p.step_tolerance : p.opt_tolerance);
+  // blocks closer to the control norm's kink than this are left to the proximal step alone.  The stage-wise direction
+  // predicts landings on the kink inside its sweep (riccati.h), so its zone is small; the dense and the L-BFGS
+  // direction have no such prediction and keep round 1's radius (warm-started ticks against the converged reference, G11:
+  // control_steps 8 at 3e-3: 2 of 407 commands more than 1e-3 away, at 1e-4 none)
+  d.kink_radius = p.kink_radius > 0.0 ? p.kink_radius : d.newton == 2 ? 1e-4 : 3e-3;
+  d.early_tol = h->no_early ? 0.0 : d.xtol;
+  d.final_tol = h->no_early ? 0.0 : (p.step_tolerance > 0.0 ? p.step_tolerance : p.opt_tolerance);
   // Beyond 3 control steps the objective is flatter per block (the weights are divided by N, and two neighbouring
   // blocks of a long horizon can trade displacement at almost no cost): the gain thresholds of the Newton
   // directions shrink with (3/N)^2 (the three-iteration window with (3/N)^3) -- measured on 1024 zero-costmap problems against solves run to the end
@@ -233,6 +253,17 @@ void derive(neo_mpc_handle* h) {
   l.total_bytes = (l.total_bytes + 15) & ~15;
 }
 
+// The term table and the pool's origins are read by every K1 wave as it starts: before either is rewritten (blocking
+// copies on the null stream, which do not order against the non-blocking streams batches are in flight on) every launch
+// that may still read them is waited for -- the events map_release recorded, one per stream.  (The device map itself is
+// ordered by stream waits in ingest(); these two small tables change on reconfiguration / pool re-centring only, so a
+// host-side wait is cheap.)
+int wait_map_users(neo_mpc_handle* h) {
+  for (auto& u : h->map_users)
+    if (u.pending) HIP_TRY(hipEventSynchronize(u.done));
+  return NEO_MPC_OK;
+}
+
 int upload_term_table(neo_mpc_handle* h) {
   double table[256];
   const neo_mpc_params& p = h->params;
@@ -242,8 +273,9 @@ int upload_term_table(neo_mpc_handle* h) {
     const double cc = c * c;                           // py:247
     table[raw] = (c == 1.0) ? cc * 1000 / n : p.w_costmap * cc / n;  // py:257-260
   }
-  int rc = h->term_buf.reserve(sizeof(table));
+  int rc = wait_map_users(h);   // (a batch in flight reads the old table to its end)
   if (rc) return rc;
+  if ((rc = h->term_buf.reserve(sizeof(table)))) return rc;
   HIP_TRY(hipMemcpy(h->term_buf.ptr, table, sizeof(table), hipMemcpyHostToDevice));
   return NEO_MPC_OK;
 }
@@ -285,7 +317,7 @@ int ingest(neo_mpc_handle* h, const uint8_t* d_cells, uint32_t maps, uint32_t sx
   a.dst = (uint8_t*)h->map_buf.ptr;
   a.size_x = (int)sx; a.size_y = (int)sy; a.pitch = pitch; a.rows = rows;
   a.maps = (int)maps; a.border = border; a.dst_stride = (int64_t)stride;
-  launch_ingest(a, stream);
+  launch_ingest(a, h->tuning, stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(h->map_ready, st));
   h->map_ready_stream = st;
@@ -416,6 +448,7 @@ int stage_out(neo_mpc_handle* h, const neo_mpc_batch* b, bool solution_is_output
 extern "C" {
 
 int neo_mpc_abi_version(void) { return NEO_MPC_ABI_VERSION; }
+int neo_mpc_behaviour_version(void) { return NEO_MPC_BEHAVIOUR_VERSION; }
 
 const char* neo_mpc_last_error(void) { return g_error.c_str(); }
 
@@ -459,6 +492,20 @@ neo_mpc_handle* neo_mpc_create(const neo_mpc_params* params, int device) {
   neo_mpc_handle* h = new (std::nothrow) neo_mpc_handle();
   if (!h) { fail(NEO_MPC_ERR_DEVICE, "out of host memory"); return nullptr; }
   h->device = device;
+  {  // the A/B switches of the measurement tools: the only place the library looks at the environment
+    const char* e = getenv("NEO_MPC_SOLVE_WAVES");
+    h->tuning.solve_waves = (e && atoi(e) >= 2 && atoi(e) <= 4) ? atoi(e) : 0;
+    h->tuning.generic_steps = getenv("NEO_MPC_GENERIC_STEPS") != nullptr;
+    h->tuning.no_tame = getenv("NEO_MPC_NO_TAME_SPECIALISATION") != nullptr;
+    h->tuning.dynamic_lds = getenv("NEO_MPC_DYNAMIC_LDS") != nullptr;
+    e = getenv("NEO_MPC_INGEST_CHUNKS");
+    h->tuning.ingest_chunks = e ? atoi(e) : 0;
+    h->no_early = getenv("NEO_MPC_NO_EARLY") != nullptr;
+    h->no_chunks = getenv("NEO_MPC_NO_CHUNKS") != nullptr;
+    e = getenv("NEO_MPC_HOST_PATH");
+    h->auto_host_path = !e ? NEO_MPC_HOST_PATH_ZEROCOPY : !strcmp(e, "staged") ? NEO_MPC_HOST_PATH_STAGED
+                        : !strcmp(e, "zerocopy_out") ? NEO_MPC_HOST_PATH_ZEROCOPY_OUT : NEO_MPC_HOST_PATH_ZEROCOPY;
+  }
   if (apply_params(h, params) != NEO_MPC_OK) { neo_mpc_destroy(h); return nullptr; }
   return h;
 }
@@ -534,6 +581,7 @@ int neo_mpc_set_costmap_pool(neo_mpc_handle* h, const uint8_t* cells, uint32_t c
   const size_t bytes = (size_t)sx * sy * count;
   int rc = h->raw_buf.reserve(bytes);
   if (rc) return rc;
+  if ((rc = wait_map_users(h))) return rc;   // (batches in flight pair the old origins with the old cells to their end)
   if ((rc = h->origins_buf.reserve((size_t)count * 16))) return rc;
   HIP_TRY(hipMemcpy(h->raw_buf.ptr, cells, bytes, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->origins_buf.ptr, origins, (size_t)count * 16, hipMemcpyHostToDevice));
@@ -548,7 +596,7 @@ int neo_mpc_solve_batch_device_timed(neo_mpc_handle* h, const neo_mpc_batch* bat
   if (rc) return rc;
   HIP_TRY(hipSetDevice(h->device));  // the stream and the buffers must belong to the handle's device
   if ((rc = map_acquire(h, stream))) return rc;
-  launch_solve(a, stream, start_event, stop_event);
+  launch_solve(a, h->tuning, stream, start_event, stop_event);
   HIP_TRY(hipGetLastError());
   return map_release(h, stream);
 }
@@ -586,7 +634,7 @@ static int solve_batch_latency_path(neo_mpc_handle* h, const neo_mpc_batch* b) {
   SolveArgs a;
   if ((rc = fill_args(h, &d, a))) return rc;
   if ((rc = map_acquire(h, nullptr))) return rc;
-  launch_solve(a, nullptr);
+  launch_solve(a, h->tuning, nullptr);
   HIP_TRY(hipGetLastError());
   if ((rc = map_release(h, nullptr))) return rc;
   HIP_TRY(hipMemcpyAsync(pin + o_state, dev + o_state, o_end - o_state, hipMemcpyDeviceToHost, nullptr));
@@ -602,11 +650,20 @@ static int solve_batch_latency_path(neo_mpc_handle* h, const neo_mpc_batch* b) {
 
 // Is `p` page-locked host memory the device can address (hipHostMalloc / hipHostRegister / neo_mpc_pin_host_memory /
 // torch pin_memory)?  -> its device-side address.
-static bool pinned_host(const void* p, void** dev) {
+static bool pinned_host(const void* p, size_t bytes, void** dev) {
   hipPointerAttribute_t at;
   if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // (unregistered memory: an error before ROCm 6)
   if (at.type != hipMemoryTypeHost || !at.devicePointer) return false;
   *dev = at.devicePointer;
+  if (bytes > 1) {
+    // ... to its LAST byte (a registered prefix of an arena, or count * stride beyond the pinned range, would fault on the
+    // GPU instead of falling back to staging), and as ONE mapping: the device-side addresses are as far apart as the host's
+    hipPointerAttribute_t last;
+    const char* end = static_cast<const char*>(p) + bytes - 1;
+    if (hipPointerGetAttributes(&last, end) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (last.type != hipMemoryTypeHost || !last.devicePointer) return false;
+    if (static_cast<const char*>(last.devicePointer) - static_cast<const char*>(at.devicePointer) != (ptrdiff_t)(bytes - 1)) return false;
+  }
   return true;
 }
 
@@ -617,17 +674,11 @@ static bool pinned_host(const void* p, void** dev) {
 //             waves compute.  One launch, one wait.
 //  kZeroCopyOut  the inputs go up as three DMA copies into device staging, the results are written straight into the
 //             caller's arrays by K1 (no D2H copies).
-// NEO_MPC_HOST_PATH=staged|zerocopy|zerocopy_out overrides the default for A/B runs.
+// NEO_MPC_HOST_PATH=staged|zerocopy|zerocopy_out in the environment of neo_mpc_create overrides what AUTO means (A/B runs).
 enum HostPath { kStaged = NEO_MPC_HOST_PATH_STAGED, kZeroCopy = NEO_MPC_HOST_PATH_ZEROCOPY,
                 kZeroCopyOut = NEO_MPC_HOST_PATH_ZEROCOPY_OUT };
 static HostPath host_path_mode(const neo_mpc_handle* h) {
-  if (h->host_path != NEO_MPC_HOST_PATH_AUTO) return (HostPath)h->host_path;
-  static int mode = -1;
-  if (mode < 0) {
-    const char* e = getenv("NEO_MPC_HOST_PATH");
-    mode = !e ? kZeroCopy : !strcmp(e, "staged") ? kStaged : !strcmp(e, "zerocopy_out") ? kZeroCopyOut : kZeroCopy;
-  }
-  return (HostPath)mode;
+  return (HostPath)(h->host_path != NEO_MPC_HOST_PATH_AUTO ? h->host_path : h->auto_host_path);
 }
 
 static int solve_batch_zero_copy(neo_mpc_handle* h, const neo_mpc_batch* b, const neo_mpc_batch& dev, HostPath mode) {
@@ -650,22 +701,26 @@ static int solve_batch_zero_copy(neo_mpc_handle* h, const neo_mpc_batch* b, cons
   if ((rc = fill_args(h, &d, a))) return bail(rc);
   a.states_out = dev.states; a.warm_out = dev.warm_start;
   if ((rc = map_acquire(h, nullptr))) return bail(rc);
-  launch_solve(a, nullptr);
+  launch_solve(a, h->tuning, nullptr);
   if (hipGetLastError() != hipSuccess) return bail(fail(NEO_MPC_ERR_DEVICE, "kernel launch failed"));
   if ((rc = map_release(h, nullptr))) return bail(rc);
   HIP_TRY(hipStreamSynchronize(nullptr));   // kernel end = system-scope release: the results are in the caller's arrays
   return NEO_MPC_OK;
 }
 
-// Is every array of the host batch page-locked?  -> `dv`: the batch with the device-side addresses of the arrays.
-static bool batch_page_locked(const neo_mpc_batch* batch, neo_mpc_batch& dv) {
+// Is every array of the host batch page-locked over its whole extent?  -> `dv`: the batch with the device-side addresses.
+static bool batch_page_locked(const neo_mpc_handle* h, const neo_mpc_batch* batch, neo_mpc_batch& dv) {
   dv = *batch;
-  bool all = pinned_host(batch->problems, (void**)&dv.problems) && pinned_host(batch->states, (void**)&dv.states) &&
-             pinned_host(batch->warm_start, (void**)&dv.warm_start) && pinned_host(batch->commands, (void**)&dv.commands);
-  if (all && batch->solution) all = pinned_host(batch->solution, (void**)&dv.solution);
-  if (all && batch->predicted_path) all = pinned_host(batch->predicted_path, (void**)&dv.predicted_path);
-  if (all && batch->velocities) all = pinned_host(batch->velocities, (void**)&dv.velocities);
-  if (all && batch->footprints && batch->footprint_points) all = pinned_host(batch->footprints, (void**)&dv.footprints);
+  const size_t n = batch->count, nv = 3 * (size_t)h->params.control_steps;
+  bool all = pinned_host(batch->problems, n * sizeof(neo_mpc_problem), (void**)&dv.problems) &&
+             pinned_host(batch->states, n * sizeof(neo_mpc_state), (void**)&dv.states) &&
+             pinned_host(batch->warm_start, n * nv * 8, (void**)&dv.warm_start) &&
+             pinned_host(batch->commands, n * sizeof(neo_mpc_command), (void**)&dv.commands);
+  if (all && batch->solution) all = pinned_host(batch->solution, n * nv * 8, (void**)&dv.solution);
+  if (all && batch->predicted_path) all = pinned_host(batch->predicted_path, n * nv * 8, (void**)&dv.predicted_path);
+  if (all && batch->velocities) all = pinned_host(batch->velocities, n * 24, (void**)&dv.velocities);
+  if (all && batch->footprints && batch->footprint_points)
+    all = pinned_host(batch->footprints, n * batch->footprint_points * 16, (void**)&dv.footprints);
   return all;
 }
 
@@ -716,7 +771,7 @@ static int solve_batch_staged_chunks(neo_mpc_handle* h, const neo_mpc_batch* b) 
     int r = fill_args(h, &d, a);
     if (r) return r;
     if ((r = map_acquire(h, st))) return r;
-    launch_solve(a, st);
+    launch_solve(a, h->tuning, st);
     if (hipGetLastError() != hipSuccess) return fail(NEO_MPC_ERR_DEVICE, "kernel launch failed");
     return map_release(h, st);
   };
@@ -754,9 +809,9 @@ int neo_mpc_solve_batch(neo_mpc_handle* h, const neo_mpc_batch* batch) {
   if (host_path_mode(h) != kStaged) {
     // page-locked arrays throughout (a fleet server's request arena): K1 works on them in place
     neo_mpc_batch dv;
-    if (batch_page_locked(batch, dv)) return solve_batch_zero_copy(h, batch, dv, host_path_mode(h));
+    if (batch_page_locked(h, batch, dv)) return solve_batch_zero_copy(h, batch, dv, host_path_mode(h));
   }
-  if (batch->count >= kChunkedMinCount && !(batch->footprints && batch->footprint_points) && !getenv("NEO_MPC_NO_CHUNKS"))
+  if (batch->count >= kChunkedMinCount && !(batch->footprints && batch->footprint_points) && !h->no_chunks)
     return solve_batch_staged_chunks(h, batch);
   neo_mpc_batch d;
   // (the staging copies are asynchronous: no way out of here while one may still be reading the caller's buffers)
@@ -764,7 +819,7 @@ int neo_mpc_solve_batch(neo_mpc_handle* h, const neo_mpc_batch* batch) {
   if ((rc = stage_in(h, batch, d, false))) return bail(rc);
   if ((rc = fill_args(h, &d, a))) return bail(rc);
   if ((rc = map_acquire(h, nullptr))) return bail(rc);
-  launch_solve(a, nullptr);
+  launch_solve(a, h->tuning, nullptr);
   if (hipGetLastError() != hipSuccess) return bail(fail(NEO_MPC_ERR_DEVICE, "kernel launch failed"));
   if ((rc = map_release(h, nullptr))) return bail(rc);
   return bail(stage_out(h, batch, true));   // (queued behind the kernel on the null stream, one wait at the end)
@@ -784,7 +839,7 @@ int neo_mpc_solve_batch_begin(neo_mpc_handle* h, const neo_mpc_batch* batch, uin
   if (batch->count == 0) return NEO_MPC_OK;   // (ticket 0: nothing to wait for)
   HIP_TRY(hipSetDevice(h->device));
   neo_mpc_batch dv;
-  if (!batch_page_locked(batch, dv))
+  if (!batch_page_locked(h, batch, dv))
     return fail(NEO_MPC_ERR_UNSUPPORTED, "neo_mpc_solve_batch_begin works on page-locked arrays in place: pin the batch's "
                 "arrays (neo_mpc_pin_host_memory) or call neo_mpc_solve_batch");
   neo_mpc_handle::InFlight* slot = nullptr;
@@ -793,14 +848,18 @@ int neo_mpc_solve_batch_begin(neo_mpc_handle* h, const neo_mpc_batch* batch, uin
     if (!h->in_flight[k].busy) { slot = &h->in_flight[k]; index = k; break; }
   if (!slot) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "%d batches in flight already: wait for one", NEO_MPC_MAX_BATCHES_IN_FLIGHT);
   if (!slot->stream) HIP_TRY(hipStreamCreateWithFlags(&slot->stream, hipStreamNonBlocking));
-  if (!slot->done) HIP_TRY(hipEventCreateWithFlags(&slot->done, hipEventDisableTiming));
+  // (system-scope release: the results are visible to the host after hipEventSynchronize also in non-coherent pinned
+  // memory -- hipHostMallocNonCoherent, HIP_HOST_COHERENT=0)
+  if (!slot->done) HIP_TRY(hipEventCreateWithFlags(&slot->done, hipEventDisableTiming | hipEventReleaseToSystem));
   if ((rc = fill_args(h, &dv, a))) return rc;
   a.states_out = dv.states; a.warm_out = dv.warm_start;
   if ((rc = map_acquire(h, slot->stream))) return rc;
-  launch_solve(a, slot->stream);
-  HIP_TRY(hipGetLastError());
-  if ((rc = map_release(h, slot->stream))) { (void)hipStreamSynchronize(slot->stream); return rc; }
-  HIP_TRY(hipEventRecord(slot->done, slot->stream));
+  launch_solve(a, h->tuning, slot->stream);
+  // from here on a kernel may be writing the caller's arrays: no way out without a ticket unless it has been waited for
+  auto bail = [&](int code) { (void)hipStreamSynchronize(slot->stream); return code; };
+  if (hipGetLastError() != hipSuccess) return bail(fail(NEO_MPC_ERR_DEVICE, "kernel launch failed"));
+  if ((rc = map_release(h, slot->stream))) return bail(rc);
+  if (hipEventRecord(slot->done, slot->stream) != hipSuccess) return bail(fail(NEO_MPC_ERR_DEVICE, "hipEventRecord failed"));
   slot->busy = true;
   *ticket = index + 1;
   return NEO_MPC_OK;
@@ -943,7 +1002,7 @@ static int hook_batch(neo_mpc_handle* h, const neo_mpc_problem* problems, const 
   a.p.max_it = max_it;
   HIP_TRY(hipMemset(h->solution.ptr, 0xFF, count * nv * 8));   // NaN rows for instances that stop before the dump
   if ((rc = map_acquire(h, nullptr))) return rc;
-  launch_solve(a, nullptr);
+  launch_solve(a, h->tuning, nullptr);
   HIP_TRY(hipGetLastError());
   if ((rc = map_release(h, nullptr))) return rc;
   HIP_TRY(hipMemcpy(grad_out, h->solution.ptr, count * nv * 8, hipMemcpyDeviceToHost));

@@ -11,7 +11,7 @@ constexpr int kLanes = 64;          // one CDNA4 wavefront per MPC instance
 constexpr int kMapBorder = 64;      // lethal border (cells) K3 adds around a single costmap
 constexpr int kPoolBorder = 16;     // ... around each map of a pool (every lookup is bounds-checked anyway)
 constexpr int kMaxTileWidth = 128;  // widest reach tile staged in LDS (bytes per row)
-constexpr int kCompatNoUnshift = 0x10000;   // DevParams.compat (internal bit): searches always start at the warm start (A/B: NEO_MPC_NO_UNSHIFT)
+constexpr int kCompatNoUnshift = 0x10000;   // DevParams.compat (internal bit): searches always start at the warm start (NEO_MPC_COMPAT_REFERENCE_START)
 constexpr int kDumpGradient = 0x40000000;  // DevParams.max_it value of the gradient test hook (neo_mpc_gradient_batch)
 
 // Constants of one solver configuration, precomputed on the host in float64 exactly as
@@ -182,10 +182,20 @@ struct CarrotArgs {
   neo_mpc_plan_batch b;  // device pointers
 };
 
-void launch_solve(const SolveArgs& a, void* stream, void* ev_start = nullptr, void* ev_stop = nullptr);
+// A/B switches of the measurement tools: read from the environment ONCE, by neo_mpc_create (include/neo_mpc.h), kept in
+// the handle -- nothing on the solve path looks at the environment.
+struct LaunchTuning {
+  int solve_waves = 0;         // NEO_MPC_SOLVE_WAVES=2|3|4: occupancy variant of K1 (0: what was measured fastest)
+  bool generic_steps = false;  // NEO_MPC_GENERIC_STEPS: the run-time-sized L-BFGS kernel at control_steps 3 too
+  bool no_tame = false;        // NEO_MPC_NO_TAME_SPECIALISATION: the general kernels for README-like parameters too
+  bool dynamic_lds = false;    // NEO_MPC_DYNAMIC_LDS: the dynamic-LDS build of the control_steps specialisations
+  int ingest_chunks = 0;       // NEO_MPC_INGEST_CHUNKS: 16-byte chunks per thread of K3 (0: kIngestUnroll)
+};
+
+void launch_solve(const SolveArgs& a, const LaunchTuning& t, void* stream, void* ev_start = nullptr, void* ev_stop = nullptr);
 void launch_carrots(const CarrotArgs& a, void* stream);
 void launch_postprocess(const SolveArgs& a, void* stream);
 void launch_objective(const ObjectiveArgs& a, void* stream);
-void launch_ingest(const IngestArgs& a, void* stream);
+void launch_ingest(const IngestArgs& a, const LaunchTuning& t, void* stream);
 
 }  // namespace neo_mpc

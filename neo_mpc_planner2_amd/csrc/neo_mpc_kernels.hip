@@ -54,6 +54,11 @@ namespace {
 constexpr int kStallIterations = 5;
 constexpr int kBlockedRun = 3;       // dense Newton: this many iterations in a row not won by a decent Newton step ...
 constexpr double kBlockedStep = 0.25;  // ... (a proximal lane, or a Newton step cut below this) arm the blocked-run stop rule
+constexpr double kFinalFracGaussNewton = 0.3;   // stage-wise direction without the second-order terms: a full step has to be this much shorter than opt_tolerance to be the last
+#ifndef NEO_EXIT_HOPS
+#define NEO_EXIT_HOPS 1
+#endif
+constexpr int kExitHops = NEO_EXIT_HOPS;         // dense Newton: hops tried where the search was about to end (each restart lengthens the slowest search of a launch)
 constexpr int kLateIteration = 20;   // from here on the three-iteration window is the control_steps-3 one (neo_mpc_capi.cpp)
 
 // Study build (make timing -> libneo_mpc_timing.so): shader-clock stamps at the phase boundaries of
@@ -158,6 +163,12 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   bool have_trig = false;  // ACS/ASN already hold sin/cos of the rollout at u
 
   load_records(a, L, b, lane);
+  // no request for this robot this tick (the plugin threw before its service call, cpp:234-236; K4 status 3): the node's
+  // state does not advance -- nothing but the flag is written
+  if (uniform_int(reinterpret_cast<const int*>(L + a.lds.prob)[PI_SKIP]) != 0) {
+    if (lane == 0) a.commands[b].flags = NEO_MPC_FLAG_SKIPPED;
+    return;
+  }
   select_map(a.map, L + a.lds.prob);
   int flags = reset_and_warm(a, L, b, lane) ? NEO_MPC_FLAG_RESET : 0;
   const double fcost = footprint_cost(a, L, b, lane);
@@ -204,6 +215,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   double* ARX = L + a.lds.rx;
   double* ARY = L + a.lds.ry;
   double* ART = L + a.lds.rt;
+  float* ARTF = reinterpret_cast<float*>(L + a.lds.rt);   // Riccati: [2 i] disc curvature lambda / r of block i, [2 i + 1] tau x SX_i (riccati.h)
   double* ANX = L + a.lds.nx;
   double* ANY = L + a.lds.ny;
   int* AMODE = reinterpret_cast<int*>(L + a.lds.mode);  // [4n]: mode, wfroz, near, near_prev
@@ -272,6 +284,8 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   }
   int npairs = 0, head = 0, nfev = 1, it = 0, status = NEO_MPC_STATUS_MAX_ITER, stall = 0;
   int blocked_run = 0;   // dense Newton: consecutive iterations not won by a decent Newton step
+  int nblocked = 1;      // consecutive iterations not won by a Newton step of at least half its length (or won by a hop)
+  int exit_hops = 0;     // dense Newton: hops taken at the point where the search was about to end
   double gain1 = INFINITY, gain2 = INFINITY;  // objective decrease of the previous two iterations
   bool final_step = false;
   const int lane_id = lane;
@@ -287,6 +301,8 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     // at 4 waves/SIMD, parks them in scratch -- recomputing them costs a few integer operations.
     int lane = lane_id;
     asm volatile("" : "+v"(lane));
+    // stage-wise direction: this iteration's sweep carries the second-order terms of the rollout step
+    const bool exact_step = kRiccati && nblocked == 0;
     // (same trick for the tolerance block: an opaque LDS offset keeps its loads inside the loop and in
     // the LDS address space -- a volatile pointer would turn them into flat loads with a full wait each)
     int tol_off = a.lds.tol;
@@ -294,6 +310,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     const double* TOL = L + tol_off;
     NEO_PHASE_DECL;
     NEO_PHASE(0);
+    bool stop = false;   // wave-uniform: one of the stop rules has fired (the exit block at the bottom of the loop)
     // ---- adjoint gradient of the tracking + terminal cost
     constexpr int kVars = 3 * kNwSteps;  // compile-time bound of the Newton system (= its size when kSteps > 0)
     const int nvr = kSteps ? kVars : nv;  // its size
@@ -398,6 +415,11 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
           raw_here = edge_stickiness(a, c, L, x, y, cs, sn, wxx, wxy, wyy, wlx, wly, has_hop, hop_x, hop_y);
           rs[RS_WXX] = (float)wxx; rs[RS_WXY] = (float)wxy; rs[RS_WYY] = (float)wyy;
           rs[RS_WLX] = (float)wlx; rs[RS_WLY] = (float)wly;
+          // position costates of this stage, for the second-order terms of the rollout step (riccati.h): only behind an
+          // iteration won by a decent Newton step (the model held there) -- far from the minimiser the exact Hessian is
+          // indefinite and the Gauss-Newton direction is the safer one
+          rs[RS_SY] = exact_step ? (float)SY : 0.0f;
+          ARTF[2 * lane + 1] = exact_step ? (float)SX : 0.0f;
         }
       }
       if (kRiccati) {
@@ -469,21 +491,14 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         t0 = g0 * sh; t1 = g1 * sh; t2 = g2 * sh;
       }
       if (!kRiccati) AMODE[4 * i + 3] = AMODE[4 * i + 2];   // (Riccati: slot 3 is its to-the-kink flag)
-      if (ne < TOL[T_KINK]) {  // next to the kink: prox-only block, outside the quasi-Newton model
-        gt[3 * i] = 0.0; gt[3 * i + 1] = 0.0; gt[3 * i + 2] = 0.0;
-        gr[3 * i] = 0.0; gr[3 * i + 1] = 0.0; gr[3 * i + 2] = 0.0;
-        // (2: exactly ON the kink with a smooth gradient inside the norm's subdifferential, |g_s| <= w_control/N --
-        // the block stays there under every proximal step: at rest, it does not hold up the Newton stop tests)
-        const int at_rest = (ne2 == 0.0 && g0 * g0 + g1 * g1 + g2 * g2 <= p.wc_n * p.wc_n) ? 2 : 1;
-        ANX[i] = 0.0; ANY[i] = 0.0; AMODE[4 * i] = 0; AMODE[4 * i + 1] = 0; AMODE[4 * i + 2] = at_rest;
-        if (kNewton) {
-#pragma unroll
-          for (int k = 0; k < kNewtonRecord; ++k) NB[kNewtonRecord * i + k] = 0.0f;  // P = 0: row/column of I
-        }
-        if (kRiccati) ART[i] = 0.0;
-        continue;
-      }
-      gt[3 * i] = t0; gt[3 * i + 1] = t1; gt[3 * i + 2] = t2;
+      // next to the kink: prox-only block, outside the quasi-Newton model.  Its SMOOTH gradient is reduced on the tangent
+      // cone below (same code path as every other block's total gradient) and written back to gs: the proximal step of
+      // such a block is taken on its face -- a component that pushes omega into its bound, or the velocity out of the
+      // disc, used to dominate the step's shrink factor and keep the block from landing on the kink (projection and prox
+      // do not commute).
+      const bool near = ne < TOL[T_KINK];
+      if (near) { t0 = g0; t1 = g1; t2 = g2; }
+      else { gt[3 * i] = t0; gt[3 * i + 1] = t1; gt[3 * i + 2] = t2; }
       const int wfroz = ((u2 <= p.lo[2] && t2 > 0.0) || (u2 >= p.hi[2] && t2 < 0.0)) ? 1 : 0;
       double r0 = t0, r1 = t1;
       // outward normals of the constraints active at u: slot 0 = vx bound, 1 = vy bound, 2 = disc
@@ -516,14 +531,34 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
             bestn = pn; mode = 1; mnx = nxk; mny = nyk; r0 = -px; r1 = -py; mslot = sk; mlam = dnk;     \
           }                                                                                            \
         }
+        // (the disc first: where a bound touches the disc with the same normal -- max_vel_x = max_vel_trans, README -- the
+        // slide is the disc's, with its curvature and without the corner stop of a bound slide)
+        NEO_TRY_SLIDE(2, v2, dn2, nx2, ny2, v0, nx0, ny0, v1, nx1, ny1)
         NEO_TRY_SLIDE(0, v0, dn0, nx0, ny0, v1, nx1, ny1, v2, nx2, ny2)
         NEO_TRY_SLIDE(1, v1, dn1, nx1, ny1, v0, nx0, ny0, v2, nx2, ny2)
-        NEO_TRY_SLIDE(2, v2, dn2, nx2, ny2, v0, nx0, ny0, v1, nx1, ny1)
 #undef NEO_TRY_SLIDE
         if (mode == 2) { r0 = 0.0; r1 = 0.0; }
       }
+      if (near) {
+        const double s2 = wfroz ? 0.0 : t2;
+        gs[3 * i] = r0; gs[3 * i + 1] = r1; gs[3 * i + 2] = s2;
+        gt[3 * i] = 0.0; gt[3 * i + 1] = 0.0; gt[3 * i + 2] = 0.0;
+        gr[3 * i] = 0.0; gr[3 * i + 1] = 0.0; gr[3 * i + 2] = 0.0;
+        // (2: exactly ON the kink with a REDUCED smooth gradient inside the norm's subdifferential, |g_s| <= w_control/N --
+        // the block stays there under every proximal step: at rest, it does not hold up the Newton stop tests)
+        const int at_rest = (ne2 == 0.0 && r0 * r0 + r1 * r1 + s2 * s2 <= p.wc_n * p.wc_n) ? 2 : 1;
+        ANX[i] = 0.0; ANY[i] = 0.0; AMODE[4 * i] = 0; AMODE[4 * i + 1] = 0; AMODE[4 * i + 2] = at_rest;
+        if (kNewton) {
+#pragma unroll
+          for (int k = 0; k < kNewtonRecord; ++k) NB[kNewtonRecord * i + k] = 0.0f;  // P = 0: row/column of I
+        }
+        if (kRiccati) ARTF[2 * i] = 0.0f;
+        continue;
+      }
       gr[3 * i] = r0; gr[3 * i + 1] = r1; gr[3 * i + 2] = wfroz ? 0.0 : t2;
-      ANX[i] = mnx; ANY[i] = mny; AMODE[4 * i] = mode; AMODE[4 * i + 1] = wfroz; AMODE[4 * i + 2] = 0;
+      // (slot 1: omega frozen | 2 x "the slide is along the disc" -- a block sliding along a box bound stops at the corner
+      // where the bound meets the disc, feasible_set.h candidate_block)
+      ANX[i] = mnx; ANY[i] = mny; AMODE[4 * i] = mode; AMODE[4 * i + 1] = wfroz | ((mode == 1 && mslot == 2) ? 2 : 0); AMODE[4 * i + 2] = 0;
       if (kNewton) {
         // Block record of the Newton system, float32: the projector onto the tangent cone's face
         // (P00 P01 P11 PW) and the block's own curvature C (3x3): the control norm's Hessian
@@ -547,7 +582,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         nb[10] = c02; nb[11] = c12; nb[12] = c22;
       }
       // Riccati: curvature lambda/r of a binding disc (the rest of the block's record is made by riccati_prepare)
-      if (kRiccati) ART[i] = (mode == 1 && mslot == 2) ? mlam * rcp_fast(p.r) : 0.0;
+      if (kRiccati) ARTF[2 * i] = (mode == 1 && mslot == 2) ? (float)(mlam * rcp_fast(p.r)) : 0.0f;
     }
     WAVE_SYNC();
     NEO_PHASE(2);
@@ -755,7 +790,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       // projection of every candidate)
       for (int i = lane; i < n; i += kLanes) {  // restrict the direction to the tangent cone's face
         if (AMODE[4 * i + 2]) { d[3 * i] = 0.0; d[3 * i + 1] = 0.0; d[3 * i + 2] = 0.0; continue; }
-        if (AMODE[4 * i + 1]) d[3 * i + 2] = 0.0;
+        if (AMODE[4 * i + 1] & 1) d[3 * i + 2] = 0.0;
         const int mode = AMODE[4 * i];
         if (mode == 1) {
           const double dot = d[3 * i] * ANX[i] + d[3 * i + 1] * ANY[i];
@@ -782,12 +817,14 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       dm = wave_max_f(dm);
       const bool near_any = __ballot(anynear != 0) != 0ull;
       // (with a cheaper cell a hop away the search runs once more: its hop lanes decide)
-      if ((double)dm < TOL[T_EARLY] && !near_any && nhops == 0) { status = NEO_MPC_STATUS_CONVERGED; break; }
+      if ((double)dm < TOL[T_EARLY] && !near_any && nhops == 0) { status = NEO_MPC_STATUS_CONVERGED; stop = true; }
       // a full Newton step below opt_tolerance (SLSQP's own step test) is the last one: searched
       // and taken like any other, but nothing re-checks the point it lands on
-      if ((double)dm < TOL[T_FINAL] && !near_any) final_step = true;
+      // (a Gauss-Newton step converges linearly: it has to be shorter to be the last)
+      if ((double)dm < ((kRiccati && !exact_step) ? kFinalFracGaussNewton : 1.0) * TOL[T_FINAL] && !near_any) final_step = true;
     }
     NEO_PHASE(4);
+    if (!stop) {   // (closed in front of the exit block at the bottom of the loop)
     if (p.max_it > kDumpGradient && it == p.max_it - kDumpGradient - 1) {
       // test hook (neo_mpc_direction_batch): the search direction of lanes 32-63 in this iteration
       for (int k = lane; k < nv; k += kLanes) a.solution[(size_t)b * nv + k] = d[k];
@@ -863,7 +900,8 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     wave_argmin(fb, best);
     }
     ++nfev;
-    if (!(fb < f)) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
+    if (!(fb < f)) { status = NEO_MPC_STATUS_CONVERGED; ++it; stop = true; }
+    if (!stop) {   // (closed in front of the exit block at the bottom of the loop)
     float stepmax = 0.0f;
     if (kSteps && kNewton) {
       // the winner holds its candidate in registers: it measures the step against u and overwrites u
@@ -914,15 +952,22 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       stepmax = wave_max_f(stepmax);
     }
     const double gain = f - fb;
-    const double fscale = fmax(1.0, fabs(fb + TOL[T_KONST]));
+    // (gain thresholds are relative to the u-dependent part of the objective: inside the loop f excludes the constant
+    // terms -- the terminal distance term, py:266, can be 20 x the rest)
+    const double fscale = fmax(1.0, fabs(fb));
     stall = (gain <= TOL[T_FTOL] * fscale || (double)stepmax <= TOL[T_STALL]) ? stall + 1 : 0;
+    // stage-wise direction: the window and closing-in rules only judge runs of BLOCKED iterations (none of the three won
+    // by a Newton step of at least half its length); iterations won by the Newton step end through the step test
+    const bool hop_won = kRiccati && best >= 1 && best <= nhops;
+    nblocked = (best < 32 || lane_value(step, best) < 0.5 || hop_won) ? nblocked + 1 : 0;
+    const bool window_on = !kRiccati || nblocked >= 3;
     // three iterations that together gained less than wtol: creeping along a costmap cell edge
     const double wtol0 = TOL[T_WTOL];   // (the closing-in rule below is on whenever the window rule is)
     const double wtol = it >= kLateIteration ? TOL[T_WTOL_LATE] : wtol0;
-    bool creeping = wtol > 0.0 && gain + gain1 + gain2 <= wtol * fscale;
+    bool creeping = wtol > 0.0 && gain + gain1 + gain2 <= wtol * fscale && window_on;
     // ... and so does a step below stall_step whose gain halved twice in a row: the search is closing in on a
     // costmap cell edge (or the kink) geometrically; what is left to gain is less than the last gain
-    creeping = creeping || (wtol > 0.0 && (double)stepmax <= TOL[T_STALL] && gain <= 0.5 * gain1 && gain1 <= 0.5 * gain2);
+    creeping = creeping || (wtol0 > 0.0 && (double)stepmax <= TOL[T_STALL] && gain <= 0.5 * gain1 && gain1 <= 0.5 * gain2 && window_on);
     // Blocked-run stop rule (dense Newton).  kBlockedRun iterations in a row not won by a decent Newton step that
     // together gain less than 0.1 x opt_tolerance (0.03 x with no costmap term under the new iterate's rollout): something
     // the quadratic model does not see is in the way -- a costmap cell edge, or blocks hovering next to the control norm's
@@ -942,7 +987,6 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     gain2 = gain1; gain1 = gain;
     f = fb;
     // (a hop that won says nothing about step lengths: damping and proximal step stay as they are)
-    const bool hop_won = kRiccati && best >= 1 && best <= nhops;
     if (kRiccati && !(it == 0 && cold) && !hop_won) {   // (an iteration that had a Newton direction)
       const float bs = (float)lane_value(step, best);
       const double mu0 = n > 8 ? (double)(n - 8) * 0.125 : 0.0, mu = TOL[T_MU];
@@ -957,7 +1001,80 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     WAVE_SYNC();
     NEO_PHASE(6);
     NEO_PHASE_DUMP();
-    if ((double)stepmax < TOL[T_XTOL] || stall >= kStallIterations || creeping || final_step || blocked_stop) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
+    if ((double)stepmax < TOL[T_XTOL] || stall >= kStallIterations || creeping || final_step || blocked_stop) { status = NEO_MPC_STATUS_CONVERGED; ++it; stop = true; }
+    }   // if (!stop): accept + stop rules
+    }   // if (!stop): candidates
+    if (!stop) continue;
+    // ---- the search is about to end (wave-uniform).
+    // Dense direction: look once for a cheaper costmap cell a hop away -- the hop candidates the stage-wise direction tries
+    // in every iteration (costmap.h edge_stickiness).  A search that closed in on a cell edge from the expensive side ends
+    // a millimetre short of a cost step no descent direction sees (held-out parameter set "a", w_costmap / w_trans = 0.08:
+    // one such step is worth 2e-3, P3 failed on 1 of 24 cases).  A hop that lowers the objective is taken and the search
+    // goes on from there, at most kExitHops times per solve.
+    if (kNewton && exit_hops < kExitHops && it < p.max_it && !(c.tile_geom & kTileFree) && p.max_it < kDumpGradient) {
+      bool has_hop = false;
+      float hop_x = 0.0f, hop_y = 0.0f;
+      {
+        // lane i < n: position and heading of stage i at u
+        double x = 0.0, y = 0.0, th = 0.0, cs = 1.0, sn = 0.0;
+#pragma unroll
+        for (int k = 0; k < kNwSteps; ++k) {
+          if ((kSteps || k < n) && k <= lane) {
+            th += u[3 * k + 2] * p.dt;
+            sincos_heading<kTame>(th, &sn, &cs);
+            x += (u[3 * k] * cs - u[3 * k + 1] * sn) * p.dt;
+            y += (u[3 * k] * sn + u[3 * k + 1] * cs) * p.dt;
+          }
+        }
+        if (lane < n) {
+          double wxx, wxy, wyy, wlx, wly;
+          (void)edge_stickiness(a, c, L, x, y, cs, sn, wxx, wxy, wyy, wlx, wly, has_hop, hop_x, hop_y);
+        }
+      }
+      const unsigned long long hmask = __ballot(has_hop);
+      if (hmask != 0ull) {   // (wave-uniform)
+        const int rank = __popcll(hmask & ((1ull << lane) - 1ull));
+        double* t = L + a.lds.tol;
+        if (has_hop && rank < kHopLanes) {
+          reinterpret_cast<int*>(t + T_HOP_STAGE)[rank] = lane;
+          reinterpret_cast<float*>(t + T_HOP_VEC)[2 * rank] = hop_x;
+          reinterpret_cast<float*>(t + T_HOP_VEC)[2 * rank + 1] = hop_y;
+        }
+        const int nh = min(__popcll(hmask), (int)kHopLanes);
+        WAVE_SYNC();
+        // lane h < nh: the current point with the block of hop stage h changed
+        int hs = -1;
+        float hx = 0.0f, hy = 0.0f;
+        if (lane < nh) {
+          hs = reinterpret_cast<const int*>(t + T_HOP_STAGE)[lane];
+          hx = reinterpret_cast<const float*>(t + T_HOP_VEC)[2 * lane];
+          hy = reinterpret_cast<const float*>(t + T_HOP_VEC)[2 * lane + 1];
+        }
+        double hb0 = 0.0, hb1 = 0.0;
+        double fh = rollout_cost<kSteps, kTame>(
+            a, c, L,
+            [&](int i, double& b0, double& b1, double& b2) {
+              b0 = u[3 * i]; b1 = u[3 * i + 1]; b2 = u[3 * i + 2];
+              if (i == hs) { b0 += (double)hx; b1 += (double)hy; project_block<kTame>(p, b0, b1, b2); hb0 = b0; hb1 = b1; }
+            });
+        if (!(fh == fh) || lane >= nh) fh = INFINITY;
+        int hbest = lane;
+        wave_argmin(fh, hbest);
+        ++nfev;
+        WAVE_SYNC();
+        if (fh < f) {
+          if (lane == hbest) { u[3 * hs] = hb0; u[3 * hs + 1] = hb1; }
+          f = fh;
+          ++exit_hops;
+          status = NEO_MPC_STATUS_MAX_ITER; stall = 0; blocked_run = 0; final_step = false; gain1 = INFINITY; gain2 = INFINITY;
+          have_trig = false;
+          WAVE_SYNC();
+          --it;   // (the exit above has counted this iteration; the for statement counts again)
+          continue;
+        }
+      }
+    }
+    break;
   }
 
   NEO_SEGMENT(1);
@@ -983,6 +1100,10 @@ __global__ __launch_bounds__(kLanes) void k_postprocess(const SolveArgs args) {
   if (b >= a.count) return;
   const int nv = 3 * a.p.n;
   load_records(a, L, b, lane);
+  if (uniform_int(reinterpret_cast<const int*>(L + a.lds.prob)[PI_SKIP]) != 0) {   // (no request this tick: see k_solve)
+    if (lane == 0) a.commands[b].flags = NEO_MPC_FLAG_SKIPPED;
+    return;
+  }
   select_map(a.map, L + a.lds.prob);
   int flags = reset_and_warm(a, L, b, lane) ? NEO_MPC_FLAG_RESET : 0;
   const double fcost = footprint_cost(a, L, b, lane);
@@ -1133,7 +1254,7 @@ __global__ __launch_bounds__(kLanes) void k_carrot(const CarrotArgs a) {
   out.status = 0; out.reserved = 0;
   if (np == 0) {                                                        // cpp:69-71
     out.status = 1;
-    if (lane == 0) a.b.carrots[b] = out;
+    if (lane == 0) { a.b.carrots[b] = out; if (a.b.problems) a.b.problems[b].skip = 1; }   // (a throw: no request this tick)
     return;
   }
   // closest pose, first minimum (min_by, cpp:83-88)
@@ -1187,7 +1308,7 @@ __global__ __launch_bounds__(kLanes) void k_carrot(const CarrotArgs a) {
   out.begin = begin; out.end = end;
   if (end == begin) {                                                   // cpp:130-132
     out.status = 2;
-    if (lane == 0) a.b.carrots[b] = out;
+    if (lane == 0) { a.b.carrots[b] = out; if (a.b.problems) a.b.problems[b].skip = 1; }
     return;
   }
   out.lookahead_dist = la;
@@ -1201,6 +1322,10 @@ __global__ __launch_bounds__(kLanes) void k_carrot(const CarrotArgs a) {
   const double cy = fabs(atan2(2.0 * qc * qs, 1.0 - 2.0 * qs * qs));  // createYawFromQuat (cpp:54-62)
   slow = (cy >= 1.0 && a.b.footprint_costs && a.b.footprint_costs[b] > 200.0) ? 1 : 0;   // cpp:221-232
   out.slow_down = slow;
+  // cpp:234-236: a footprint cost of 255 makes the plugin throw here -- after the slow_down_ update, before the
+  // optimizer request: this robot makes no request this tick
+  const bool no_request = a.b.footprint_costs && a.b.footprint_costs[b] == 255.0;
+  if (no_request) out.status = 3;
   if (lane == 0) {
     a.b.carrots[b] = out;
     a.b.slow_down[b] = slow;
@@ -1208,6 +1333,8 @@ __global__ __launch_bounds__(kLanes) void k_carrot(const CarrotArgs a) {
       neo_mpc_problem* pr = a.b.problems + b;
       pr->carrot_xy[0] = out.xy[0]; pr->carrot_xy[1] = out.xy[1];
       pr->carrot_q[0] = 0.0; pr->carrot_q[1] = 0.0; pr->carrot_q[2] = qs; pr->carrot_q[3] = qc;
+      pr->switch_opt = out.closer_to_goal;   // cpp:245
+      pr->skip = no_request ? 1 : 0;
     }
   }
 }
@@ -1219,35 +1346,29 @@ __global__ __launch_bounds__(kLanes) void k_carrot(const CarrotArgs a) {
 // the Newton kernel needs 124 VGPRs and the generic kernel 118, both spill-free at 4 waves/SIMD; the
 // control_steps == 3 L-BFGS kernel needs 130 (3 waves/SIMD).  __launch_bounds__ pins the occupancy
 // each was measured at, so that a later edit cannot silently drop a wave per SIMD (it would spill
-// instead, which `make resource-usage` shows).  NEO_MPC_SOLVE_WAVES=2|3|4 overrides, for A/B runs.
-static int solve_variant(int fallback) {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("NEO_MPC_SOLVE_WAVES");
-    v = (e && atoi(e) >= 2 && atoi(e) <= 4) ? atoi(e) : 0;
-  }
-  return v ? v : fallback;
-}
+// instead, which `make resource-usage` shows).  NEO_MPC_SOLVE_WAVES=2|3|4 in the environment of neo_mpc_create overrides
+// (LaunchTuning), for A/B runs.
+static int solve_variant(const LaunchTuning& t, int fallback) { return t.solve_waves ? t.solve_waves : fallback; }
 
 // The Riccati variants of K1 live in a translation unit of their own (neo_mpc_riccati.hip = this file with
 // NEO_MPC_TU_RICCATI, compiled with -fno-slp-vectorize): the SLP vectoriser packs the sweep's float32
 // arithmetic into v_pk_* instructions and pays for it with three hundred register moves that assemble the
 // operand pairs (859 vector instructions in the sweep against 757 without it) -- measured +7 % solves/s at
 // control_steps 8 and +9 % at 32 without; the dense-Newton kernels are 0.5 % faster WITH it.
-void launch_solve_riccati(const SolveArgs& a, void* stream, void* ev_start, void* ev_stop);
+void launch_solve_riccati(const SolveArgs& a, const LaunchTuning& tuning, void* stream, void* ev_start, void* ev_stop);
 
 #ifdef NEO_MPC_TU_RICCATI
-void launch_solve_riccati(const SolveArgs& a, void* stream, void* ev_start, void* ev_stop) {
+void launch_solve_riccati(const SolveArgs& a, const LaunchTuning& tuning, void* stream, void* ev_start, void* ev_stop) {
 #else
-void launch_solve(const SolveArgs& a, void* stream, void* ev_start, void* ev_stop) {
+void launch_solve(const SolveArgs& a, const LaunchTuning& tuning, void* stream, void* ev_start, void* ev_stop) {
 #endif
   if (a.count == 0) return;
   const dim3 grid(a.count), block(kLanes);
   hipStream_t st = (hipStream_t)stream;
-  const bool generic = getenv("NEO_MPC_GENERIC_STEPS") != nullptr || a.p.mem != 4;  // A/B: LDS-only path
-  const bool disc = a.p.tame != 0 && getenv("NEO_MPC_NO_TAME_SPECIALISATION") == nullptr;
+  const bool generic = tuning.generic_steps || a.p.mem != 4;  // A/B: LDS-only path
+  const bool disc = a.p.tame != 0 && !tuning.no_tame;
   const size_t lds = a.lds.total_bytes;
-  const bool small_tile = a.lds.tile_w * a.lds.tile_h <= 1024 && getenv("NEO_MPC_DYNAMIC_LDS") == nullptr;
+  const bool small_tile = a.lds.tile_w * a.lds.tile_h <= 1024 && !tuning.dynamic_lds;
   // with events: hipExtLaunchKernel stamps them from the dispatch packet itself (no barrier packets in
   // front of and behind the kernel, which is what separate hipEventRecord calls put on the queue)
   hipEvent_t e0 = (hipEvent_t)ev_start, e1 = (hipEvent_t)ev_stop;
@@ -1268,31 +1389,31 @@ void launch_solve(const SolveArgs& a, void* stream, void* ev_start, void* ev_sto
     // 11.3 KB = 14 workgroups/CU: +9 %; with 12 workgroups/CU the 4-wave build's spills make it 4 % slower; the general
     // variant's 10 spilled VGPRs at 4 waves/SIMD cost nothing measurable: "turn" parameter set, 65 536 instances, same
     // box: 34.9 M solves/s against 30.6 M at 3 waves/SIMD, tools/ab_general.py)
-    const int w = solve_variant(lds <= 12600 ? 4 : 3);
+    const int w = solve_variant(tuning, lds <= 12600 ? 4 : 3);
     if (disc) NEO_LAUNCH_W(w, 0, 2, true);
     else NEO_LAUNCH_W(w, 0, 2);
   }
   (void)generic; (void)small_tile;
 #else
-  if (a.p.newton == 2) { launch_solve_riccati(a, stream, ev_start, ev_stop); return; }
+  if (a.p.newton == 2) { launch_solve_riccati(a, tuning, stream, ev_start, ev_stop); return; }
   if (a.p.n == 3 && a.p.newton == 1) {  // projected Newton, dense 9 x 9 system (its layout does not depend on lbfgs_memory)
     // (the general variant at 4 waves/SIMD spills 7 VGPRs -- 32 bytes of scratch -- and is still the faster one: measured
     // on the "cut" parameter set, same box, tools/ab_general.py: 0.123 ms against 0.133 ms per 4096 instances at 3
     // waves/SIMD -- 4096 waves are one residency round at 4 --, 55.9 M against 51.3 M solves/s at 65 536)
-    const int w = solve_variant(4);
+    const int w = solve_variant(tuning, 4);
     if (disc && w == 4 && small_tile) NEO_LAUNCH_LDS(0, 4, 3, 1, true, 1024);   // (the static variant takes no dynamic LDS)
     else if (disc) NEO_LAUNCH_W(w, 3, 1, true);
     else NEO_LAUNCH_W(w, 3, 1);
   } else if (a.p.n == 3 && a.p.newton == 0 && !generic) {
-    NEO_LAUNCH_W(solve_variant(3), 3);
+    NEO_LAUNCH_W(solve_variant(tuning, 3), 3);
   } else if (a.p.newton == 1) {  // control_steps <= kNewtonMaxSteps, dense system with run-time size
     // (a 24-entry row per lane: 158 VGPRs, 187 without the tame specialisation -- spill-free at 3 and 2 waves/SIMD)
-    const int w = solve_variant(disc ? 3 : 2);
+    const int w = solve_variant(tuning, disc ? 3 : 2);
     if (disc && w == 3 && small_tile) NEO_LAUNCH_LDS(0, 3, 0, 1, true, 1024);
     else if (disc) NEO_LAUNCH_W(w, 0, 1, true);
     else NEO_LAUNCH_W(w, 0, 1);
   } else {  // projected L-BFGS, any control_steps
-    const int w = solve_variant(3);
+    const int w = solve_variant(tuning, 3);
     if (disc) NEO_LAUNCH_W(w, 0, 0, true);
     else NEO_LAUNCH_W(w, 0, 0);
   }
@@ -1314,10 +1435,10 @@ void launch_objective(const ObjectiveArgs& a, void* stream) {
   if (a.count == 0) return;
   hipLaunchKernelGGL(k_objective, dim3((a.count + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
 }
-void launch_ingest(const IngestArgs& a, void* stream) {
+void launch_ingest(const IngestArgs& a, const LaunchTuning& tuning, void* stream) {
   const long total = (long)a.rows * (a.pitch >> 4);
   // a few 16-byte chunks per thread: one-chunk threads make the launch dispatch-bound for pools of small maps
-  const int per_thread = getenv("NEO_MPC_INGEST_CHUNKS") ? atoi(getenv("NEO_MPC_INGEST_CHUNKS")) : kIngestUnroll;
+  const int per_thread = tuning.ingest_chunks > 0 ? tuning.ingest_chunks : kIngestUnroll;
   int blocks = (int)((total + 256L * per_thread - 1) / (256L * per_thread));
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(k_ingest, dim3(blocks, a.maps > 0 ? a.maps : 1), dim3(256), 0, (hipStream_t)stream, a);

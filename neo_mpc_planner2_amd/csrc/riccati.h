@@ -11,12 +11,16 @@
 // value-function Hessians and one forward sweep, O(control_steps), no (3N)^2 matrix and no finite
 // differences.
 //
-// The sweep keeps the GAUSS-NEWTON part of H (the lambda_i . d2F_i terms are left out): every stage system is
-// then positive definite by construction, the value function stays positive semi-definite, and the
-// recursion is safe in float32.  With the second-order terms the stage systems turn indefinite far from the
-// minimiser, pivots get replaced and the forward sweep can blow up (seen at control_steps 64: |d| ~ 1e53)
-// -- for 1-3 % fewer iterations (measured on the CPU mirror, which carries both variants: 12.07 against
-// 12.21 iterations at control_steps 32, 7.01 / 7.06 at 8).
+// Far from the minimiser the sweep keeps the GAUSS-NEWTON part of H (the lambda_i . d2F_i terms are left out): every
+// stage system is then positive definite by construction, the value function stays positive semi-definite, and the
+// recursion is safe in float32 -- with the second-order terms the stage systems turn indefinite there, pivots get
+// replaced and the forward sweep can blow up (seen at control_steps 64: |d| ~ 1e53; a search blocked by a lethal wall
+// crept along it, G8 "turn").  Round 4: behind an iteration won by a Newton step of at least half its length (the model
+// held there) the sweep carries the second-order terms (k_solve scales the costates it stores by tau = 0 / 1): the
+// Gauss-Newton direction converges LINEARLY wherever the tracking residuals are large -- on the held-out parameter sets
+// (G10 "a", "c": heavy control / tracking weights) first controls ended 1.4e-3 ... 3.2e-3 from SLSQP's converged ones
+// when a stop rule cut in; with the exact Hessian near the minimiser: <= 3e-4 everywhere, in 15-35 % fewer iterations
+// on those sets and as many as before at the README's weights.
 //
 // Beyond 8 control steps the block curvature carries an adaptive Levenberg-Marquardt term (k_solve keeps mu: two
 // neighbouring blocks of a long horizon trade displacement at almost no cost, and the undamped step along such a
@@ -57,7 +61,8 @@ enum : int {
   RS_GS = 19,          // [3] smooth gradient                             -> K[1][1..2], K[2][0]
   RS_WK = 22,          // [3] the step onto the kink                      -> K[2][1..2], k[0]
   RS_WLX = 25, RS_WLY, // wall push-back (linear term on the stage position, costmap.h) -> k[1], k[2]
-  RS_PAD = 27,         //                                                 -> -
+  RS_SY = 27,          // tau x SY_i: position costate of the stage (second-order terms; tau x SX_i sits next to the disc
+                       // curvature in the rt slot of the stage)                   -> -
   RS_GAIN = 16,        // K (row-major 3x3) then k: 12 floats from here
   kRicStage = 28
 };
@@ -107,7 +112,7 @@ __device__ __forceinline__ void riccati_prepare(const SolveArgs& a, const Ctx& c
   rs[RS_TX] = rtx; rs[RS_TY] = rty;
   const int near = am[2];
   const int xy = near ? 2 : am[0];          // 0: both velocity directions free, 1: sliding along the tangent, 2: pinned
-  const bool wfree = !(near || am[1]);
+  const bool wfree = !(near || (am[1] & 1));
   const int kase = xy == 0 ? (wfree ? RC_FREE3 : RC_XY) : xy == 1 ? (wfree ? RC_SLIDE_W : RC_SLIDE) : (wfree ? RC_W : RC_NONE);
   const int flags = kase | ((!near && v_feasible) ? RF_KINK_OK : 0);
   rs[RS_FLAGS] = (float)flags;   // (a small integer as a float VALUE: its bit pattern would be a denormal)
@@ -120,7 +125,7 @@ __device__ __forceinline__ void riccati_prepare(const SolveArgs& a, const Ctx& c
     const float ine = fn2 > 0.0f ? __builtin_amdgcn_rsqf(fn2) : 0.0f;
     const float i2 = (float)(idt * idt);
     const float sN = (float)p.wc_n * ine * i2, h0 = f0 * ine, h1 = f1 * ine, h2 = f2 * ine;
-    const float k2 = (float)L[a.lds.rt + lane] * i2;
+    const float k2 = reinterpret_cast<const float*>(L + a.lds.rt)[2 * lane] * i2;
     c00 = sN * (1.0f - h0 * h0) + k2 * rtx * rtx; c01 = -sN * h0 * h1 + k2 * rtx * rty; c02 = -sN * h0 * h2;
     c11 = sN * (1.0f - h1 * h1) + k2 * rty * rty; c12 = -sN * h1 * h2; c22 = sN * (1.0f - h2 * h2);
     const float mt = mu * (float)(2.0 * p.wt_n);
@@ -140,6 +145,7 @@ __device__ __forceinline__ void riccati_sweep(const SolveArgs& a, double* L, int
   float* RS = static_cast<float*>(__builtin_assume_aligned(reinterpret_cast<float*>(L + a.lds.ric), 16));
   int* AMODE = reinterpret_cast<int*>(L + a.lds.mode);
   double* d = L + a.lds.d;
+  const float* ARTF = reinterpret_cast<const float*>(L + a.lds.rt);
   const T w2 = (T)(2.0 * p.wt_n), wo2 = (T)(2.0 * p.wo_n), wterm2 = (T)(2.0 * p.wterm_o);
   // kink test |B0^T r| <= w_control/N  <=>  |r| <= w_control / (N dt)
   const T wc2 = (T)((p.wc_n * p.wc_n) / (p.dt * p.dt));
@@ -162,6 +168,8 @@ __device__ __forceinline__ void riccati_sweep(const SolveArgs& a, double* L, int
     const T c00 = r2.x, c01 = r2.y, c02 = r2.z, c11 = r2.w, c12 = r3.x, c22 = r3.y;
     const T gt0 = r4.x, gt1 = r4.y, gt2 = r4.z, gs0 = r4.w, gs1 = r5.x, gs2 = r5.y, e0 = r5.z, e1 = r5.w, e2 = r6.x;
     v0 += (T)r6.y; v1 += (T)r6.z;   // wall push-back: linear term of this stage's own cost in its position
+    // position costates of the stage, already scaled by tau (0: Gauss-Newton sweep)
+    const T sy = (T)r6.w, sx = (T)ARTF[2 * i + 1];
     if (kPrefetch && i > 0) {
       const ric_f4* R4 = reinterpret_cast<const ric_f4*>(RS + kRicStage * (i - 1));
       r0 = R4[0]; r1 = R4[1]; r2 = R4[2]; r3 = R4[3]; r4 = R4[4]; r5 = R4[5]; r6 = R4[6];
@@ -172,6 +180,10 @@ __device__ __forceinline__ void riccati_sweep(const SolveArgs& a, double* L, int
     const T M02 = ric_fma(-py, S00, ric_fma(px, S01, V02));
     const T M12 = ric_fma(-py, S01, ric_fma(px, S11, V12));
     const T M22 = ric_fma(-py, M02, ric_fma(px, M12, ric_fma(-py, V02, ric_fma(px, V12, S22))));
+    // second-order terms of the rollout step, weighted by the costate of its result (displacement coordinates):
+    // T = [[0 0 SY] [0 0 -SX] [SY -SX kappa]], kappa = -(SX px + SY py).  They enter Quu whole, Quz in its theta
+    // COLUMN (rows of Quz: (S00 S01 Z02), (S01 S11 Z12), (M02 M12 Z22)) and Qzz in its corner only.
+    const T Z02 = M02 + sy, Z12 = M12 - sx, Z22 = M22 - ric_fma(sx, px, sy * py);
     // linear terms: Qz = A^T v, Qu = g~ + Qz
     const T z0 = v0, z1 = v1, z2 = ric_fma(-py, v0, ric_fma(px, v1, v2));
     // ---- the stage system in the coordinates of its face.  Six straight-line cases (wave-uniform switch):
@@ -185,16 +197,16 @@ __device__ __forceinline__ void riccati_sweep(const SolveArgs& a, double* L, int
     if (flags & RF_KINK_OK) {
       // does the stage model put this block ON the kink?  0 in Qu_s + M k + w d|.| at k = the step onto the kink
       // <=> |Qu_s + M k| <= w  (smooth parts only)
-      const T q0 = gs0 + z0 + S00 * e0 + S01 * e1 + M02 * e2;
-      const T q1 = gs1 + z1 + S01 * e0 + S11 * e1 + M12 * e2;
-      const T q2 = gs2 + z2 + M02 * e0 + M12 * e1 + M22 * e2;
+      const T q0 = gs0 + z0 + S00 * e0 + S01 * e1 + Z02 * e2;
+      const T q1 = gs1 + z1 + S01 * e0 + S11 * e1 + Z12 * e2;
+      const T q2 = gs2 + z2 + Z02 * e0 + Z12 * e1 + Z22 * e2;
       if (__builtin_amdgcn_readfirstlane((int)(q0 * q0 + q1 * q1 + q2 * q2 <= wc2))) { tokink = true; kase = RC_KINK; }
     }
     const T q0 = gt0 + z0, q1 = gt1 + z1, q2 = gt2 + z2;   // gradient on the stage
     switch (kase) {
       case RC_FREE3: {
         // L D L^T of Quu = M + R~ without pivoting, pivots made positive
-        const T Q00 = S00 + c00, Q01 = S01 + c01, Q02 = M02 + c02, Q11 = S11 + c11, Q12 = M12 + c12, Q22 = M22 + c22;
+        const T Q00 = S00 + c00, Q01 = S01 + c01, Q02 = Z02 + c02, Q11 = S11 + c11, Q12 = Z12 + c12, Q22 = Z22 + c22;
         const T delta = ric_max((T)1e-6 * ric_max(ric_abs(Q00), ric_max(ric_abs(Q11), ric_abs(Q22))), (T)1e-30);
         const T d0 = ric_pivot(Q00, delta), i0 = ric_rcp(d0);
         const T l10 = Q01 * i0, l20 = Q02 * i0;
@@ -212,17 +224,17 @@ __device__ __forceinline__ void riccati_sweep(const SolveArgs& a, double* L, int
         NEO_RIC_SOLVE3(q0, q1, q2, k0, k1, k2)
         NEO_RIC_SOLVE3(S00, S01, M02, K00, K10, K20)
         NEO_RIC_SOLVE3(S01, S11, M12, K01, K11, K21)
-        NEO_RIC_SOLVE3(M02, M12, M22, K02, K12, K22)
+        NEO_RIC_SOLVE3(Z02, Z12, Z22, K02, K12, K22)
 #undef NEO_RIC_SOLVE3
         v0 = z0 + S00 * k0 + S01 * k1 + M02 * k2;
         v1 = z1 + S01 * k0 + S11 * k1 + M12 * k2;
-        v2 = z2 + M02 * k0 + M12 * k1 + M22 * k2;
+        v2 = z2 + Z02 * k0 + Z12 * k1 + Z22 * k2;
         V00 = S00 + S00 * K00 + S01 * K10 + M02 * K20;
         V01 = S01 + S00 * K01 + S01 * K11 + M02 * K21;
         V02 = M02 + S00 * K02 + S01 * K12 + M02 * K22;
         V11 = S11 + S01 * K01 + S11 * K11 + M12 * K21;
         V12 = M12 + S01 * K02 + S11 * K12 + M12 * K22;
-        V22 = M22 + M02 * K02 + M12 * K12 + M22 * K22;
+        V22 = Z22 + Z02 * K02 + Z12 * K12 + Z22 * K22;
         break;
       }
       case RC_SLIDE_W:     // a = tangent (rtx, rty, 0), b = omega
@@ -232,11 +244,11 @@ __device__ __forceinline__ void riccati_sweep(const SolveArgs& a, double* L, int
         const T Q00 = S00 + c00, Q01 = S01 + c01, Q11 = S11 + c11;
         const T Qa0 = ax * Q00 + ay * Q01, Qa1 = ax * Q01 + ay * Q11;
         const T haa = Qa0 * ax + Qa1 * ay;
-        const T hab = bw ? ax * (M02 + c02) + ay * (M12 + c12) : Qa1;
-        const T hbb = bw ? M22 + c22 : Q11;
+        const T hab = bw ? ax * (Z02 + c02) + ay * (Z12 + c12) : Qa1;
+        const T hbb = bw ? Z22 + c22 : Q11;
         const T ga = ax * q0 + ay * q1, gb = bw ? q2 : q1;
-        const T Za0 = ax * S00 + ay * S01, Za1 = ax * S01 + ay * S11, Za2 = ax * M02 + ay * M12;
-        const T Zb0 = bw ? M02 : S01, Zb1 = bw ? M12 : S11, Zb2 = bw ? M22 : M12;
+        const T Za0 = ax * S00 + ay * S01, Za1 = ax * S01 + ay * S11, Za2 = ax * Z02 + ay * Z12;
+        const T Zb0 = bw ? M02 : S01, Zb1 = bw ? M12 : S11, Zb2 = bw ? Z22 : Z12;
         const T delta = ric_max((T)1e-6 * ric_max(ric_abs(haa), ric_abs(hbb)), (T)1e-30);
         const T d0 = ric_pivot(haa, delta), i0 = ric_rcp(d0);
         const T l = hab * i0;
@@ -255,7 +267,7 @@ __device__ __forceinline__ void riccati_sweep(const SolveArgs& a, double* L, int
 #undef NEO_RIC_SOLVE2
         v0 = z0 + Za0 * ka + Zb0 * kb; v1 = z1 + Za1 * ka + Zb1 * kb; v2 = z2 + Za2 * ka + Zb2 * kb;
         V00 = S00 + Za0 * Ka0 + Zb0 * Kb0; V01 = S01 + Za0 * Ka1 + Zb0 * Kb1; V02 = M02 + Za0 * Ka2 + Zb0 * Kb2;
-        V11 = S11 + Za1 * Ka1 + Zb1 * Kb1; V12 = M12 + Za1 * Ka2 + Zb1 * Kb2; V22 = M22 + Za2 * Ka2 + Zb2 * Kb2;
+        V11 = S11 + Za1 * Ka1 + Zb1 * Kb1; V12 = M12 + Za1 * Ka2 + Zb1 * Kb2; V22 = Z22 + Za2 * Ka2 + Zb2 * Kb2;
         k0 = ax * ka; k1 = ay * ka; K00 = ax * Ka0; K01 = ax * Ka1; K02 = ax * Ka2; K10 = ay * Ka0; K11 = ay * Ka1; K12 = ay * Ka2;
         if (bw) { k2 = kb; K20 = Kb0; K21 = Kb1; K22 = Kb2; }
         else { k1 = kb; K10 = Kb0; K11 = Kb1; K12 = Kb2; }
@@ -265,33 +277,33 @@ __device__ __forceinline__ void riccati_sweep(const SolveArgs& a, double* L, int
         const T Q00 = S00 + c00, Q01 = S01 + c01, Q11 = S11 + c11;
         const T haa = (rtx * Q00 + rty * Q01) * rtx + (rtx * Q01 + rty * Q11) * rty;
         const T i0 = -ric_rcp(ric_pivot(haa, ric_max((T)1e-6 * ric_abs(haa), (T)1e-30)));
-        const T Za0 = rtx * S00 + rty * S01, Za1 = rtx * S01 + rty * S11, Za2 = rtx * M02 + rty * M12;
+        const T Za0 = rtx * S00 + rty * S01, Za1 = rtx * S01 + rty * S11, Za2 = rtx * Z02 + rty * Z12;
         const T ka = (rtx * q0 + rty * q1) * i0, Ka0 = Za0 * i0, Ka1 = Za1 * i0, Ka2 = Za2 * i0;
         v0 = z0 + Za0 * ka; v1 = z1 + Za1 * ka; v2 = z2 + Za2 * ka;
         V00 = S00 + Za0 * Ka0; V01 = S01 + Za0 * Ka1; V02 = M02 + Za0 * Ka2;
-        V11 = S11 + Za1 * Ka1; V12 = M12 + Za1 * Ka2; V22 = M22 + Za2 * Ka2;
+        V11 = S11 + Za1 * Ka1; V12 = M12 + Za1 * Ka2; V22 = Z22 + Za2 * Ka2;
         k0 = rtx * ka; k1 = rty * ka; K00 = rtx * Ka0; K01 = rtx * Ka1; K02 = rtx * Ka2; K10 = rty * Ka0; K11 = rty * Ka1; K12 = rty * Ka2;
         break;
       }
       case RC_W: {         // omega only (velocity pinned)
-        const T hbb = M22 + c22;
+        const T hbb = Z22 + c22;
         const T i0 = -ric_rcp(ric_pivot(hbb, ric_max((T)1e-6 * ric_abs(hbb), (T)1e-30)));
-        k2 = q2 * i0; K20 = M02 * i0; K21 = M12 * i0; K22 = M22 * i0;
-        v0 = z0 + M02 * k2; v1 = z1 + M12 * k2; v2 = z2 + M22 * k2;
+        k2 = q2 * i0; K20 = M02 * i0; K21 = M12 * i0; K22 = Z22 * i0;
+        v0 = z0 + M02 * k2; v1 = z1 + M12 * k2; v2 = z2 + Z22 * k2;
         V00 = S00 + M02 * K20; V01 = S01 + M02 * K21; V02 = M02 + M02 * K22;
-        V11 = S11 + M12 * K21; V12 = M12 + M12 * K22; V22 = M22 + M22 * K22;
+        V11 = S11 + M12 * K21; V12 = M12 + M12 * K22; V22 = Z22 + Z22 * K22;
         break;
       }
       case RC_KINK:        // fixed step onto the kink, no feedback
         k0 = e0; k1 = e1; k2 = e2;
         v0 = z0 + S00 * k0 + S01 * k1 + M02 * k2;
         v1 = z1 + S01 * k0 + S11 * k1 + M12 * k2;
-        v2 = z2 + M02 * k0 + M12 * k1 + M22 * k2;
-        V00 = S00; V01 = S01; V02 = M02; V11 = S11; V12 = M12; V22 = M22;
+        v2 = z2 + Z02 * k0 + Z12 * k1 + Z22 * k2;
+        V00 = S00; V01 = S01; V02 = M02; V11 = S11; V12 = M12; V22 = Z22;
         break;
       default:             // RC_NONE: nothing moves
         v0 = z0; v1 = z1; v2 = z2;
-        V00 = S00; V01 = S01; V02 = M02; V11 = S11; V12 = M12; V22 = M22;
+        V00 = S00; V01 = S01; V02 = M02; V11 = S11; V12 = M12; V22 = Z22;
         break;
     }
     if (lane == 0) {   // the gains take the place of the stage's linear terms
@@ -340,7 +352,7 @@ __device__ __forceinline__ void riccati_finish(const SolveArgs& a, const Ctx& c,
         const double dot = d0 * nx + d1 * ny;
         d0 -= dot * nx; d1 -= dot * ny;
       } else if (mode == 2) { d0 = 0.0; d1 = 0.0; }
-      d[0] = d0; d[1] = d1; d[2] = (am[2] || am[1]) ? 0.0 : w2 * idt;
+      d[0] = d0; d[1] = d1; d[2] = (am[2] || (am[1] & 1)) ? 0.0 : w2 * idt;
     }
   }
   WAVE_SYNC();

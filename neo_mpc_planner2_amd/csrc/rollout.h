@@ -225,7 +225,11 @@ __device__ void postprocess(const SolveArgs& a, const Ctx& c, double* L, uint32_
     if (a.velocities) { double* v = a.velocities + 3 * (size_t)b; v[0] = out0; v[1] = out1; v[2] = out2; }
   }
   WAVE_SYNC();
-  if (lane < 16) reinterpret_cast<double*>(a.states_out + b)[lane] = S[lane];
+  // the state goes back field by field: last_control, waiting_time and the flags every tick (48 bytes), old_goal (56
+  // bytes) only when it changed -- py:402 assigns it every call, but between two resets it is the same goal
+  const bool goal_changed = (flags & NEO_MPC_FLAG_RESET) != 0;
+  if (lane < 3 || (lane >= S_WAIT && lane < kStateDoubles) || (goal_changed && lane >= S_OLD_GOAL && lane < S_WAIT))
+    reinterpret_cast<double*>(a.states_out + b)[lane] = S[lane];
 }
 
 // py:358-361; returns true when the reset is taken.  x0 -> L[u]
@@ -257,9 +261,11 @@ __device__ __forceinline__ void select_map(DevMap& m, const double* P) {
   m.origin_y = m.pool_origins[2 * idx + 1];
 }
 
+// (only the fields that exist are read: 216 of the 256 bytes of a request, 104 of the 128 of a state record -- with
+// page-locked host batches worked on in place these loads cross PCIe)
 __device__ void load_records(const SolveArgs& a, double* L, uint32_t b, int lane) {
-  if (lane < 32) L[a.lds.prob + lane] = reinterpret_cast<const double*>(a.problems + b)[lane];
-  else if (lane < 48) L[a.lds.state + lane - 32] = reinterpret_cast<const double*>(a.states + b)[lane - 32];
+  if (lane < kProblemDoubles) L[a.lds.prob + lane] = reinterpret_cast<const double*>(a.problems + b)[lane];
+  else if (lane >= 32 && lane < 32 + kStateDoubles) L[a.lds.state + lane - 32] = reinterpret_cast<const double*>(a.states + b)[lane - 32];
   load_term_table(a.term_table, L, a.lds.term, lane);
   WAVE_SYNC();
 }

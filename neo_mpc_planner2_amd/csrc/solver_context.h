@@ -15,6 +15,9 @@ enum : int {
   P_CUR_X = 0, P_CUR_Y = 1, P_CUR_Q = 2, P_CARROT_X = 6, P_CARROT_Y = 7, P_CARROT_Q = 8,
   P_GOAL = 12, P_GOAL_Q = 15, P_VEL = 19, P_INTERVAL = 22, P_DELTA_T = 23, P_FOOTPRINT = 24,
   PI_MAP_INDEX = 50,  // int32 view of the request record: neo_mpc_problem.map_index
+  PI_SKIP = 52,       // ... neo_mpc_problem.skip (no request this tick, cpp:234-236)
+  kProblemDoubles = 27,  // what of the 32-double request record the device reads (the rest is reserved)
+  kStateDoubles = 13,    // ... of the 16-double state record
   S_LAST = 0, S_OLD_GOAL = 3, S_WAIT = 10, SI_HAS_GOAL = 22, SI_COLLISION = 23, SI_COLL_FP = 24
 };
 

@@ -36,6 +36,10 @@ class BatchSolver:
         if self._handle is not None:
             self._lib.neo_mpc_destroy(self._handle)
             self._handle = None
+        # (the marshalled batches keep the caller's arrays alive: let go of them with the handle)
+        self._last_call = None
+        self._keep = None
+        self._in_flight = {}
 
     def __del__(self):
         try:
@@ -52,11 +56,13 @@ class BatchSolver:
     # -- configuration --------------------------------------------------------------
     def set_params(self, **changes):
         """Dynamic reconfigure (reference: cb_params, mpc_optimization_server.py:405-439)."""
-        self.params.update(changes)
-        ps = abi.params_struct(self.params)
+        new = dict(self.params)
+        new.update(changes)
+        ps = abi.params_struct(new)
         if int(ps.control_steps) != self.control_steps:
             raise ValueError("control_steps cannot change on a live handle (the reference bakes it at init, py:125-137)")
         _lib.check(self._lib.neo_mpc_set_params(self._handle, C.byref(ps)))
+        self.params = new    # (a refused set keeps the old parameters, like the library does)
 
     def set_costmap(self, cells, resolution, origin_x, origin_y):
         """cells: uint8 [size_y, size_x] raw nav2 costs (NumPy) or a CUDA uint8 torch tensor."""
@@ -137,7 +143,8 @@ class BatchSolver:
         if out is not None and not want_path and footprints is None:
             # a caller that owns its arrays (a fleet server's request arena) passes the same ones every tick: the
             # marshalled batch of the previous call is reused as long as every array is the same object
-            key = (id(problems), id(states), id(warm), id(out[0]), id(out[1]))
+            # (address and shape are part of the key: an array resized or re-allocated in place keeps its id())
+            key = tuple((id(a), a.ctypes.data, a.shape) for a in (problems, states, warm, out[0], out[1]))
             if self._last_call is not None and self._last_call[0] == key:
                 _lib.check(self._lib.neo_mpc_solve_batch(self._handle, self._last_call[1]))
                 return out
@@ -163,7 +170,11 @@ class BatchSolver:
     def solve_wait(self, ticket):
         """Second half (`result.get()`, cpp:250): blocks until the batch of `ticket` is done; its results are then in the
         arrays handed to `solve_begin`, which are returned."""
-        _lib.check(self._lib.neo_mpc_solve_batch_wait(self._handle, C.c_uint32(ticket)))
+        try:
+            _lib.check(self._lib.neo_mpc_solve_batch_wait(self._handle, C.c_uint32(ticket)))
+        except Exception:
+            self._in_flight.pop(ticket, None)   # (the library has given the slot up either way: no stale entry)
+            raise
         return self._in_flight.pop(ticket)[4]
 
     def postprocess(self, problems, states, warm, solution, success=None, want_path=False, footprints=None):

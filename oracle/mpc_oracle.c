@@ -402,12 +402,14 @@ static void orc_tangent(const orc_ctx* c, const double* ui, const double* gi, do
   double nx[3], ny[3];
   int isdisc[3] = {0, 0, 0};
   int na = 0;
+  /* (the disc first: where a bound touches the disc with the same normal -- max_vel_x = max_vel_trans, README -- the slide
+   * is the disc's, with its curvature and without the corner stop of a bound slide) */
+  double nv = sqrt(ui[0] * ui[0] + ui[1] * ui[1]);
+  if (nv > 0.0 && nv >= c->r * (1.0 - 1e-12)) { nx[na] = ui[0] / nv; ny[na] = ui[1] / nv; isdisc[na] = 1; ++na; }
   if (ui[0] <= c->lo[0]) { nx[na] = -1.0; ny[na] = 0.0; ++na; }
   else if (ui[0] >= c->hi[0]) { nx[na] = 1.0; ny[na] = 0.0; ++na; }
   if (ui[1] <= c->lo[1]) { nx[na] = 0.0; ny[na] = -1.0; ++na; }
   else if (ui[1] >= c->hi[1]) { nx[na] = 0.0; ny[na] = 1.0; ++na; }
-  double nv = sqrt(ui[0] * ui[0] + ui[1] * ui[1]);
-  if (nv > 0.0 && nv >= c->r * (1.0 - 1e-12)) { nx[na] = ui[0] / nv; ny[na] = ui[1] / nv; isdisc[na] = 1; ++na; }
   const double dx = -gi[0], dy = -gi[1]; /* steepest descent */
   *mode = 0; *nxo = 0.0; *nyo = 0.0; *disc = 0; *lambda = 0.0;
   int violated = 0;
@@ -1083,7 +1085,9 @@ static void orc_candidate(const orc_ctx* c, const orc_active* act, int lane, dou
         const double inward = -(t * (d[3 * i] * e[0] + d[3 * i + 1] * e[1] + d[3 * i + 2] * e[2]));
         if (rho2 > 0.0 && inward >= rho2) for (int k = 0; k < 3; ++k) b[k] = c->v[k];
       }
-      if (orc_corner_stop && act->mode[i] == 1 && !act->disc[i] && !act->tokink[i]) {
+      const double rl = c->r * (1.0 - 1e-12);
+      if (orc_corner_stop && act->mode[i] == 1 && !act->disc[i] && !act->tokink[i] &&
+          u[3 * i] * u[3 * i] + u[3 * i + 1] * u[3 * i + 1] < rl * rl) {   /* (not AT the corner already: from there the projection slides it along the disc) */
         /* a block sliding along a box bound stops where the bound meets the speed disc (the Euclidean projection of a
          * point beyond the corner slides down the disc instead, away from the bound) */
         const int free_axis = act->nx[i] != 0.0 ? 1 : 0, fixed_axis = 1 - free_axis;
@@ -1506,7 +1510,8 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
           f = fbest;
           ++exit_hops;
           status = NEO_MPC_STATUS_MAX_ITER; stall = 0; blocked_run = 0; final = 0; gain1 = INFINITY; gain2 = INFINITY;
-          continue;   /* (the for statement's ++it is skipped by the exits above having counted this iteration) */
+          --it;       /* (the exit above has counted this iteration; the for statement counts again) */
+          continue;
         }
       }
     }
@@ -1553,6 +1558,7 @@ void orc_postprocess_batch(const neo_mpc_params* p, const uint8_t* cells, int32_
   const int nv = 3 * p->control_steps;
   for (size_t i = 0; i < b->count; ++i) {
     neo_mpc_command* out = &b->commands[i];
+    if (b->problems[i].skip) { out->flags = NEO_MPC_FLAG_SKIPPED; continue; }   /* (no request this tick: see orc_solve_batch) */
     memset(out, 0, sizeof(*out));
     double* warm = b->warm_start + i * nv;
     if (orc_reset_if_new_goal(p, &b->problems[i], &b->states[i], warm)) out->flags |= NEO_MPC_FLAG_RESET;
@@ -1583,6 +1589,9 @@ void orc_solve_batch(const neo_mpc_params* p, const uint8_t* cells, int32_t sx, 
   for (long long ii = 0; ii < (long long)b->count; ++ii) {
     size_t i = (size_t)ii;
     neo_mpc_command* out = &b->commands[i];
+    /* no request for this robot this tick (the plugin threw before its service call, cpp:234-236): the node's state does
+     * not advance; nothing but the flag is written */
+    if (b->problems[i].skip) { out->flags = NEO_MPC_FLAG_SKIPPED; continue; }
     memset(out, 0, sizeof(*out));
     double* warm = b->warm_start + i * nv;
     if (orc_reset_if_new_goal(p, &b->problems[i], &b->states[i], warm)) out->flags |= NEO_MPC_FLAG_RESET;
@@ -1704,6 +1713,7 @@ static void orc_select_carrot(const neo_mpc_lookahead_params* lp, const double* 
   else sd = 0;
   *slow_down = sd;
   out->slow_down = sd;
+  if (footprint_cost == 255) out->status = 3;                           /* cpp:234-236: the plugin throws, no request */
 }
 
 void orc_select_carrots(const neo_mpc_lookahead_params* lp, const neo_mpc_plan_batch* b) {
@@ -1711,10 +1721,13 @@ void orc_select_carrots(const neo_mpc_lookahead_params* lp, const neo_mpc_plan_b
     const uint32_t o0 = b->plan_offsets[i], o1 = b->plan_offsets[i + 1];
     orc_select_carrot(lp, b->plan_poses + 3 * (size_t)o0, o1 - o0, b->robot_poses + 3 * i,
                       b->footprint_costs ? b->footprint_costs[i] : 0.0, &b->slow_down[i], &b->carrots[i]);
-    if (b->problems && b->carrots[i].status == 0) {
+    if (b->problems && (b->carrots[i].status == 0 || b->carrots[i].status == 3)) {
       b->problems[i].carrot_xy[0] = b->carrots[i].xy[0];
       b->problems[i].carrot_xy[1] = b->carrots[i].xy[1];
       for (int k = 0; k < 4; ++k) b->problems[i].carrot_q[k] = b->carrots[i].q[k];
+      b->problems[i].switch_opt = b->carrots[i].closer_to_goal;         /* cpp:245 */
     }
+    /* every non-zero status is a throw in front of the service call (cpp:70, 131, 235): no request this tick */
+    if (b->problems) b->problems[i].skip = b->carrots[i].status != 0;
   }
 }

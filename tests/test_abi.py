@@ -28,7 +28,11 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.EXPORTS) == names
-    assert lib.neo_mpc_abi_version() == 1
+    assert lib.neo_mpc_abi_version() == abi.ABI_VERSION == 2
+    lib.neo_mpc_behaviour_version.restype = C.c_int
+    assert lib.neo_mpc_behaviour_version() == 4
+    header = open(HEADER).read()
+    assert "#define NEO_MPC_ABI_VERSION 2" in header and "#define NEO_MPC_BEHAVIOUR_VERSION 4" in header
 
 
 def test_record_layouts_match_the_header(tmp_path):
@@ -45,6 +49,7 @@ int main(void) {
   P(neo_mpc_params, control_steps); P(neo_mpc_params, step_tolerance); P(neo_mpc_params, kink_radius); P(neo_mpc_params, stall_step); P(neo_mpc_params, method); P(neo_mpc_params, window_tolerance);
   P(neo_mpc_problem, carrot_xy); P(neo_mpc_problem, goal_xyz); P(neo_mpc_problem, cur_vel);
   P(neo_mpc_problem, control_interval); P(neo_mpc_problem, footprint_cost); P(neo_mpc_problem, map_index);
+  P(neo_mpc_problem, switch_opt); P(neo_mpc_problem, skip);
   P(neo_mpc_state, old_goal); P(neo_mpc_state, waiting_time); P(neo_mpc_state, has_old_goal);
   P(neo_mpc_state, collision_footprint);
   P(neo_mpc_command, cost); P(neo_mpc_command, status); P(neo_mpc_command, flags);
@@ -62,7 +67,7 @@ int main(void) {
     assert got["sizeof.batch"] == C.sizeof(abi.NeoMpcBatch)
     for f in ("control_steps", "step_tolerance", "kink_radius", "stall_step", "method", "window_tolerance"):
         assert got["neo_mpc_params." + f] == getattr(abi.NeoMpcParams, f).offset
-    for f in ("carrot_xy", "goal_xyz", "cur_vel", "control_interval", "footprint_cost", "map_index"):
+    for f in ("carrot_xy", "goal_xyz", "cur_vel", "control_interval", "footprint_cost", "map_index", "switch_opt", "skip"):
         assert got["neo_mpc_problem." + f] == abi.PROBLEM_DTYPE.fields[f][1]
     for f in ("old_goal", "waiting_time", "has_old_goal", "collision_footprint"):
         assert got["neo_mpc_state." + f] == abi.STATE_DTYPE.fields[f][1]

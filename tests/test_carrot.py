@@ -44,14 +44,16 @@ def transcription(poses, robot, slow, fcost, lp):
         new_slow = 1
     else:
         new_slow = 0
-    return dict(status=0, begin=begin, end=end, closer=closer, la=la, xy=(lx[k], ly[k]), yaw=yaw_w, slow=new_slow)
+    # cpp:234-236: `if (footprint_cost == 255) throw ...` -- after the slow_down_ update, before the optimizer request
+    return dict(status=3 if fcost == 255 else 0, begin=begin, end=end, closer=closer, la=la, xy=(lx[k], ly[k]), yaw=yaw_w,
+                slow=new_slow)
 
 
 def _inputs(count, seed):
     poses, offsets, robots = synthetic.make_plans(count, seed=seed, min_len=8, max_len=300)
     rng = np.random.default_rng(seed + 1)
     slow = rng.integers(0, 2, size=count).astype(np.int32)
-    fcost = rng.choice([0.0, 150.0, 201.0, 253.0], size=count)
+    fcost = rng.choice([0.0, 150.0, 201.0, 253.0, 255.0], size=count)
     return poses, offsets, robots, slow, fcost
 
 
@@ -66,7 +68,7 @@ def test_oracle_restatement_matches_literal_transcription():
     for i in range(len(robots)):
         t = transcription(poses[offsets[i]:offsets[i + 1]], robots[i], slow_in[i], fcost[i], LP)
         assert car["status"][i] == t["status"]
-        if t["status"]:
+        if t["status"] in (1, 2):
             continue
         assert (car["begin"][i], car["end"][i]) == (t["begin"], t["end"])
         assert bool(car["closer_to_goal"][i]) == t["closer"] and car["lookahead_dist"][i] == t["la"]
@@ -87,6 +89,31 @@ def test_oracle_empty_plan_and_problem_write():
     assert car["status"][1] == 1 and (probs["carrot_xy"][1] == before[1]).all()
     ok = car["status"] == 0
     assert (probs["carrot_xy"][ok] == car["xy"][ok]).all() and (probs["carrot_q"][ok] == car["q"][ok]).all()
+    # every throw in front of the service call (cpp:70, 131, 235) means "no request this tick": the record says so
+    assert (probs["skip"] == (car["status"] != 0)).all() and (probs["switch_opt"][ok] == car["closer_to_goal"][ok]).all()
+
+
+def test_footprint_cost_255_makes_no_request():
+    """cpp:234-236: a footprint cost of 255 throws AFTER the slow_down_ update and BEFORE the optimizer request: carrot
+    status 3, the request record is marked `skip`, and the solver (here: the CPU mirror) leaves that robot's state, warm
+    start and command alone."""
+    from oracle import mpc_oracle as orc
+    poses, offsets, robots, slow, fcost = _inputs(64, seed=31)
+    fcost[::4] = 255.0
+    probs = synthetic.make_problems(64, 500, seed=4)
+    car = c_oracle.select_carrots(poses, offsets, robots, slow, fcost, problems=probs, **LP)
+    thrown = fcost == 255.0
+    assert ((car["status"] == 3) == (thrown & (car["status"] != 2) & (car["status"] != 1))).all() and (car["status"] == 3).any()
+    assert (probs["skip"] == (car["status"] != 0)).all()
+    cmap = synthetic.make_costmap(500, seed=0)
+    st, warm = synthetic.make_states(probs, 3)
+    warm[:] = 0.01
+    st0, warm0 = st.copy(), warm.copy()
+    cm, _, _ = c_oracle.solve_batch(orc.make_params(), cmap, probs, st, warm)
+    sk = probs["skip"] != 0
+    assert (cm["flags"][sk] == abi.FLAG_SKIPPED).all() and ((cm["flags"][~sk] & abi.FLAG_SKIPPED) == 0).all()
+    assert st[sk].tobytes() == st0[sk].tobytes() and (warm[sk] == warm0[sk]).all() and (cm["vel"][sk] == 0.0).all()
+    assert st[~sk].tobytes() != st0[~sk].tobytes()
 
 
 @pytest.mark.gpu
@@ -107,7 +134,8 @@ def test_carrot_kernel_matches_oracle():
     assert np.allclose(got["q"], want["q"], rtol=0, atol=1e-12)
     assert np.allclose(pg["carrot_xy"], pc["carrot_xy"], rtol=0, atol=1e-12)
     assert np.allclose(pg["carrot_q"], pc["carrot_q"], rtol=0, atol=1e-12)
-    assert (got["status"] == 0).sum() >= 4000
+    assert (got["status"] == 0).sum() >= 3000 and (got["status"] == 3).sum() >= 500
+    assert (pg["skip"] == pc["skip"]).all() and (pg["switch_opt"] == pc["switch_opt"]).all() and (pg["skip"] != 0).sum() >= 500
 
 
 @pytest.mark.gpu
@@ -141,3 +169,56 @@ def test_carrots_feed_the_solver_on_device():
     dv = np.abs(got["vel"] - want["vel"]).max(axis=1)
     # the carrots agree to an ulp; the Newton path's finite-difference Hessian amplifies that a little
     assert (dv <= 1e-6).mean() >= 0.98 and (dv <= 1e-3).mean() >= 0.995
+
+
+@pytest.mark.gpu
+def test_skipped_instances_are_left_alone_by_the_solver():
+    """neo_mpc_problem.skip (set by K4 with carrot status 3, cpp:234-236): K1 and K2 write NEO_MPC_FLAG_SKIPPED and nothing
+    else -- state, warm start, solution and the command's other fields keep their bytes -- on the staged path, the small
+    latency path and the in-place (page-locked) path; the other instances come out exactly as without any skip."""
+    import ctypes as C
+    from neo_mpc_planner2_amd import _lib
+    from neo_mpc_planner2_amd.solver import BatchSolver
+    from oracle import mpc_oracle as orc
+    lib = _lib.load()
+    cmap = synthetic.make_costmap(500, seed=0)
+    for count in (48, 700):                      # latency path / staged path
+        probs = synthetic.make_problems(count, 500, seed=6)
+        st0, warm0 = synthetic.make_states(probs, 3)
+        warm0[:] = 0.02
+        with BatchSolver(orc.make_params()) as s:
+            s.set_costmap(*cmap)
+            st_a, warm_a = st0.copy(), warm0.copy()
+            ref, xref = s.solve(probs, st_a, warm_a)
+            sk = np.zeros(count, dtype=bool)
+            sk[::3] = True
+            p2 = probs.copy()
+            p2["skip"] = sk
+            st_b, warm_b = st0.copy(), warm0.copy()
+            cmds = np.zeros(count, dtype=abi.COMMAND_DTYPE)
+            cmds["vel"] = 7.0
+            sol = np.full((count, 9), 5.0)
+            s.solve(p2, st_b, warm_b, out=(cmds, sol))
+            assert (cmds["flags"][sk] == abi.FLAG_SKIPPED).all() and (cmds["vel"][sk] == 7.0).all() and (sol[sk] == 5.0).all()
+            assert st_b[sk].tobytes() == st0[sk].tobytes() and (warm_b[sk] == warm0[sk]).all()
+            assert cmds[~sk].tobytes() == ref[~sk].tobytes() and (sol[~sk] == xref[~sk]).all()
+            assert st_b[~sk].tobytes() == st_a[~sk].tobytes() and (warm_b[~sk] == warm_a[~sk]).all()
+            # K2 alone
+            st_c, warm_c = st0.copy(), warm0.copy()
+            c2 = s.postprocess(p2, st_c, warm_c, xref)
+            assert (c2["flags"][sk] == abi.FLAG_SKIPPED).all() and st_c[sk].tobytes() == st0[sk].tobytes()
+            if count > 64:   # in place on page-locked arrays
+                arrays = [np.ascontiguousarray(p2).copy(), st0.copy(), warm0.copy(), cmds.copy(), sol.copy()]
+                arrays[3]["vel"] = 7.0
+                arrays[3]["flags"] = 0
+                arrays[4][:] = 5.0
+                for a in arrays:
+                    assert lib.neo_mpc_pin_host_memory(C.c_void_p(a.ctypes.data), a.nbytes) == 0
+                try:
+                    b = abi.batch_struct(*arrays)
+                    _lib.check(lib.neo_mpc_solve_batch(s._handle, C.byref(b)))
+                    assert arrays[3].tobytes() == cmds.tobytes() and (arrays[4] == sol).all()
+                    assert arrays[1].tobytes() == st_b.tobytes() and (arrays[2] == warm_b).all()
+                finally:
+                    for a in arrays:
+                        assert lib.neo_mpc_unpin_host_memory(C.c_void_p(a.ctypes.data)) == 0

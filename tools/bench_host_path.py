@@ -58,8 +58,10 @@ with BatchSolver(README_PARAMS) as s:
             g_warm[...] = warm
         res["pageable"] = rate(lambda: s.solve(probs, g_st, g_warm), count, prep=reset_pageable)
         if count >= 65536:   # (staged batches this large go through in four pieces on two streams: the one-piece path beside it)
-            os.environ["NEO_MPC_NO_CHUNKS"] = "1"
-            res["pageable_one_piece"] = rate(lambda: s.solve(probs, g_st, g_warm), count, prep=reset_pageable)
+            os.environ["NEO_MPC_NO_CHUNKS"] = "1"     # (read once, by neo_mpc_create: a handle of its own)
+            with BatchSolver(README_PARAMS) as s1:
+                s1.set_costmap(*cmap)
+                res["pageable_one_piece"] = rate(lambda: s1.solve(probs, g_st, g_warm), count, prep=reset_pageable)
             del os.environ["NEO_MPC_NO_CHUNKS"]
         p_probs, p_st, p_warm = pinned(np.ascontiguousarray(probs)), pinned(st), pinned(warm)
         p_cmd, p_sol = pinned(np.zeros(count, dtype=abi.COMMAND_DTYPE)), pinned(np.zeros((count, 9)))
