@@ -64,9 +64,9 @@ extern "C" {
 /* neo_mpc_command.flags */
 #define NEO_MPC_FLAG_RESET 1   /* new goal: warm start / last_control / waiting_time reset (py:358-361) */
 #define NEO_MPC_FLAG_STOPPED 2 /* zero twist because of the collision latch (py:374-377) */
-#define NEO_MPC_FLAG_SKIPPED 4 /* neo_mpc_problem.skip was set: no request was made for this robot this tick (cpp:234-236);
-                                  nothing but this flag has been written: state, warm start and the command's other fields
-                                  are what they were */
+#define NEO_MPC_FLAG_SKIPPED 4 /* neo_mpc_problem.skip was set: no request was made for this robot this tick (cpp:234-236).
+                                  Its state record and warm start have not been touched; the command is zero twist with this
+                                  flag alone, its rows of solution / predicted_path / velocities are zero */
 
 /* neo_mpc_params.compat_flags */
 #define NEO_MPC_COMPAT_ODOM_YAW_GOAL_W 1 /* py:213: odom_yaw takes quaternion w from the goal pose */
@@ -152,8 +152,8 @@ typedef struct neo_mpc_problem {
   int32_t switch_opt;      /* request.switch_opt = closer_to_goal (cpp:245); the reference stores it (py:354)
                               and never reads it -- carried so that the record is the request field for field */
   int32_t skip;            /* != 0: this robot makes NO request this tick -- the plugin threw before its service call
-                              (footprint cost 255, cpp:234-236; neo_mpc_select_carrots sets it with carrot status 3): the
-                              solver leaves the robot's state and warm start alone and writes NEO_MPC_FLAG_SKIPPED only */
+                              (footprint cost 255, cpp:234-236; neo_mpc_select_carrots sets it with every non-zero carrot
+                              status): the solver leaves the robot's state and warm start alone (NEO_MPC_FLAG_SKIPPED) */
   int32_t reserved_i;
   double reserved[5];      /* (never read by the device: a request is 216 bytes on the wire) */
 } neo_mpc_problem;
@@ -247,6 +247,8 @@ typedef struct neo_mpc_handle neo_mpc_handle;
 int neo_mpc_abi_version(void);
 int neo_mpc_behaviour_version(void);   /* NEO_MPC_BEHAVIOUR_VERSION of the library that answers */
 const char* neo_mpc_last_error(void);
+int neo_mpc_last_error_code(void);     /* the NEO_MPC_ERR_* of the calling thread's last failure (neo_mpc_create returns
+                                          NULL and no code) */
 
 /* Fills the defaults the reference node declares (py:49-75) and this build's solver options. */
 int neo_mpc_default_params(neo_mpc_params* params);

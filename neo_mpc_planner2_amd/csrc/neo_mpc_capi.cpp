@@ -22,6 +22,7 @@ using namespace neo_mpc;
 namespace {
 
 thread_local std::string g_error;
+thread_local int g_error_code = 0;
 
 int fail(int code, const char* fmt, ...) {
   char buf[512];
@@ -30,6 +31,7 @@ int fail(int code, const char* fmt, ...) {
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
   g_error = buf;
+  g_error_code = code;
   return code;
 }
 
@@ -42,6 +44,7 @@ int neo_mpc_set_error(int code, const char* fmt, ...) {
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
   g_error = buf;
+  g_error_code = code;
   return code;
 }
 namespace {
@@ -451,6 +454,7 @@ int neo_mpc_abi_version(void) { return NEO_MPC_ABI_VERSION; }
 int neo_mpc_behaviour_version(void) { return NEO_MPC_BEHAVIOUR_VERSION; }
 
 const char* neo_mpc_last_error(void) { return g_error.c_str(); }
+int neo_mpc_last_error_code(void) { return g_error_code; }
 
 int neo_mpc_default_params(neo_mpc_params* p) {
   if (!p) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "null params");

@@ -55,10 +55,6 @@ constexpr int kStallIterations = 5;
 constexpr int kBlockedRun = 3;       // dense Newton: this many iterations in a row not won by a decent Newton step ...
 constexpr double kBlockedStep = 0.25;  // ... (a proximal lane, or a Newton step cut below this) arm the blocked-run stop rule
 constexpr double kFinalFracGaussNewton = 0.3;   // stage-wise direction without the second-order terms: a full step has to be this much shorter than opt_tolerance to be the last
-#ifndef NEO_EXIT_HOPS
-#define NEO_EXIT_HOPS 1
-#endif
-constexpr int kExitHops = NEO_EXIT_HOPS;         // dense Newton: hops tried where the search was about to end (each restart lengthens the slowest search of a launch)
 constexpr int kLateIteration = 20;   // from here on the three-iteration window is the control_steps-3 one (neo_mpc_capi.cpp)
 
 // Study build (make timing -> libneo_mpc_timing.so): shader-clock stamps at the phase boundaries of
@@ -164,11 +160,8 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
 
   load_records(a, L, b, lane);
   // no request for this robot this tick (the plugin threw before its service call, cpp:234-236; K4 status 3): the node's
-  // state does not advance -- nothing but the flag is written
-  if (uniform_int(reinterpret_cast<const int*>(L + a.lds.prob)[PI_SKIP]) != 0) {
-    if (lane == 0) a.commands[b].flags = NEO_MPC_FLAG_SKIPPED;
-    return;
-  }
+  // state does not advance: state record and warm start keep their bytes, the outputs say "skipped" (rollout.h)
+  if (uniform_int(reinterpret_cast<const int*>(L + a.lds.prob)[PI_SKIP]) != 0) { skip_instance(a, b, lane); return; }
   select_map(a.map, L + a.lds.prob);
   int flags = reset_and_warm(a, L, b, lane) ? NEO_MPC_FLAG_RESET : 0;
   const double fcost = footprint_cost(a, L, b, lane);
@@ -285,7 +278,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   int npairs = 0, head = 0, nfev = 1, it = 0, status = NEO_MPC_STATUS_MAX_ITER, stall = 0;
   int blocked_run = 0;   // dense Newton: consecutive iterations not won by a decent Newton step
   int nblocked = 1;      // consecutive iterations not won by a Newton step of at least half its length (or won by a hop)
-  int exit_hops = 0;     // dense Newton: hops taken at the point where the search was about to end
+  double u_term = 0.0;   // dense Newton: sum of the costmap terms under the current iterate's rollout (0: every stage in a free cell)
   double gain1 = INFINITY, gain2 = INFINITY;  // objective decrease of the previous two iterations
   bool final_step = false;
   const int lane_id = lane;
@@ -310,7 +303,6 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     const double* TOL = L + tol_off;
     NEO_PHASE_DECL;
     NEO_PHASE(0);
-    bool stop = false;   // wave-uniform: one of the stop rules has fired (the exit block at the bottom of the loop)
     // ---- adjoint gradient of the tracking + terminal cost
     constexpr int kVars = 3 * kNwSteps;  // compile-time bound of the Newton system (= its size when kSteps > 0)
     const int nvr = kSteps ? kVars : nv;  // its size
@@ -817,14 +809,13 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       dm = wave_max_f(dm);
       const bool near_any = __ballot(anynear != 0) != 0ull;
       // (with a cheaper cell a hop away the search runs once more: its hop lanes decide)
-      if ((double)dm < TOL[T_EARLY] && !near_any && nhops == 0) { status = NEO_MPC_STATUS_CONVERGED; stop = true; }
+      if ((double)dm < TOL[T_EARLY] && !near_any && nhops == 0) { status = NEO_MPC_STATUS_CONVERGED; break; }
       // a full Newton step below opt_tolerance (SLSQP's own step test) is the last one: searched
       // and taken like any other, but nothing re-checks the point it lands on
       // (a Gauss-Newton step converges linearly: it has to be shorter to be the last)
       if ((double)dm < ((kRiccati && !exact_step) ? kFinalFracGaussNewton : 1.0) * TOL[T_FINAL] && !near_any) final_step = true;
     }
     NEO_PHASE(4);
-    if (!stop) {   // (closed in front of the exit block at the bottom of the loop)
     if (p.max_it > kDumpGradient && it == p.max_it - kDumpGradient - 1) {
       // test hook (neo_mpc_direction_batch): the search direction of lanes 32-63 in this iteration
       for (int k = lane; k < nv; k += kLanes) a.solution[(size_t)b * nv + k] = d[k];
@@ -894,14 +885,13 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         }, kNewton ? &cterm : nullptr);
     NEO_PHASE(5);
     if (!(fc == fc)) fc = INFINITY;
-    if (it == 0) f = lane_value(fc, 0);
+    if (it == 0) { f = lane_value(fc, 0); if (kNewton) u_term = lane_value(cterm, 0); }
     fb = fc;
     best = lane;
     wave_argmin(fb, best);
     }
     ++nfev;
-    if (!(fb < f)) { status = NEO_MPC_STATUS_CONVERGED; ++it; stop = true; }
-    if (!stop) {   // (closed in front of the exit block at the bottom of the loop)
+    if (!(fb < f)) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
     float stepmax = 0.0f;
     if (kSteps && kNewton) {
       // the winner holds its candidate in registers: it measures the step against u and overwrites u
@@ -986,6 +976,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     }
     gain2 = gain1; gain1 = gain;
     f = fb;
+    if (kNewton) u_term = lane_value(cterm, best);
     // (a hop that won says nothing about step lengths: damping and proximal step stay as they are)
     if (kRiccati && !(it == 0 && cold) && !hop_won) {   // (an iteration that had a Newton direction)
       const float bs = (float)lane_value(step, best);
@@ -1001,80 +992,73 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     WAVE_SYNC();
     NEO_PHASE(6);
     NEO_PHASE_DUMP();
-    if ((double)stepmax < TOL[T_XTOL] || stall >= kStallIterations || creeping || final_step || blocked_stop) { status = NEO_MPC_STATUS_CONVERGED; ++it; stop = true; }
-    }   // if (!stop): accept + stop rules
-    }   // if (!stop): candidates
-    if (!stop) continue;
-    // ---- the search is about to end (wave-uniform).
-    // Dense direction: look once for a cheaper costmap cell a hop away -- the hop candidates the stage-wise direction tries
-    // in every iteration (costmap.h edge_stickiness).  A search that closed in on a cell edge from the expensive side ends
-    // a millimetre short of a cost step no descent direction sees (held-out parameter set "a", w_costmap / w_trans = 0.08:
-    // one such step is worth 2e-3, P3 failed on 1 of 24 cases).  A hop that lowers the objective is taken and the search
-    // goes on from there, at most kExitHops times per solve.
-    if (kNewton && exit_hops < kExitHops && it < p.max_it && !(c.tile_geom & kTileFree) && p.max_it < kDumpGradient) {
-      bool has_hop = false;
-      float hop_x = 0.0f, hop_y = 0.0f;
-      {
-        // lane i < n: position and heading of stage i at u
-        double x = 0.0, y = 0.0, th = 0.0, cs = 1.0, sn = 0.0;
+    if ((double)stepmax < TOL[T_XTOL] || stall >= kStallIterations || creeping || final_step || blocked_stop) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
+  }
+
+  // ---- Dense direction: a search that has ENDED looks once for a cheaper costmap cell a hop away -- the hop candidates
+  // the stage-wise direction tries in every iteration (costmap.h edge_stickiness).  A search that closed in on a cell edge
+  // from the expensive side ends a millimetre short of a cost step no descent direction sees (held-out parameter set "a",
+  // w_costmap / w_trans = 0.08: one such step is worth 2e-3, P3 failed on 1 of 24 cases).  A hop that lowers the objective is
+  // taken; the search is not taken up again (measured on the mirror: restarting it gains 7e-6 per instance on average
+  // and lengthens the slowest searches of a launch by two iterations).  Skipped when no stage of the iterate has a costmap
+  // term under it: nothing is cheaper next door.
+  if (kNewton && status == NEO_MPC_STATUS_CONVERGED && u_term != 0.0 && !(c.tile_geom & kTileFree) && p.max_it < kDumpGradient) {
+    bool has_hop = false;
+    float hop_x = 0.0f, hop_y = 0.0f;
+    {
+      // lane i < n: position and heading of stage i at u
+      double x = 0.0, y = 0.0, th = 0.0, cs = 1.0, sn = 0.0;
 #pragma unroll
-        for (int k = 0; k < kNwSteps; ++k) {
-          if ((kSteps || k < n) && k <= lane) {
-            th += u[3 * k + 2] * p.dt;
-            sincos_heading<kTame>(th, &sn, &cs);
-            x += (u[3 * k] * cs - u[3 * k + 1] * sn) * p.dt;
-            y += (u[3 * k] * sn + u[3 * k + 1] * cs) * p.dt;
-          }
-        }
-        if (lane < n) {
-          double wxx, wxy, wyy, wlx, wly;
-          (void)edge_stickiness(a, c, L, x, y, cs, sn, wxx, wxy, wyy, wlx, wly, has_hop, hop_x, hop_y);
+      for (int k = 0; k < (kNewton ? (kSteps ? kSteps : kNewtonMaxSteps) : 1); ++k) {
+        if ((kSteps || k < n) && k <= lane) {
+          th += u[3 * k + 2] * p.dt;
+          sincos_heading<kTame>(th, &sn, &cs);
+          x += (u[3 * k] * cs - u[3 * k + 1] * sn) * p.dt;
+          y += (u[3 * k] * sn + u[3 * k + 1] * cs) * p.dt;
         }
       }
-      const unsigned long long hmask = __ballot(has_hop);
-      if (hmask != 0ull) {   // (wave-uniform)
-        const int rank = __popcll(hmask & ((1ull << lane) - 1ull));
-        double* t = L + a.lds.tol;
-        if (has_hop && rank < kHopLanes) {
-          reinterpret_cast<int*>(t + T_HOP_STAGE)[rank] = lane;
-          reinterpret_cast<float*>(t + T_HOP_VEC)[2 * rank] = hop_x;
-          reinterpret_cast<float*>(t + T_HOP_VEC)[2 * rank + 1] = hop_y;
-        }
-        const int nh = min(__popcll(hmask), (int)kHopLanes);
-        WAVE_SYNC();
-        // lane h < nh: the current point with the block of hop stage h changed
-        int hs = -1;
-        float hx = 0.0f, hy = 0.0f;
-        if (lane < nh) {
-          hs = reinterpret_cast<const int*>(t + T_HOP_STAGE)[lane];
-          hx = reinterpret_cast<const float*>(t + T_HOP_VEC)[2 * lane];
-          hy = reinterpret_cast<const float*>(t + T_HOP_VEC)[2 * lane + 1];
-        }
-        double hb0 = 0.0, hb1 = 0.0;
-        double fh = rollout_cost<kSteps, kTame>(
-            a, c, L,
-            [&](int i, double& b0, double& b1, double& b2) {
-              b0 = u[3 * i]; b1 = u[3 * i + 1]; b2 = u[3 * i + 2];
-              if (i == hs) { b0 += (double)hx; b1 += (double)hy; project_block<kTame>(p, b0, b1, b2); hb0 = b0; hb1 = b1; }
-            });
-        if (!(fh == fh) || lane >= nh) fh = INFINITY;
-        int hbest = lane;
-        wave_argmin(fh, hbest);
-        ++nfev;
-        WAVE_SYNC();
-        if (fh < f) {
-          if (lane == hbest) { u[3 * hs] = hb0; u[3 * hs + 1] = hb1; }
-          f = fh;
-          ++exit_hops;
-          status = NEO_MPC_STATUS_MAX_ITER; stall = 0; blocked_run = 0; final_step = false; gain1 = INFINITY; gain2 = INFINITY;
-          have_trig = false;
-          WAVE_SYNC();
-          --it;   // (the exit above has counted this iteration; the for statement counts again)
-          continue;
-        }
+      if (lane < n) {
+        double wxx, wxy, wyy, wlx, wly;
+        (void)edge_stickiness(a, c, L, x, y, cs, sn, wxx, wxy, wyy, wlx, wly, has_hop, hop_x, hop_y);
       }
     }
-    break;
+    const unsigned long long hmask = __ballot(has_hop);
+    if (hmask != 0ull) {   // (wave-uniform)
+      const int rank = __popcll(hmask & ((1ull << lane) - 1ull));
+      double* t = L + a.lds.tol;
+      if (has_hop && rank < kHopLanes) {
+        reinterpret_cast<int*>(t + T_HOP_STAGE)[rank] = lane;
+        reinterpret_cast<float*>(t + T_HOP_VEC)[2 * rank] = hop_x;
+        reinterpret_cast<float*>(t + T_HOP_VEC)[2 * rank + 1] = hop_y;
+      }
+      const int nh = min(__popcll(hmask), (int)kHopLanes);
+      WAVE_SYNC();
+      // lane h < nh: the current point with the block of hop stage h changed
+      int hs = -1;
+      float hx = 0.0f, hy = 0.0f;
+      if (lane < nh) {
+        hs = reinterpret_cast<const int*>(t + T_HOP_STAGE)[lane];
+        hx = reinterpret_cast<const float*>(t + T_HOP_VEC)[2 * lane];
+        hy = reinterpret_cast<const float*>(t + T_HOP_VEC)[2 * lane + 1];
+      }
+      double hb0 = 0.0, hb1 = 0.0;
+      double fh = rollout_cost<kSteps, kTame>(
+          a, c, L,
+          [&](int i, double& b0, double& b1, double& b2) {
+            b0 = u[3 * i]; b1 = u[3 * i + 1]; b2 = u[3 * i + 2];
+            if (i == hs) { b0 += (double)hx; b1 += (double)hy; project_block<kTame>(p, b0, b1, b2); hb0 = b0; hb1 = b1; }
+          });
+      if (!(fh == fh) || lane >= nh) fh = INFINITY;
+      int hbest = lane;
+      wave_argmin(fh, hbest);
+      ++nfev;
+      WAVE_SYNC();
+      if (fh < f) {
+        if (lane == hbest) { u[3 * hs] = hb0; u[3 * hs + 1] = hb1; }
+        f = fh;
+        WAVE_SYNC();
+      }
+    }
   }
 
   NEO_SEGMENT(1);
@@ -1100,10 +1084,7 @@ __global__ __launch_bounds__(kLanes) void k_postprocess(const SolveArgs args) {
   if (b >= a.count) return;
   const int nv = 3 * a.p.n;
   load_records(a, L, b, lane);
-  if (uniform_int(reinterpret_cast<const int*>(L + a.lds.prob)[PI_SKIP]) != 0) {   // (no request this tick: see k_solve)
-    if (lane == 0) a.commands[b].flags = NEO_MPC_FLAG_SKIPPED;
-    return;
-  }
+  if (uniform_int(reinterpret_cast<const int*>(L + a.lds.prob)[PI_SKIP]) != 0) { skip_instance(a, b, lane, true); return; }   // (no request this tick: see k_solve)
   select_map(a.map, L + a.lds.prob);
   int flags = reset_and_warm(a, L, b, lane) ? NEO_MPC_FLAG_RESET : 0;
   const double fcost = footprint_cost(a, L, b, lane);

@@ -249,6 +249,25 @@ __device__ bool reset_and_warm(const SolveArgs& a, double* L, uint32_t b, int la
   return !same;
 }
 
+// neo_mpc_problem.skip: the reference made no optimizer call for this robot this tick (the plugin threw in front of it,
+// cpp:234-236).  The node's state does not advance -- state record and warm start are not touched --, the command is
+// zero twist with NEO_MPC_FLAG_SKIPPED and the optional outputs of the instance are zero rows (defined bytes whatever
+// path the batch took to the device).
+__device__ void skip_instance(const SolveArgs& a, uint32_t b, int lane, bool solution_is_input = false) {
+  const int nv = 3 * a.p.n;
+  if (lane == 0) {
+    neo_mpc_command cmd;
+    cmd.vel[0] = 0.0; cmd.vel[1] = 0.0; cmd.vel[2] = 0.0; cmd.cost = 0.0;
+    cmd.status = 0; cmd.iterations = 0; cmd.evaluations = 0; cmd.flags = NEO_MPC_FLAG_SKIPPED;
+    a.commands[b] = cmd;
+  }
+  if (a.velocities && lane < 3) a.velocities[3 * (size_t)b + lane] = 0.0;
+  for (int k = lane; k < nv; k += kLanes) {
+    if (a.solution && !solution_is_input) a.solution[(size_t)b * nv + k] = 0.0;   // (K2 alone: `solution` is an INPUT)
+    if (a.path) a.path[(size_t)b * nv + k] = 0.0;
+  }
+}
+
 // costmap pool: point `m` at the map the request names (wave-uniform), the single map otherwise
 template <bool kUniform = true>
 __device__ __forceinline__ void select_map(DevMap& m, const double* P) {

@@ -25,7 +25,8 @@ class BatchSolver:
         self.device = int(device)
         h = self._lib.neo_mpc_create(C.byref(ps), self.device)
         if not h:
-            raise _lib.NeoMpcError(-1, (self._lib.neo_mpc_last_error() or b"").decode())
+            code = self._lib.neo_mpc_last_error_code() if hasattr(self._lib, "neo_mpc_last_error_code") else -1
+            raise _lib.NeoMpcError(code, (self._lib.neo_mpc_last_error() or b"").decode())
         self._handle = C.c_void_p(h)
         self._keep = None
         self._last_call = None

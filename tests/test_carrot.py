@@ -113,6 +113,7 @@ def test_footprint_cost_255_makes_no_request():
     sk = probs["skip"] != 0
     assert (cm["flags"][sk] == abi.FLAG_SKIPPED).all() and ((cm["flags"][~sk] & abi.FLAG_SKIPPED) == 0).all()
     assert st[sk].tobytes() == st0[sk].tobytes() and (warm[sk] == warm0[sk]).all() and (cm["vel"][sk] == 0.0).all()
+    assert (cm["iterations"][sk] == 0).all() and (cm["cost"][sk] == 0.0).all()
     assert st[~sk].tobytes() != st0[~sk].tobytes()
 
 
@@ -173,9 +174,9 @@ def test_carrots_feed_the_solver_on_device():
 
 @pytest.mark.gpu
 def test_skipped_instances_are_left_alone_by_the_solver():
-    """neo_mpc_problem.skip (set by K4 with carrot status 3, cpp:234-236): K1 and K2 write NEO_MPC_FLAG_SKIPPED and nothing
-    else -- state, warm start, solution and the command's other fields keep their bytes -- on the staged path, the small
-    latency path and the in-place (page-locked) path; the other instances come out exactly as without any skip."""
+    """neo_mpc_problem.skip (set by K4 with carrot status 3, cpp:234-236): K1 and K2 leave the robot's state record and warm
+    start alone and answer zero twist + NEO_MPC_FLAG_SKIPPED (zero rows in the optional outputs) -- on the staged path, the
+    small latency path and the in-place (page-locked) path; the other instances come out exactly as without any skip."""
     import ctypes as C
     from neo_mpc_planner2_amd import _lib
     from neo_mpc_planner2_amd.solver import BatchSolver
@@ -199,7 +200,8 @@ def test_skipped_instances_are_left_alone_by_the_solver():
             cmds["vel"] = 7.0
             sol = np.full((count, 9), 5.0)
             s.solve(p2, st_b, warm_b, out=(cmds, sol))
-            assert (cmds["flags"][sk] == abi.FLAG_SKIPPED).all() and (cmds["vel"][sk] == 7.0).all() and (sol[sk] == 5.0).all()
+            assert (cmds["flags"][sk] == abi.FLAG_SKIPPED).all() and (cmds["vel"][sk] == 0.0).all() and (sol[sk] == 0.0).all()
+            assert (cmds["iterations"][sk] == 0).all() and (cmds["status"][sk] == 0).all() and (cmds["cost"][sk] == 0.0).all()
             assert st_b[sk].tobytes() == st0[sk].tobytes() and (warm_b[sk] == warm0[sk]).all()
             assert cmds[~sk].tobytes() == ref[~sk].tobytes() and (sol[~sk] == xref[~sk]).all()
             assert st_b[~sk].tobytes() == st_a[~sk].tobytes() and (warm_b[~sk] == warm_a[~sk]).all()

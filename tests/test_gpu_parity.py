@@ -366,7 +366,7 @@ def test_forced_directions_without_a_wall_model_are_refused_at_heavy_costmap_wei
         assert e.value.code == -5
     with pytest.raises(_lib.NeoMpcError) as e:
         solver_mod.BatchSolver(util.orc.make_params(compat_flags=1 | 0x40))
-    assert e.value.code == -1 and "compat_flags" in str(e.value)
+    assert e.value.code == -1 and "compat_flags" in str(e.value) and lib.neo_mpc_last_error_code() == -1
     solver_mod.BatchSolver(util.orc.make_params(compat_flags=abi.COMPAT_ODOM_YAW_GOAL_W | abi.COMPAT_REFERENCE_START)).close()
 
 
