@@ -76,7 +76,11 @@ def pcie_inclusive(solver, probs, st, warm, n, seconds=3.0):
         t_all += time.perf_counter() - t0
         reps += 1
     res = {"value": count * reps / t_all, "unit": "solves/s", "ms_per_call": 1e3 * t_all / reps, "calls": reps,
+           # (round 4: the device reads 216 of a request's 256 bytes and 104 of a state record's 128; it writes back 48 bytes
+           # of state per tick -- old_goal only when it changed -- + warm start + command + solution; the staged path still
+           # copies whole records)
            "bytes_in_per_call": count * (256 + 128 + 24 * n), "bytes_out_per_call": count * (48 + 128 + 48 * n),
+           "bytes_in_per_call_in_place": count * (216 + 104 + 24 * n), "bytes_out_per_call_in_place": count * (48 + 48 + 48 * n),
            "what": "neo_mpc_solve_batch on host buffers (pageable NumPy arrays), same instances, cold start"}
     # the same call on page-locked host buffers (what a fleet server that owns its request arena would hand over):
     # every transfer is then a DMA queued behind / in front of the kernel, one wait per call
@@ -253,41 +257,74 @@ def source_sha():
 
 
 def pmc_entry(workload, batch):
-    """HBM bytes / VALU instructions per launch from the committed PMC passes (profiles/hbm_traffic.json): reported
-    only while the device sources are the ones the counters were collected on (source_sha) and the batch is the
-    config's; (None, None, reason) otherwise."""
+    """The committed PMC passes of a workload (profiles/hbm_traffic.json): reported only while the device sources are the
+    ones the counters were collected on (source_sha) and the batch is the config's; (None, reason) otherwise."""
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if not os.path.exists(tpath):
-        return None, None, "no profiles/hbm_traffic.json"
+        return None, "no profiles/hbm_traffic.json"
     try:
         entry = json.load(open(tpath)).get(workload)
     except Exception as e:
-        return None, None, "profiles/hbm_traffic.json unreadable: %s" % e
+        return None, "profiles/hbm_traffic.json unreadable: %s" % e
     if not isinstance(entry, dict):
-        return None, None, "no PMC entry for this workload in profiles/hbm_traffic.json"
+        return None, "no PMC entry for this workload in profiles/hbm_traffic.json"
     if entry.get("source_sha") != source_sha():
-        return None, None, "stale: PMC passes ran on source_sha %s, this build is %s" % (entry.get("source_sha"), source_sha())
+        return None, "stale: PMC passes ran on source_sha %s, this build is %s" % (entry.get("source_sha"), source_sha())
     if entry.get("batch") != batch:
-        return None, None, "PMC passes ran at batch %s" % entry.get("batch")
-    valu = entry.get("valu_insts")
-    if valu and entry.get("valu_f32_fma_add_mul") is not None:
-        valu = (valu, entry["valu_f32_fma_add_mul"])   # (all vector instructions, the plain float32 fma/add/mul among them)
-    return entry.get("hbm_bytes"), valu, entry.get("note")
+        return None, "PMC passes ran at batch %s" % entry.get("batch")
+    return entry, entry.get("note")
 
 
-def valu_issue(valu, k_ms):
-    """what actually bounds K1: VALU issue.  SQ_INSTS_VALU of the committed PMC pass priced in
-    issue cycles -- 4 per wave64 instruction, 2 for plain float32 fma / add / mul (measured: tools/mb_valu_rates.hip;
-    their count comes from the type-mix PMC pass) -- over 1024 SIMDs x this run's kernel time at the nominal clock.
-    `frac_at_4_cycles` prices every instruction at 4 cycles (the figure of rounds 1-2)."""
-    if not valu:
+#: issue cycles per wave64 instruction by counter class (tools/mb_valu_rates.hip, mb_select_rates.hip; table in
+#: profiles/r03_b_ab_experiments.txt): float64 and transcendental / conversion instructions 4, plain float32 fma / add / mul
+#: and 32-bit integer arithmetic 2.  What no typed counter covers -- moves, selects, compares, lane reads, DPP -- was
+#: measured at 2 (moves) to 4 (compares, SGPR-masked selects, v_readlane, DPP): priced at both, `frac_low` / `frac_high`.
+VALU_CYCLES = {"FMA_F64": 4, "ADD_F64": 4, "MUL_F64": 4, "TRANS_F64": 4, "TRANS_F32": 4, "CVT": 4, "INT64": 4,
+               "FMA_F32": 2, "ADD_F32": 2, "MUL_F32": 2, "INT32": 2}
+
+
+def valu_issue(entry, k_ms):
+    """what actually bounds K1: VALU issue.  SQ_INSTS_VALU of the committed PMC pass priced in issue
+    cycles by instruction class (VALU_CYCLES; the class counts come from the type-mix PMC passes) over 1024 SIMDs x this
+    run's kernel time at the clock MEASURED in the PMC pass (GRBM_GUI_ACTIVE per XCD over the dispatch's own duration),
+    not the 2.4 GHz name-plate.  `frac_at_4_cycles` prices every instruction at 4 cycles at the name-plate clock (the
+    figure of rounds 1-2)."""
+    if not entry or not entry.get("valu_insts"):
         return None
-    total, fast = valu if isinstance(valu, tuple) else (valu, None)
-    simd_cycles = 1024 * k_ms * 1e-3 * SIMD_CLOCK_GHZ * 1e9
-    out = {"insts_per_launch": total, "f32_fma_add_mul_per_launch": fast, "simds": 1024, "clock_ghz": SIMD_CLOCK_GHZ,
-           "frac_at_4_cycles": total * 4 / simd_cycles}
-    out["frac"] = (total * 4 - (fast or 0) * 2) / simd_cycles
+    total, mix = entry["valu_insts"], entry.get("valu_mix") or {}
+    clock = entry.get("clock_ghz_measured") or SIMD_CLOCK_GHZ
+    simd_cycles = 1024 * k_ms * 1e-3 * clock * 1e9
+    typed = {k: mix.get("SQ_INSTS_VALU_" + k, 0.0) for k in VALU_CYCLES}
+    typed_cycles = sum(VALU_CYCLES[k] * v for k, v in typed.items())
+    untyped = max(0.0, total - sum(typed.values()))
+    out = {"insts_per_launch": total, "typed_insts_per_launch": sum(typed.values()), "untyped_insts_per_launch": untyped,
+           "simds": 1024, "clock_ghz": clock, "clock_ghz_measured": entry.get("clock_ghz_measured"),
+           "clock_note": entry.get("clock_note"),
+           "frac_low": (typed_cycles + 2 * untyped) / simd_cycles, "frac_high": (typed_cycles + 4 * untyped) / simd_cycles,
+           "frac_at_4_cycles": total * 4 / (1024 * k_ms * 1e-3 * SIMD_CLOCK_GHZ * 1e9)}
+    out["frac"] = 0.5 * (out["frac_low"] + out["frac_high"])
     return out
+
+
+def roofline(workload, batch, n, k_ms, launches_timed=None, params_over=None):
+    """The HBM object the north star asks for + what actually limits the kernel.  `achieved` = algorithmic bytes per launch
+    over the kernel's mean duration; `traffic` = HBM bytes per launch from the committed PMC passes, CORRECTED with the
+    calibration of the counters on K1's own access shapes (tools/mb_k1_traffic.hip; raw FETCH_SIZE / WRITE_SIZE beside it)."""
+    algo = ALGO_BYTES.get(n, (17 + 3 * n) * 4 + (3 + 3 * n + 1) * 4 + 729)
+    achieved = algo * batch / (k_ms * 1e-3) / 1e9
+    entry, note = pmc_entry(workload, batch) if not params_over else (None, "other parameter set")
+    r = {"bound": "hbm", "limiting": "valu_issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_note": note, "kernel": "k_solve", "kernel_ms": k_ms,
+         "algorithmic_bytes_per_solve": algo}
+    if launches_timed is not None:
+        r["kernel_ms_launches_timed"] = launches_timed
+    if entry:
+        r["traffic"] = entry.get("hbm_bytes_calibrated") or entry.get("hbm_bytes")
+        r["traffic_raw"] = entry.get("hbm_bytes")
+        r["traffic_note"] = ("calibrated: " + entry["calibration_note"]) if entry.get("hbm_bytes_calibrated") else \
+            ("raw counters (no calibration entry): " + str(entry.get("note")))
+        r["traffic_over_algorithmic"] = r["traffic"] / (algo * batch) if r["traffic"] else None
+    return r, entry
 
 
 def other_workload(name, dev, local_rank, steps=3, warmup=1, params_over=None, label=None):
@@ -332,18 +369,13 @@ def other_workload(name, dev, local_rank, steps=3, warmup=1, params_over=None, l
         elapsed = time.perf_counter() - t0
         k_ms = float(np.mean([a.elapsed_time(b) for (a, b), on in zip(evs, stamped) if on]))
         cmds = sets[-1].commands_host()
-    algo = ALGO_BYTES.get(n, (17 + 3 * n) * 4 + (3 + 3 * n + 1) * 4 + 729)
-    achieved = algo * cfg["batch"] / (k_ms * 1e-3) / 1e9
-    traffic, valu, note = pmc_entry(name, cfg["batch"]) if not params_over else (None, None, "other parameter set")
+    roof, entry = roofline(name, cfg["batch"], n, k_ms, params_over=params_over)
     return {"workload": label or name, "batch": cfg["batch"], "control_steps": n, "map_size": cfg["map_size"],
             "steps": steps, "value": cfg["batch"] * steps / elapsed, "unit": "solves/s", "ms_per_step": 1e3 * elapsed / steps,
             "kernel_ms": k_ms,
             "solver": {"mean_iterations": float(cmds["iterations"].mean()), "max_iterations_seen": int(cmds["iterations"].max()),
                        "converged_frac": float((cmds["status"] == 0).mean()), "status_max_iter": int((cmds["status"] == 1).sum())},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": note,
-                         "algorithmic_bytes_per_solve": algo},
-            "valu_issue": valu_issue(valu, k_ms)}
+            "roofline": roof, "valu_issue": valu_issue(entry, k_ms)}
 
 
 #: parameter sets away from the README's that take the GENERAL (non-"tame") kernels -- the ones the G8 fixtures pin:
@@ -379,7 +411,7 @@ def spawn_ranks(n):
     import subprocess
     import torch
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and os.environ.get("NEO_MPC_BENCH_SHARE_DEVICE") != "1":
         raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible" % (n, have))
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -433,6 +465,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # NEO_MPC_BENCH_SHARE_DEVICE=1: every rank on device 0 -- the whole world > 1 path (spawned ranks, per-rank seeds, the
+    # all-gather on device tensors, the MAX reduce, rccl.per_rank, the JSON line) on a box with ONE GPU.  RCCL refuses two
+    # ranks on one device, so the collective goes through gloo (host-staged in sharding.gather_commands); the numbers of
+    # such a run measure nothing, its `rccl.gather_check` and the shape of the line are what it is for.
+    share = os.environ.get("NEO_MPC_BENCH_SHARE_DEVICE") == "1" and world > 1
+    if share:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit("rank %d: HIP device %d is not visible (%d devices)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
@@ -445,7 +484,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+    comm_dev = "cpu" if share else dev      # where the small bookkeeping collectives live (gloo gathers host tensors only)
 
     cfg = dict(synthetic.CONFIGS[args.workload])
     if args.workload == "C4":
@@ -555,14 +598,26 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = [pair[0].elapsed_time(pair[1]) for pair in evs if pair is not None]
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
     per_rank = None
+    gather_check = None
     if use_dist:
-        # every rank's own time beside the maximum: a SCALE run that falls short shows which rank (GPU) was slow
-        mine = torch.tensor([elapsed, float(np.mean(kernel_ms))], dtype=torch.float64, device=dev)
+        # every rank's own time beside the maximum: a SCALE run that falls short shows which rank (GPU) was slow; and a
+        # checksum of the commands the rank itself produced in the last step, to hold against its slice of the gathered
+        # buffer (rank 0 sees every slice: gathered == the concatenation of the ranks' own commands)
+        last = sets[args.steps - 1].vel
+        own_sum, own_abs = float(last.sum().item()), float(last.abs().sum().item())
+        mine = torch.tensor([elapsed, float(np.mean(kernel_ms)), own_sum, own_abs], dtype=torch.float64, device=comm_dev)
         every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
         dist.all_gather(every, mine)
         per_rank = [(float(e[0]), float(e[1])) for e in every]
+        g = gathered[(args.steps - 1) % ring]
+        ok = [bool(float(g[r].sum().item()) == float(e[2]) and float(g[r].abs().sum().item()) == float(e[3]))
+              for r, e in enumerate(every)]
+        gather_check = {"ok": all(ok) and bool((g[rank] == last).all().item()), "per_rank": ok,
+                        "distinct_slices": len({float(e[3]) for e in every}) == len(every),
+                        "what": "sum and sum|.| of every rank's own last-step commands (sent through a second collective) "
+                                "against its slice of the gathered buffer on rank 0; rank 0's own slice element by element"}
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -571,9 +626,7 @@ def main():
         total_instances = cfg["batch"] * world
         value = total_instances * args.steps / elapsed
         k_ms = float(np.mean(kernel_ms))
-        algo_bytes = ALGO_BYTES.get(n, (17 + 3 * n) * 4 + (3 + 3 * n + 1) * 4 + 729)   # BASELINE.md's per-solve figure
-        achieved = algo_bytes * cfg["batch"] / (k_ms * 1e-3) / 1e9
-        traffic, valu, traffic_note = pmc_entry(args.workload, cfg["batch"])
+        roof, pmc = roofline(args.workload, cfg["batch"], n, k_ms, launches_timed=len(kernel_ms))
         out = {
             "metric": "MPC solves/sec (control_steps=%d, %dx%d costmap)" % (n, cfg["map_size"], cfg["map_size"]),
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -584,11 +637,8 @@ def main():
                                                                   cfg["map_size"]),
                        "parallelism": "instances sharded x%d, 1 RCCL all-gather of (vx,vy,w)/step" % world
                        if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                         "kernel": "k_solve", "kernel_ms": k_ms, "kernel_ms_launches_timed": len(kernel_ms),
-                         "algorithmic_bytes_per_solve": algo_bytes},
-            "valu_issue": valu_issue(valu, k_ms),
+            "roofline": roof,
+            "valu_issue": valu_issue(pmc, k_ms),
             **({"study_streams": args.streams} if args.streams > 1 else {}),
             "solver": {"mean_iterations": float(cmds["iterations"].mean()),
                        "max_iterations_seen": int(cmds["iterations"].max()),
@@ -597,7 +647,8 @@ def main():
                        "status_max_iter": int((cmds["status"] == 1).sum())},
         }
         if use_dist:
-            out["rccl"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+            out["rccl"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "shared_device": share,
+                           "gather_check": gather_check,
                            "gather_ms": float(np.mean([a.elapsed_time(b) for a, b in gather_evs])) if gather_evs else None,
                            "gather_bytes_per_rank": cfg["batch"] * 24,
                            "per_rank": [{"rank": r, "ms_per_step": 1e3 * e / args.steps, "kernel_ms": k,
@@ -606,6 +657,11 @@ def main():
                                    "step's solve; gather_ms = its own duration (events on the side stream)"}
         if world == 1 and not args.no_pcie:
             out["pcie_inclusive"] = pcie_inclusive(solver, probs, st, warm, n)
+            # SURVEY 8d's own metric (H2D of the requests and D2H of the results inside the clock), first class beside
+            # `value` (the resident-data variant): page-locked arrays worked on in place, and pageable ones
+            pin = out["pcie_inclusive"].get("pinned") or {}
+            out["value_pcie_inclusive"] = pin.get("value")
+            out["value_pcie_inclusive_pageable"] = out["pcie_inclusive"]["value"]
         if world == 1 and not args.no_others and args.workload == "C2" and not args.batch:
             # the other BASELINE configs and the deployed (closed-loop, warm-started) mode, a few launches each, so
             # that the driver's line carries them; the inputs are generated here, outside every timed region

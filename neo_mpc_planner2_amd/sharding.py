@@ -28,10 +28,24 @@ def gather_commands(local, out=None, group=None, async_op=False):
     local = local.contiguous()
     if out is None:
         out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo gathers host tensors only: staged through the host.  (What `bench.py --gpus N` uses when every rank shares
+        # ONE device -- NEO_MPC_BENCH_SHARE_DEVICE=1, RCCL refuses that --, so that the world > 1 path runs on a 1-GPU box.)
+        host = torch.empty((world,) + tuple(local.shape), dtype=local.dtype)
+        dist.all_gather_into_tensor(host.view((-1,) + tuple(local.shape[1:])), local.cpu(), group=group)
+        out.copy_(host)
+        return (out, _Done()) if async_op else out
     # concatenated layout [world * n_local, 3] (the form both RCCL and gloo accept)
     work = dist.all_gather_into_tensor(out.view((-1,) + tuple(local.shape[1:])), local, group=group,
                                        async_op=async_op)
     return (out, work) if async_op else out
+
+
+class _Done:
+    """work handle of a collective that has already completed"""
+
+    def wait(self):
+        return True
 
 
 def solve_sharded(solve_fn, problems, states, warm, group=None):
