@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long fixture regeneration from the reference (NEO_MPC_REGEN_ALL=1)")
 
 
 @pytest.fixture(scope="session")

@@ -26,5 +26,8 @@ done
 cd $R
 python tools/rocprof_summary.py kernels $OUT/trace_results.db > $OUT/kernels.txt 2>&1
 python tools/rocprof_summary.py pmc $OUT > $OUT/pmc.txt 2>&1
-python tools/rocprof_summary.py traffic $OUT $W > $OUT/traffic_entry.json 2>&1
+# (the FETCH_SIZE / WRITE_SIZE calibration on K1's access shapes, when tools/profile_k1_traffic.sh has run for this tag)
+CAL=$R/gpurun_out/prof_${TAG}_k1cal/calibration.json
+[ -f $CAL ] || CAL=""
+python tools/rocprof_summary.py traffic $OUT $W k_solve $CAL > $OUT/traffic_entry.json 2>&1
 cat $OUT/kernels.txt $OUT/pmc.txt $OUT/traffic_entry.json
