@@ -20,6 +20,30 @@ __device__ __forceinline__ double rcp_fast(double x) {
   return r;
 }
 
+// a * b + c as ONE three-address v_fma_f64.  Left to itself the compiler turns the Horner steps of the polynomial kernels
+// below into v_mov_b64 (copy the coefficient) + v_fmac_f64 (two-address multiply-accumulate into the copy): the coefficients
+// live across the solver loop, so every step pays a 64-bit move -- ten per sincos, sixty per solver iteration of the
+// control_steps-3 kernel (tools/opcode_histogram.py: v_mov_b64 was the third most frequent vector opcode of the loop).
+__device__ __forceinline__ double fma3(double a, double b, double c) {
+#ifdef NEO_NO_FMA3
+  return fma(a, b, c);
+#else
+  // (the addend -- a literal coefficient -- in a SCALAR register pair: two s_mov_b32 on the scalar unit instead of sixteen
+  // loop-resident vector registers of coefficients)
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+  return r;
+#endif
+}
+
+// 1/sqrt(x), x > 0, to ~1e-13 relative: v_rsq_f64 (2^-26.x, tools/rsq_check.hip) and ONE Newton step -- for quantities that
+// place a candidate (the prox step's shrink factor, the radial projection onto the speed disc): the objective of every
+// candidate is evaluated at the point it actually is
+__device__ __forceinline__ double rsq_fast1(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  return r * fma(fma(-x * r, r, 1.0), 0.5, 1.0);
+}
+
 // 1/sqrt(x), x > 0: v_rsq_f64 and two Newton steps
 __device__ __forceinline__ double rsq_fast(double x) {
   double r = __builtin_amdgcn_rsq(x);
@@ -51,16 +75,16 @@ __device__ __forceinline__ void sincos_fast(double x, double* sn, double* cs) {
   r = fma(-k, 2.02226624879595063154e-21, r);
   const double z = r * r;
   double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-  ps = fma(z, ps, 2.75573137070700676789e-06);
-  ps = fma(z, ps, -1.98412698298579493134e-04);
-  ps = fma(z, ps, 8.33333333332248946124e-03);
-  ps = fma(z, ps, -1.66666666666666324348e-01);
+  ps = fma3(z, ps, 2.75573137070700676789e-06);
+  ps = fma3(z, ps, -1.98412698298579493134e-04);
+  ps = fma3(z, ps, 8.33333333332248946124e-03);
+  ps = fma3(z, ps, -1.66666666666666324348e-01);
   const double sr = fma(z * r, ps, r);
   double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-  pc = fma(z, pc, -2.75573143513906633035e-07);
-  pc = fma(z, pc, 2.48015872894767294178e-05);
-  pc = fma(z, pc, -1.38888888888741095749e-03);
-  pc = fma(z, pc, 4.16666666666666019037e-02);
+  pc = fma3(z, pc, -2.75573143513906633035e-07);
+  pc = fma3(z, pc, 2.48015872894767294178e-05);
+  pc = fma3(z, pc, -1.38888888888741095749e-03);
+  pc = fma3(z, pc, 4.16666666666666019037e-02);
   const double cr = fma(z * z, pc, fma(z, -0.5, 1.0));
   const int q = (int)fmin(fmax(k, -2.0e9), 2.0e9) & 3;
   const double s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
@@ -74,16 +98,16 @@ __device__ __forceinline__ void sincos_fast(double x, double* sn, double* cs) {
 __device__ __forceinline__ void sincos_small(double r, double* sn, double* cs) {
   const double z = r * r;
   double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-  ps = fma(z, ps, 2.75573137070700676789e-06);
-  ps = fma(z, ps, -1.98412698298579493134e-04);
-  ps = fma(z, ps, 8.33333333332248946124e-03);
-  ps = fma(z, ps, -1.66666666666666324348e-01);
+  ps = fma3(z, ps, 2.75573137070700676789e-06);
+  ps = fma3(z, ps, -1.98412698298579493134e-04);
+  ps = fma3(z, ps, 8.33333333332248946124e-03);
+  ps = fma3(z, ps, -1.66666666666666324348e-01);
   *sn = fma(z * r, ps, r);
   double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-  pc = fma(z, pc, -2.75573143513906633035e-07);
-  pc = fma(z, pc, 2.48015872894767294178e-05);
-  pc = fma(z, pc, -1.38888888888741095749e-03);
-  pc = fma(z, pc, 4.16666666666666019037e-02);
+  pc = fma3(z, pc, -2.75573143513906633035e-07);
+  pc = fma3(z, pc, 2.48015872894767294178e-05);
+  pc = fma3(z, pc, -1.38888888888741095749e-03);
+  pc = fma3(z, pc, 4.16666666666666019037e-02);
   *cs = fma(z * z, pc, fma(z, -0.5, 1.0));
 }
 template <bool kTame>

@@ -19,11 +19,15 @@ __device__ __forceinline__ double clampd(double v, double lo, double hi) { retur
 // kTame: the caller knows at compile time that the disc lies inside the vx/vy box (DevParams.tame)
 template <bool kTame = false>
 __device__ __forceinline__ void project_block(const DevParams& p, double& b0, double& b1, double& b2) {
-  b2 = clampd(b2, p.lo[2], p.hi[2]);
+  // (v_max / v_min: two instructions where the compare-and-select form of clampd takes eight; a NaN turn rate -- only ever
+  // next to NaN velocities, whose candidate is discarded -- comes out as a bound)
+  b2 = fmin(fmax(b2, p.lo[2]), p.hi[2]);
   const double zx = b0, zy = b1, r = p.r;
   if (kTame || p.disc_in_box) {  // README parameters: the box never binds, the projection is radial
     const double n2 = zx * zx + zy * zy;
-    if (n2 > r * r) { const double sc = r * rsq_fast(n2); b0 = zx * sc; b1 = zy * sc; }
+    // (one Newton step on v_rsq_f64: the point lands within 1e-13 of the disc -- and never outside r (1 + 1e-12), which is
+    // what the tangent-cone pass calls "on the disc")
+    if (n2 > r * r) { const double sc = r * rsq_fast1(n2); b0 = zx * sc; b1 = zy * sc; }
     return;
   }
   const double px = clampd(zx, p.lo[0], p.hi[0]), py = clampd(zy, p.lo[1], p.hi[1]);
@@ -91,7 +95,9 @@ __device__ __forceinline__ void candidate_block(const SolveArgs& a, const Ctx& c
   // step is made with the gradient at u, the other blocks' Newton step was computed with them held: when both correct
   // the same residual the candidate overshoots, the search cuts the step length for everybody (the "hovering" searches
   // of warm-started ticks: 2.2 % of the converged reference's commands missed by more than 1e-3, none with this)
+#ifndef NEO_AB_NO_NEARPUT
   if (near && lane >= 32 && (lane & 1)) { b0 = u[0]; b1 = u[1]; b2 = u[2]; return; }
+#endif
   if (lane < 32 || near) {  // proximal gradient: forward step on the smooth part (for a block next to the kink: reduced
                             // on its face by the tangent-cone pass), prox of the control norm
     if (lane >= 32) step = pstep;
@@ -100,7 +106,7 @@ __device__ __forceinline__ void candidate_block(const SolveArgs& a, const Ctx& c
     const double e0 = (u[0] - step * gs[0]) - c.v0, e1 = (u[1] - step * gs[1]) - c.v1,
                  e2 = (u[2] - step * gs[2]) - c.v2;
     const double ne2 = e0 * e0 + e1 * e1 + e2 * e2;
-    const double sh = (ne2 > 0.0) ? fmax(0.0, 1.0 - step * a.p.wc_n * rsq_fast(ne2)) : 0.0;
+    const double sh = (ne2 > 0.0) ? fmax(0.0, 1.0 - step * a.p.wc_n * rsq_fast1(ne2)) : 0.0;
     b0 = c.v0 + sh * e0; b1 = c.v1 + sh * e1; b2 = c.v2 + sh * e2;
   } else {          // quasi-Newton / Newton direction
     const double* d = L + a.lds.d + 3 * i;

@@ -295,7 +295,11 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     int lane = lane_id;
     asm volatile("" : "+v"(lane));
     // stage-wise direction: this iteration's sweep carries the second-order terms of the rollout step
+#ifdef NEO_AB_NO_TAU
+    const bool exact_step = false;
+#else
     const bool exact_step = kRiccati && nblocked == 0;
+#endif
     // (same trick for the tolerance block: an opaque LDS offset keeps its loads inside the loop and in
     // the LDS address space -- a volatile pointer would turn them into flat loads with a full wait each)
     int tol_off = a.lds.tol;
@@ -877,7 +881,9 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         a, c, L,
         [&](int i, double& b0, double& b1, double& b2) {
           candidate_block<kTame, kRiccati>(a, c, L, lane, step, pstep, i, b0, b1, b2, hop_stage, hop_x, hop_y);
-          if (it == 0 && lane == 0) { b0 = u[3 * i]; b1 = u[3 * i + 1]; b2 = u[3 * i + 2]; }
+          // (a scalar branch taken in the first iteration only -- the empty asm keeps the compiler from turning it into
+          // six selects per block that every iteration pays)
+          if (it == 0) { asm volatile(""); if (lane == 0) { b0 = u[3 * i]; b1 = u[3 * i + 1]; b2 = u[3 * i + 2]; } }
           if (kSteps) { cand[3 * i] = b0; cand[3 * i + 1] = b1; cand[3 * i + 2] = b2; }
         },
         [&](int i, double sn, double cs) {
