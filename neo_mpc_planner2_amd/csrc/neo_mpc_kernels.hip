@@ -170,9 +170,19 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   load_tile(a, c, L, lane);
   // the per-instance constants are wave-uniform: keep them in scalar registers
   c.cx = lane_value(c.cx, 0); c.cy = lane_value(c.cy, 0); c.tyaw = lane_value(c.tyaw, 0);
-  c.fyaw = lane_value(c.fyaw, 0); c.c0 = lane_value(c.c0, 0); c.s0 = lane_value(c.s0, 0);
-  c.X0 = lane_value(c.X0, 0); c.Y0 = lane_value(c.Y0, 0); c.v0 = lane_value(c.v0, 0);
+  c.fyaw = lane_value(c.fyaw, 0); c.v0 = lane_value(c.v0, 0);
   c.v1 = lane_value(c.v1, 0); c.v2 = lane_value(c.v2, 0);
+#ifdef NEO_GEOMETRY_IN_SGPRS
+  c.c0 = lane_value(c.c0, 0); c.s0 = lane_value(c.s0, 0); c.X0 = lane_value(c.X0, 0); c.Y0 = lane_value(c.Y0, 0);
+#else
+  // ... except the four the costmap lookup of every stage of every candidate needs (world position = X0 + Rot(psi0) (x, y)):
+  // they stay in VECTOR registers (every lane holds the same value).  The scalar file is over-subscribed -- a hundred
+  // scalars are spilled to vector lanes -- and each use of a spilled pair costs two v_readlane and a wait state: twelve
+  // lane reads per stage.  (Round 4: the three-address polynomial kernels freed nine vector registers.)
+  // (the general kernels have no vector register to spare at four waves per SIMD: scalar there, as before)
+  if (kTame) asm volatile("" : "+v"(c.c0), "+v"(c.s0), "+v"(c.X0), "+v"(c.Y0));
+  else { c.c0 = lane_value(c.c0, 0); c.s0 = lane_value(c.s0, 0); c.X0 = lane_value(c.X0, 0); c.Y0 = lane_value(c.Y0, 0); }
+#endif
   c.tile_x0 = uniform_int(c.tile_x0); c.tile_y0 = uniform_int(c.tile_y0); c.tile_geom = uniform_int(c.tile_geom);
 
   // The stop tolerances are read once per iteration: from LDS, so that they do not sit in (and get
