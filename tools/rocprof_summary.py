@@ -79,7 +79,8 @@ def traffic(directory, workload, match="k_solve", calibration=None):
         extra["hbm_bytes_calibrated"] = (vals["FETCH_SIZE"] * 1024 / cal["fetch_ratio_records"] +
                                          vals["WRITE_SIZE"] * 1024 / cal["write_ratio"])
         extra["calibration_note"] = ("FETCH_SIZE / %.3f + WRITE_SIZE / %.3f: the counters' ratios to the bytes K1's own access "
-                                     "shapes move (tools/mb_k1_traffic.hip, %s)" % (cal["fetch_ratio_records"], cal["write_ratio"], calibration))
+                                     "shapes move (tools/mb_k1_traffic.hip, %s)" % (cal["fetch_ratio_records"], cal["write_ratio"],
+                                                                                      os.path.relpath(calibration)))
     print(json.dumps({workload: {
         **extra,
         "hbm_bytes": (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024, "valu_insts": vals.get("SQ_INSTS_VALU"),
