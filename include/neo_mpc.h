@@ -257,7 +257,8 @@ int neo_mpc_default_params(neo_mpc_params* params);
  * cpp:308.  `device` is the HIP device ordinal.  NULL on failure.
  * The A/B switches of the measurement tools are environment variables READ HERE, ONCE (never on the solve path; a tool
  * that flips one re-creates its handle): NEO_MPC_SOLVE_WAVES=2|3|4, NEO_MPC_GENERIC_STEPS, NEO_MPC_NO_TAME_SPECIALISATION,
- * NEO_MPC_DYNAMIC_LDS (kernel variant), NEO_MPC_NO_EARLY (Newton step tests off), NEO_MPC_INGEST_CHUNKS=n (K3),
+ * NEO_MPC_DYNAMIC_LDS (kernel variant), NEO_MPC_LDS_PAD=bytes (fewer resident waves: occupancy study), NEO_MPC_NO_EARLY
+ * (Newton step tests off), NEO_MPC_INGEST_CHUNKS=n (K3),
  * NEO_MPC_NO_CHUNKS (large staged host batches in one piece), NEO_MPC_HOST_PATH=staged|zerocopy|zerocopy_out (what
  * NEO_MPC_HOST_PATH_AUTO means).  None changes a result beyond rounding. */
 neo_mpc_handle* neo_mpc_create(const neo_mpc_params* params, int device);
@@ -275,7 +276,9 @@ int neo_mpc_get_params(const neo_mpc_handle* handle, neo_mpc_params* params);
  * solve / postprocess / objective entry point makes its own stream wait for it; every solve records an event
  * on its stream and the next ingest waits for it before it rewrites the device map -- a solve never sees a
  * half-written map whatever streams the caller mixes.  (The caller's own buffers -- `d_cells`, `d_origins`,
- * the batch arrays -- stay the caller's to order.) */
+ * the batch arrays -- stay the caller's to order.)  The two small tables every wave reads as it starts -- the pool's origins
+ * (neo_mpc_set_costmap_pool) and the per-step costmap terms (neo_mpc_set_params) -- are rewritten only after every launch
+ * that may still read them has ended (a host-side wait): both calls are safe between neo_mpc_solve_batch_begin and _wait. */
 int neo_mpc_set_costmap(neo_mpc_handle* handle, const uint8_t* cells, uint32_t size_x,
                         uint32_t size_y, double resolution, double origin_x, double origin_y);
 /* Same, `d_cells` already in device memory; ingested on `stream` (hipStream_t, may be NULL). */

@@ -504,6 +504,8 @@ neo_mpc_handle* neo_mpc_create(const neo_mpc_params* params, int device) {
     h->tuning.dynamic_lds = getenv("NEO_MPC_DYNAMIC_LDS") != nullptr;
     e = getenv("NEO_MPC_INGEST_CHUNKS");
     h->tuning.ingest_chunks = e ? atoi(e) : 0;
+    e = getenv("NEO_MPC_LDS_PAD");
+    h->tuning.lds_pad = (e && atoi(e) > 0 && atoi(e) <= 65536) ? atoi(e) : 0;
     h->no_early = getenv("NEO_MPC_NO_EARLY") != nullptr;
     h->no_chunks = getenv("NEO_MPC_NO_CHUNKS") != nullptr;
     e = getenv("NEO_MPC_HOST_PATH");

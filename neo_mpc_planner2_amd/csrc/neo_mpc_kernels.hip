@@ -1371,8 +1371,8 @@ void launch_solve(const SolveArgs& a, const LaunchTuning& tuning, void* stream, 
   hipEvent_t e0 = (hipEvent_t)ev_start, e1 = (hipEvent_t)ev_stop;
 #define NEO_LAUNCH_LDS(bytes, ...)                                                                       \
   do {                                                                                                   \
-    if (e0 || e1) hipExtLaunchKernelGGL((k_solve<__VA_ARGS__>), grid, block, bytes, st, e0, e1, 0, a);   \
-    else hipLaunchKernelGGL((k_solve<__VA_ARGS__>), grid, block, bytes, st, a);                          \
+    if (e0 || e1) hipExtLaunchKernelGGL((k_solve<__VA_ARGS__>), grid, block, (bytes) + tuning.lds_pad, st, e0, e1, 0, a);   \
+    else hipLaunchKernelGGL((k_solve<__VA_ARGS__>), grid, block, (bytes) + tuning.lds_pad, st, a);                          \
   } while (0)
 #define NEO_LAUNCH(...) NEO_LAUNCH_LDS(lds, __VA_ARGS__)
 #define NEO_LAUNCH_W(w, ...)                                                                             \

@@ -674,6 +674,63 @@ def test_batches_in_flight_begin_and_wait(solver_mod):
                     lib.neo_mpc_unpin_host_memory(C.c_void_p(a.ctypes.data))
 
 
+def test_pool_and_parameters_replaced_behind_batches_in_flight(solver_mod):
+    """neo_mpc_set_costmap_pool and neo_mpc_set_params between `begin` and `wait`: the pool's origins and the per-step
+    costmap-term table are read by every K1 wave as it starts, and both are rewritten by blocking copies that do not order
+    against the streams batches are in flight on -- the library waits for every launch that may still read them first
+    (round-3 advisor, medium).  Two large page-locked batches in flight on a pool of four maps; pool (other cells, other
+    origins) and parameters (other costmap weight) are replaced before anything has been waited for: the batches come out
+    exactly as with the OLD pool and parameters, the next tick exactly as with the new ones."""
+    import ctypes as C
+    from neo_mpc_planner2_amd import _lib
+    lib = _lib.load()
+    params = util.orc.make_params()
+    params2 = dict(params, w_costmap=0.2)
+    maps = np.stack([synthetic.make_costmap(300, seed=60 + k)[0] for k in range(4)])
+    maps2 = np.stack([synthetic.make_costmap(300, seed=70 + k)[0] for k in range(4)])
+    origins = np.array([[-7.5, -7.5], [-7.0, -7.5], [-7.5, -7.0], [-8.0, -8.0]])
+    origins2 = origins + 0.35
+    fleets = []
+    for k in range(2):
+        probs = np.ascontiguousarray(synthetic.make_problems(60000, 300, seed=80 + k))
+        probs["map_index"] = np.arange(len(probs)) % 4
+        st, warm = synthetic.make_states(probs, 3)
+        fleets.append((probs, st, warm))
+    with solver_mod.BatchSolver(params) as s:
+        s.set_costmap_pool(maps, 0.05, origins)
+        ref_old = [s.solve(p, st.copy(), w.copy())[0].copy() for p, st, w in fleets]
+        s.set_costmap_pool(maps2, 0.05, origins2)
+        s.set_params(**params2)
+        ref_new = [s.solve(p, st.copy(), w.copy())[0].copy() for p, st, w in fleets]
+        assert ref_old[0].tobytes() != ref_new[0].tobytes()
+        s.set_params(**params)
+        s.set_costmap_pool(maps, 0.05, origins)
+        pinned = []
+        try:
+            for probs, st, warm in fleets:
+                arrays = [probs.copy(), st.copy(), warm.copy(), np.zeros(len(probs), dtype=abi.COMMAND_DTYPE), np.zeros((len(probs), 9))]
+                for a in arrays:
+                    assert lib.neo_mpc_pin_host_memory(C.c_void_p(a.ctypes.data), a.nbytes) == 0, lib.neo_mpc_last_error()
+                pinned.append(arrays)
+            tickets = [s.solve_begin(a[0], a[1], a[2], out=(a[3], a[4])) for a in pinned]
+            s.set_costmap_pool(maps2, 0.05, origins2)      # ... while 120 000 instances are in flight
+            s.set_params(**params2)
+            for t, r in zip(tickets, ref_old):
+                cmd, _ = s.solve_wait(t)
+                assert cmd.tobytes() == r.tobytes()
+            for a, (probs, st, warm) in zip(pinned, fleets):
+                a[1][...] = st
+                a[2][...] = warm
+            tickets = [s.solve_begin(a[0], a[1], a[2], out=(a[3], a[4])) for a in pinned]
+            for t, r in zip(tickets, ref_new):
+                cmd, _ = s.solve_wait(t)
+                assert cmd.tobytes() == r.tobytes()
+        finally:
+            for arrays in pinned:
+                for a in arrays:
+                    lib.neo_mpc_unpin_host_memory(C.c_void_p(a.ctypes.data))
+
+
 def test_errors_are_reported_not_thrown(solver_mod):
     from neo_mpc_planner2_amd import _lib
     s = solver_mod.BatchSolver(util.orc.make_params())
