@@ -96,18 +96,20 @@ __device__ __forceinline__ void sincos_fast(double x, double* sn, double* cs) {
 // never leaves that range when max|omega| * prediction_horizon <= 0.78 (DevParams.tame; 0.56 with
 // the README's parameters).
 __device__ __forceinline__ void sincos_small(double r, double* sn, double* cs) {
+  // (the two Horner chains step by step side by side: each step of one is independent of the other's, so a wave that is
+  // alone with its latency -- the tail of a one-round launch -- issues them back to back)
   const double z = r * r;
   double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-  ps = fma3(z, ps, 2.75573137070700676789e-06);
-  ps = fma3(z, ps, -1.98412698298579493134e-04);
-  ps = fma3(z, ps, 8.33333333332248946124e-03);
-  ps = fma3(z, ps, -1.66666666666666324348e-01);
-  *sn = fma(z * r, ps, r);
   double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  ps = fma3(z, ps, 2.75573137070700676789e-06);
   pc = fma3(z, pc, -2.75573143513906633035e-07);
+  ps = fma3(z, ps, -1.98412698298579493134e-04);
   pc = fma3(z, pc, 2.48015872894767294178e-05);
+  ps = fma3(z, ps, 8.33333333332248946124e-03);
   pc = fma3(z, pc, -1.38888888888741095749e-03);
+  ps = fma3(z, ps, -1.66666666666666324348e-01);
   pc = fma3(z, pc, 4.16666666666666019037e-02);
+  *sn = fma(z * r, ps, r);
   *cs = fma(z * z, pc, fma(z, -0.5, 1.0));
 }
 template <bool kTame>
