@@ -9,6 +9,7 @@
 #include "wave_ops.h"
 #include "solver_context.h"
 #include "fast_math.h"
+#include "solver_rules.h"
 
 namespace neo_mpc {
 namespace {
@@ -70,7 +71,7 @@ __device__ __forceinline__ double step_term(const SolveArgs& a, const Ctx& c, co
 // candidate lethal; the stage's path along a straight wall is curved in the controls: a stand-off of 2 % of a cell lets
 // a slide advance a centimetre per iteration, 10 % five times that).
 // Returns the raw cost of the stage's own cell.
-constexpr double kSticky = 100.0, kWall = 1e4, kStickyDist = 0.02, kWallDist = 0.1;
+constexpr double kSticky = NEO_RULE_STICKY, kWall = NEO_RULE_WALL, kStickyDist = NEO_RULE_STICKY_DIST, kWallDist = NEO_RULE_WALL_DIST;
 // Hop candidates.  The costmap term is piecewise constant: a stage within `hop_range` cells of a cell edge behind which
 // the term is LOWER (by more than hop_min_drop) can gain that step for a displacement of millimetres, but no descent
 // direction says so -- the term has no gradient -- and at a heavy costmap weight one such step is worth more than the
@@ -78,7 +79,7 @@ constexpr double kSticky = 100.0, kWall = 1e4, kStickyDist = 0.02, kWallDist = 0
 // across such edges by chance).  hop_x / hop_y: the change of THIS stage's block (vx, vy) that puts the stage
 // kHopMargin cells inside the cheaper neighbour (every later stage shifts with it); lanes 1-4 of the search try the
 // current point with one such block changed (feasible_set.h).
-constexpr double kHopMargin = 0.01;   // (well inside kStickyDist: a stage that has just hopped must not sit ON the edge of the sticky zone; deeper costs objective)
+constexpr double kHopMargin = NEO_RULE_HOP_MARGIN;   // (well inside kStickyDist: a stage that has just hopped must not sit ON the edge of the sticky zone; deeper costs objective)
 __device__ __forceinline__ int edge_stickiness(const SolveArgs& a, const Ctx& c, const double* L, double x, double y,
                                                double cs, double sn, double& wxx, double& wxy, double& wyy, double& lx,
                                                double& ly, bool& hop, float& hop_x, float& hop_y) {

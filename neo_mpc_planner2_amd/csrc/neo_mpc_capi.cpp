@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "neo_mpc_device.h"
+#include "solver_rules.h"
 
 using namespace neo_mpc;
 
@@ -180,13 +181,17 @@ void derive(neo_mpc_handle* h) {
   d.r = p.max_vel_trans;
   d.acc[0] = p.acc_x_limit; d.acc[1] = p.acc_y_limit; d.acc[2] = p.acc_theta_limit;
   d.low_pass_gain = p.low_pass_gain;
-  d.xtol = p.step_tolerance > 0.0 ? p.step_tolerance : 1e-3 * p.opt_tolerance;
-  // (set below, once the search direction is known)
-  d.stall_step = p.stall_step > 0.0 ? p.stall_step : 0.3 * p.opt_tolerance;
-  d.hop_min_drop = 0.1 * p.opt_tolerance;
-  d.hop_range = h->has_map ? fmin(0.25, 0.05 * d.dt / h->map.resolution) : 0.25;
-  d.max_it = p.max_iterations > 0 ? p.max_iterations : 100;
-  d.mem = p.lbfgs_memory > 0 ? p.lbfgs_memory : 4;
+  // every tolerance of the search comes out of solver_rules.h -- the one rule book the device code and the CPU mirror
+  // (test infrastructure) share; all of them derive from opt_tolerance
+  neo_rules r;
+  neo_rules_derive(&p, &r);
+  d.xtol = r.xtol;
+  d.kink_radius = r.kink_radius;
+  d.stall_step = r.stall_step;
+  d.hop_min_drop = r.hop_min_drop;
+  d.hop_range = h->has_map ? neo_rules_hop_range(d.dt, h->map.resolution) : NEO_RULE_HOP_DIST;
+  d.max_it = r.max_iterations;
+  d.mem = r.lbfgs_memory;
   d.compat = (p.compat_flags & NEO_MPC_COMPAT_ODOM_YAW_GOAL_W) |
              ((p.compat_flags & NEO_MPC_COMPAT_REFERENCE_START) ? kCompatNoUnshift : 0);
   d.disc_in_box = (p.min_vel_x <= -p.max_vel_trans && p.max_vel_x >= p.max_vel_trans &&
@@ -198,39 +203,14 @@ void derive(neo_mpc_handle* h) {
   // walls the search has to slide along, and the wall model lives in the stage-wise direction (costmap.h).  Against
   // the reference's SLSQP solves at w_costmap = 0.3 (G8 "turn") the dense direction ends 3e-3 and 9e-3 above
   // SLSQP's value in 2 of 24 cases, the stage-wise one in none.
-  const bool heavy_costmap = p.w_costmap > 0.25 * p.w_trans;
-  d.newton = p.method == NEO_MPC_METHOD_LBFGS ? 0
-             : p.method == NEO_MPC_METHOD_NEWTON ? 1
-             : p.method == NEO_MPC_METHOD_RICCATI ? 2
-             : (n == 3 && !heavy_costmap ? 1 : 2);
-  // blocks closer to the control norm's kink than this are left to the proximal step alone.  The stage-wise direction
-  // predicts landings on the kink inside its sweep (riccati.h), so its zone is small; the dense and the L-BFGS
-  // direction have no such prediction and keep round 1's radius (warm-started ticks against the converged reference, G11:
-  // control_steps 8 at 3e-3: 2 of 407 commands more than 1e-3 away, at 1e-4 none)
-  d.kink_radius = p.kink_radius > 0.0 ? p.kink_radius : d.newton == 2 ? 1e-4 : 3e-3;
-  d.early_tol = h->no_early ? 0.0 : d.xtol;
-  d.final_tol = h->no_early ? 0.0 : (p.step_tolerance > 0.0 ? p.step_tolerance : p.opt_tolerance);
-  // Beyond 3 control steps the objective is flatter per block (the weights are divided by N, and two neighbouring
-  // blocks of a long horizon can trade displacement at almost no cost): the gain thresholds of the Newton
-  // directions shrink with (3/N)^2 (the three-iteration window with (3/N)^3) -- measured on 1024 zero-costmap problems against solves run to the end
-  // (tools/parity_report.py): with the control_steps-3 thresholds 59 first controls at N = 32 (7 at 16, 2 at 8) end
-  // more than 1e-3 away (max 0.09, objective within 1e-4), with the scaled ones none, for 8 % more iterations at 32.
-  const double flat = (d.newton && n > 3) ? (3.0 / n) * (3.0 / n) : 1.0;
-  d.ftol = p.cost_tolerance > 0.0 ? p.cost_tolerance : (d.newton ? 3e-4 * flat : 3e-6) * p.opt_tolerance;
-  d.wtol = p.window_tolerance > 0.0 ? p.window_tolerance
-           : (p.window_tolerance == 0.0 && d.newton) ? 3e-3 * p.opt_tolerance * flat * fmin(1.0, 3.0 / n) : 0.0;
-  // (a long-horizon search that has run twice its usual length is creeping, gaining 1e-8 of f per iteration up to the
-  // iteration cap -- a handful per 65 536 solves, but a launch lasts as long as its slowest wave: from iteration
-  // kLateIteration on the window is the control_steps-3 one again)
-  d.wtol_late = p.window_tolerance > 0.0 ? p.window_tolerance
-                : (p.window_tolerance == 0.0 && d.newton) ? 3e-3 * p.opt_tolerance : 0.0;
-
-  // Blocked-run stop rule of the dense Newton direction (neo_mpc_kernels.hip kBlockedRun): three iterations in a row not
-  // won by a decent Newton step that together gain less than 0.1 x opt_tolerance -- 0.03 x when no stage of the rollout
-  // has a costmap term under it -- end the search.  Absolute (a search on its way out of a lethal cell has a huge f);
-  // scaled with the horizon like the stall threshold; part of the window rule (off with it).
-  d.btol_map = (d.newton == 1 && d.wtol > 0.0) ? 0.1 * flat * p.opt_tolerance : 0.0;
-  d.btol_free = (d.newton == 1 && d.wtol > 0.0) ? 0.03 * flat * p.opt_tolerance : 0.0;
+  d.newton = r.direction;
+  d.early_tol = h->no_early ? 0.0 : r.xtol;
+  d.final_tol = h->no_early ? 0.0 : r.final_tol;
+  d.ftol = r.ftol;
+  d.wtol = r.wtol;
+  d.wtol_late = r.wtol_late;
+  d.btol_map = r.btol_map;
+  d.btol_free = r.btol_free;
 
   // LDS carve-up (shared with the kernel specialisations) + reach tile geometry
   LdsLayout& l = h->lds;

@@ -41,6 +41,7 @@
 #include "wave_ops.h"
 #include "fast_math.h"
 #include "solver_context.h"
+#include "solver_rules.h"
 #include "costmap.h"
 #include "feasible_set.h"
 #include "rollout.h"
@@ -49,13 +50,13 @@
 namespace neo_mpc {
 namespace {
 
-// consecutive iterations gaining less than ftol*max(1,|f|) or moving less than stall_step that end
-// the search (creeping along a costmap cell edge gains ~1e-9 per iteration for ever)
-constexpr int kStallIterations = 5;
-constexpr int kBlockedRun = 3;       // dense Newton: this many iterations in a row not won by a decent Newton step ...
-constexpr double kBlockedStep = 0.25;  // ... (a proximal lane, or a Newton step cut below this) arm the blocked-run stop rule
-constexpr double kFinalFracGaussNewton = 0.3;   // stage-wise direction without the second-order terms: a full step has to be this much shorter than opt_tolerance to be the last
-constexpr int kLateIteration = 20;   // from here on the three-iteration window is the control_steps-3 one (neo_mpc_capi.cpp)
+// the stop-rule constants: solver_rules.h (shared with the host side and with the CPU mirror)
+constexpr int kStallIterations = NEO_RULE_STALL_ITERATIONS;
+constexpr int kBlockedRun = NEO_RULE_BLOCKED_RUN;
+constexpr double kBlockedStep = NEO_RULE_BLOCKED_STEP;
+constexpr double kFinalFracGaussNewton = NEO_RULE_FINAL_FRAC_GN;
+constexpr double kWindowStep = NEO_RULE_WINDOW_STEP;
+constexpr int kLateIteration = NEO_RULE_LATE_ITERATION;
 
 // Study build (make timing -> libneo_mpc_timing.so): shader-clock stamps at the phase boundaries of
 // solver iteration 2 in entries 0-5 of `solution` (tools/phase_timing.py); wall-clock start and end of
@@ -848,7 +849,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     // starts, CPU mirror): 71 % of such trials succeed, 3.9 searches saved per solve for 0.3 iterations more;
     // the results are the same.  (With a costmap term under the rollout the search's spread of candidates is
     // what steps over cost edges and out of lethal cells.)
-    constexpr double kTrialRatio = 0.75;
+    constexpr double kTrialRatio = NEO_RULE_TRIAL_RATIO;
     bool took_trial = false;
     double fb = INFINITY, cterm = 0.0;   // (cterm, dense Newton: the costmap terms of this lane's candidate alone)
     int best = 32;
@@ -965,7 +966,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     // stage-wise direction: the window and closing-in rules only judge runs of BLOCKED iterations (none of the three won
     // by a Newton step of at least half its length); iterations won by the Newton step end through the step test
     const bool hop_won = kRiccati && best >= 1 && best <= nhops;
-    nblocked = (best < 32 || lane_value(step, best) < 0.5 || hop_won) ? nblocked + 1 : 0;
+    nblocked = (best < 32 || lane_value(step, best) < kWindowStep || hop_won) ? nblocked + 1 : 0;
     const bool window_on = !kRiccati || nblocked >= 3;
     // three iterations that together gained less than wtol: creeping along a costmap cell edge
     const double wtol0 = TOL[T_WTOL];   // (the closing-in rule below is on whenever the window rule is)

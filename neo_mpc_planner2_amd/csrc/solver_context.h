@@ -27,7 +27,7 @@ enum : int {
 // (dvx, dvy) pairs as float32.
 enum : int { T_XTOL, T_EARLY, T_FINAL, T_FTOL, T_STALL, T_WTOL, T_KINK, T_KONST, T_TRUE_YAW, T_MU, T_WTOL_LATE,
              T_HOP_DROP, T_HOP_RANGE, T_HOP_STAGE = 13 /* int32[6]: stage[4], count, - */, T_HOP_VEC = 16 /* float[8] */,
-             T_BTOL_MAP = 20, T_BTOL_FREE = 21, kHopLanes = 4 };
+             T_BTOL_MAP = 20, T_BTOL_FREE = 21, kHopLanes = 4 /* = NEO_RULE_HOP_LANES (solver_rules.h) */ };
 
 constexpr int kTileFree = 0x80;   // Ctx::tile_geom: every cell of the reach tile is free (raw cost 0)
 

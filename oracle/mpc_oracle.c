@@ -27,9 +27,12 @@
 #include <string.h>
 
 #include "../include/neo_mpc.h"
+/* the rule book of the build's search (constants + derived tolerances): shared with the product so that the mirror
+ * (part 2) cannot drift from the device code; parts 1 and 3 (the restatement of the REFERENCE) use nothing of it */
+#include "../neo_mpc_planner2_amd/csrc/solver_rules.h"
 
 #define ORC_LANES 64
-#define ORC_STALL_ITERATIONS 5 /* consecutive iterations below cost_tolerance that end the search */
+#define ORC_STALL_ITERATIONS NEO_RULE_STALL_ITERATIONS
 #define ORC_MAXN NEO_MPC_MAX_CONTROL_STEPS
 #define ORC_MAXV (3 * ORC_MAXN)
 
@@ -225,8 +228,6 @@ typedef struct orc_ctx {
   const orc_map* map;
 } orc_ctx;
 
-static double orc_kink_radius_stagewise = 1e-4;
-void orc_set_kink_radius_stagewise(double r) { orc_kink_radius_stagewise = r; }
 static void orc_ctx_init(orc_ctx* c, const neo_mpc_params* p, const orc_map* m,
                          const neo_mpc_problem* q, double footprint_cost) {
   const int n = p->control_steps;
@@ -258,12 +259,10 @@ static void orc_ctx_init(orc_ctx* c, const neo_mpc_params* p, const orc_map* m,
   c->lo[2] = p->min_vel_theta; c->hi[2] = p->max_vel_theta;
   c->r = p->max_vel_trans;
   {
-    /* (round 4) the stage-wise direction predicts landings on the kink inside its sweep (orc_riccati_direction_disp_tau:
-     * tokink), so the zone in which a block is left to the proximal step alone is small; the dense direction has no such
-     * prediction and keeps round 1's radius */
-    const int stagewise = p->method == NEO_MPC_METHOD_RICCATI ||
-                          (p->method == NEO_MPC_METHOD_AUTO && (p->control_steps != 3 || p->w_costmap > 0.25 * p->w_trans));
-    c->kink_radius = p->kink_radius > 0.0 ? p->kink_radius : stagewise ? orc_kink_radius_stagewise : 3e-3;
+    /* (the stage-wise direction predicts landings on the kink inside its sweep: its prox-only zone is small) */
+    neo_rules r;
+    neo_rules_derive(p, &r);
+    c->kink_radius = r.kink_radius;
   }
   c->map = m;
 }
@@ -637,8 +636,8 @@ static void orc_sym3_solve(double L[3][3], const double* b, double* x) {
   }
 }
 
-#define ORC_STICKY 100.0     /* penalty on motion across a rising cost step, in units of the tracking curvature */
-#define ORC_STICKY_DIST 0.02 /* ... for stage positions closer than this to the cell edge (fraction of a cell) */
+#define ORC_STICKY NEO_RULE_STICKY
+#define ORC_STICKY_DIST NEO_RULE_STICKY_DIST
 static double orc_term_at(const orc_ctx* c, int64_t mx, int64_t my) {
   int raw = 254;
   if (mx >= 0 && my >= 0 && mx < c->map->size_x && my < c->map->size_y)
@@ -658,8 +657,8 @@ static double orc_term_at(const orc_ctx* c, int64_t mx, int64_t my) {
  * alone a search blocked by a lethal cell crept up to the wall -- 1e-6 cells -- and ended there with every candidate
  * lethal: 0.79 above the reference's SLSQP value in one case of the G8 fixtures; with the wall model it ends ON the
  * reference's optimum.) */
-#define ORC_WALL 1e4
-#define ORC_WALL_DIST 0.1   /* wall zone and stand-off, cells */
+#define ORC_WALL NEO_RULE_WALL
+#define ORC_WALL_DIST NEO_RULE_WALL_DIST
 static void orc_wall_model(const orc_ctx* c, double x, double y, double* W, double* l) {
   const double X = c->X0 + (c->c0 * x - c->s0 * y), Y = c->Y0 + (c->s0 * x + c->c0 * y);
   const orc_map* m = c->map;
@@ -1109,10 +1108,10 @@ static void orc_candidate(const orc_ctx* c, const orc_active* act, int lane, dou
  * edges by chance).  Lanes 1..ORC_HOP_LANES of the search therefore try: the current point with ONE block changed so
  * that its stage lands ORC_HOP_MARGIN cells inside the cheaper neighbour cell (all later stages shift with it).
  * hop[i] = the change of block i's (vx, vy), has[i] = stage i has a cheaper neighbour in range. */
-#define ORC_HOP_DIST 0.25
-#define ORC_HOP_MARGIN 0.01   /* (well inside ORC_STICKY_DIST: a stage that has just hopped must not sit ON the edge of the wall model's sticky zone; deeper costs objective -- the control norm charges every mm/s) */
-#define ORC_HOP_MAX_DV 0.05   /* a hop never changes a velocity by more than this (m/s): hop range <= 0.05 dt */
-#define ORC_HOP_LANES 4
+#define ORC_HOP_DIST NEO_RULE_HOP_DIST
+#define ORC_HOP_MARGIN NEO_RULE_HOP_MARGIN
+#define ORC_HOP_MAX_DV NEO_RULE_HOP_MAX_DV
+#define ORC_HOP_LANES NEO_RULE_HOP_LANES
 static int orc_hops_on = 1;
 void orc_set_hops(int on) { orc_hops_on = on; }
 static int orc_hops(const orc_ctx* c, const double* u, double min_drop, double hop[][2], uint8_t* has) {
@@ -1153,9 +1152,9 @@ static int orc_hops(const orc_ctx* c, const double* u, double min_drop, double h
 static int orc_capture_it = -1;
 static double* orc_capture_d = NULL;
 void orc_capture_direction(int it, double* d_out) { orc_capture_it = it; orc_capture_d = d_out; }
-#define ORC_TRIAL_RATIO 0.75
-#define ORC_BLOCKED_STEP 0.25
-#define ORC_LATE_ITERATION 20
+#define ORC_TRIAL_RATIO NEO_RULE_TRIAL_RATIO
+#define ORC_BLOCKED_STEP NEO_RULE_BLOCKED_STEP
+#define ORC_LATE_ITERATION NEO_RULE_LATE_ITERATION
 static int orc_trial = 1;
 void orc_set_trial(int on) { orc_trial = on; }
 static int orc_unshift = 1;
@@ -1189,9 +1188,7 @@ void orc_set_trace(int on) { orc_trace = on; }
  * 5.8e-4).  Part of the window rule: off with it.  The stage-wise direction does not take it (its wall model and hop
  * candidates deal with cell edges, and its long shots need their blocked iterations to get out of lethal cells).
  * Beyond 3 control steps (run-time-sized dense kernel) the thresholds shrink with (3/N)^2 like the stall threshold. */
-#define ORC_BLOCKED_RUN 3
-#define ORC_BLOCKED_TOL_MAP 0.1
-#define ORC_BLOCKED_TOL_FREE 0.03
+#define ORC_BLOCKED_RUN NEO_RULE_BLOCKED_RUN
 static int orc_blocked_rule = 1;
 void orc_set_blocked_rule(int on) { orc_blocked_rule = on; }
 
@@ -1203,7 +1200,7 @@ void orc_set_blocked_rule(int on) { orc_blocked_rule = on; }
  * of the objective that depends on u (the constant terminal distance term, py:266, can be 20x that), and with the
  * stage-wise direction the three-iteration window and the closing-in rule only judge runs of BLOCKED iterations
  * (iterations won by a decent Newton step end through the Newton step test); 0: rounds 2-3. */
-static double orc_final_frac = 0.3;   /* a Gauss-Newton (not exact) full step has to be this much shorter than opt_tolerance to be the last */
+static double orc_final_frac = NEO_RULE_FINAL_FRAC_GN;
 void orc_set_final_frac(double f) { orc_final_frac = f; }
 static int orc_tau_mode = 1, orc_rule_mode = 1;
 void orc_set_tau_mode(int m) { orc_tau_mode = m; }
@@ -1214,26 +1211,18 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
   orc_ctx c;
   orc_ctx_init(&c, p, m, q, footprint_cost);
   const int n = c.n, nv = 3 * n;
-  const int max_it = p->max_iterations > 0 ? p->max_iterations : 100;
-  int mem = p->lbfgs_memory > 0 ? p->lbfgs_memory : 4;
+  /* every tolerance and the choice of the search direction: solver_rules.h, the rule book shared with the device code
+   * (neo_mpc_capi.cpp derive()) */
+  neo_rules rules;
+  neo_rules_derive(p, &rules);
+  const int max_it = rules.max_iterations;
+  int mem = rules.lbfgs_memory;
   if (mem > NEO_MPC_MAX_LBFGS_MEMORY) mem = NEO_MPC_MAX_LBFGS_MEMORY;
-  const double xtol = p->step_tolerance > 0.0 ? p->step_tolerance : 1e-3 * p->opt_tolerance;
-  const double stall_step = p->stall_step > 0.0 ? p->stall_step : 0.3 * p->opt_tolerance;
+  const double xtol = rules.xtol, stall_step = rules.stall_step;
   /* search direction of lanes 32-63: stage-wise (Riccati) Newton, dense Newton (control_steps <= 8) or L-BFGS */
-  /* (AUTO: dense at control_steps 3 unless the costmap weight is heavy -- the wall model lives in the stage-wise
-   * direction, neo_mpc_capi.cpp) */
-  const int riccati = p->method == NEO_MPC_METHOD_RICCATI ||
-                      (p->method == NEO_MPC_METHOD_AUTO && (p->control_steps != 3 || p->w_costmap > 0.25 * p->w_trans));
-  const int newton = riccati || (p->method != NEO_MPC_METHOD_LBFGS && 3 * p->control_steps <= ORC_NEWTON_MAXV);
-  /* Newton converges quadratically, so a run of tiny gains means creeping along a costmap cell
-   * edge much earlier than with L-BFGS: looser default */
-  /* Beyond 3 control steps the objective is flatter per block (the weights are divided by N, and two
-   * neighbouring blocks of a long horizon can trade displacement at almost no cost): the gain thresholds of the
-   * Newton directions shrink with (3/N)^2 (the three-iteration window with (3/N)^3) -- measured on 1024 zero-costmap problems against solves run to the end:
-   * with the control_steps-3 thresholds 59 first controls at N = 32 (7 at 16, 2 at 8) end more than 1e-3 away
-   * (max 0.09, objective within 1e-4), with the scaled ones none (max 4e-4), for 8 % more iterations at 32. */
-  const double flat = (newton && p->control_steps > 3) ? (3.0 / p->control_steps) * (3.0 / p->control_steps) : 1.0;
-  const double ftol = p->cost_tolerance > 0.0 ? p->cost_tolerance : (newton ? 3e-4 * flat : 3e-6) * p->opt_tolerance;
+  const int riccati = rules.direction == NEO_DIRECTION_STAGEWISE;
+  const int newton = riccati || (rules.direction == NEO_DIRECTION_DENSE && 3 * p->control_steps <= ORC_NEWTON_MAXV);
+  const double ftol = rules.ftol;
 
   double u[ORC_MAXV], gs[ORC_MAXV], gt[ORC_MAXV], gr[ORC_MAXV], d[ORC_MAXV];
   double u_prev[ORC_MAXV], gt_prev[ORC_MAXV], cand[ORC_MAXV], best_c[ORC_MAXV];
@@ -1285,12 +1274,9 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
   double mu = mu0;
   int nfev = 1, it = 0, status = NEO_MPC_STATUS_MAX_ITER, stall = 0;
   /* three iterations in a row that together gain less than wtol end the search (Newton only by default) */
-  const double wtol = p->window_tolerance > 0.0 ? p->window_tolerance
-                      : (p->window_tolerance == 0.0 && newton) ? 3e-3 * p->opt_tolerance * flat * fmin(1.0, 3.0 / p->control_steps) : 0.0;
-  const double wtol_late = p->window_tolerance > 0.0 ? p->window_tolerance
-                           : (p->window_tolerance == 0.0 && newton) ? 3e-3 * p->opt_tolerance : 0.0;
+  const double wtol = rules.wtol, wtol_late = rules.wtol_late;
   double gain1 = INFINITY, gain2 = INFINITY;
-  const double final_tol = p->step_tolerance > 0.0 ? p->step_tolerance : p->opt_tolerance;
+  const double final_tol = rules.final_tol;
   int final = 0;
   int blocked_run = 0;   /* consecutive iterations not won by a decent Newton step */
   int exact_step = 0;    /* this iteration's stage-wise direction carries the second-order terms */
@@ -1301,7 +1287,7 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
     double hop[ORC_MAXN][2];
     uint8_t has_hop[ORC_MAXN];
     int hop_stage[ORC_HOP_LANES], nhops = 0;
-    if (riccati && orc_hops_on && orc_hops(&c, u, 0.1 * p->opt_tolerance, hop, has_hop))
+    if (riccati && orc_hops_on && orc_hops(&c, u, rules.hop_min_drop, hop, has_hop))
       for (int i = 0; i < n && nhops < ORC_HOP_LANES; ++i) if (has_hop[i]) hop_stage[nhops++] = i;
     if (newton) {
       /* a cold start (x0 = 0, the reference's reset state py:359) is far from the minimiser and the
@@ -1467,7 +1453,7 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
     const double wnow = it >= ORC_LATE_ITERATION ? wtol_late : wtol;
     /* stage-wise direction: the window and closing-in rules only judge runs of BLOCKED iterations (none of the three won
      * by a Newton step of at least half its length); iterations won by the Newton step end through the step test */
-    nblocked = (best < 32 || orc_lane_scale(best, act.longshots) < 0.5 || hop_won) ? nblocked + 1 : 0;
+    nblocked = (best < 32 || orc_lane_scale(best, act.longshots) < NEO_RULE_WINDOW_STEP || hop_won) ? nblocked + 1 : 0;
     const int creeping = wnow > 0.0 && decrease + gain1 + gain2 <= wnow * fsc && (orc_rule_mode < 1 || !riccati || nblocked >= 3);
     /* ... and so does a step below stall_step whose gain halved twice in a row: the search is closing in on a
      * costmap cell edge (or the kink) geometrically, what is left to gain is less than the last gain (part of the
@@ -1475,7 +1461,7 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
     const int closing_in = wtol > 0.0 && step <= stall_step && decrease <= 0.5 * gain1 && gain1 <= 0.5 * gain2 && (orc_rule_mode < 1 || !riccati || nblocked >= 3);
     int blocked_stop = 0;
     if (newton && !riccati && orc_blocked_rule && wtol > 0.0 && blocked_run >= ORC_BLOCKED_RUN)
-      blocked_stop = decrease + gain1 + gain2 <= (orc_term_sum(&c, u) == 0.0 ? ORC_BLOCKED_TOL_FREE : ORC_BLOCKED_TOL_MAP) * flat * p->opt_tolerance;
+      blocked_stop = decrease + gain1 + gain2 <= (orc_term_sum(&c, u) == 0.0 ? rules.btol_free : rules.btol_map);
     gain2 = gain1; gain1 = decrease;
     if (step < xtol || stall >= ORC_STALL_ITERATIONS || creeping || closing_in || final || blocked_stop) { status = NEO_MPC_STATUS_CONVERGED; ++it; goto exit_check; }
     continue;
@@ -1491,7 +1477,7 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
   if (newton && !riccati && orc_hops_on && orc_exit_hops && status == NEO_MPC_STATUS_CONVERGED && orc_term_sum(&c, u) != 0.0) {
     double hop2[ORC_MAXN][2];
     uint8_t has2[ORC_MAXN];
-    if (orc_hops(&c, u, 0.1 * p->opt_tolerance, hop2, has2)) {
+    if (orc_hops(&c, u, rules.hop_min_drop, hop2, has2)) {
       double fbest = f;
       int ibest = -1;
       double bb[3] = {0, 0, 0};
