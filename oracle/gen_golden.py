@@ -369,6 +369,55 @@ def gen_g10(mod):
     print("G10: %d groups x %d cold solves in %.0fs" % (len(jobs), G10_COUNT, time.time() - t0), flush=True)
 
 
+#: G12 "after the tuning stopped": parameter sets, control_steps and map seeds drawn AFTER the last change of round 4 to a
+#: threshold or to the search -- the check that G10 (which the search was hardened on) did not become a training set
+G12_SETS = {
+    "d": dict(w_trans=0.6, w_orient=0.35, w_control=0.12, w_terminal=0.1, w_costmap=0.09, max_vel_x=0.8, min_vel_x=-0.8,
+              max_vel_y=0.8, min_vel_y=-0.8, max_vel_trans=0.8, max_vel_theta=1.0, min_vel_theta=-1.0,
+              prediction_horizon=1.2),
+    "e": dict(w_trans=2.0, w_orient=1.0, w_control=0.02, w_terminal=0.02, w_costmap=0.3, max_vel_x=0.5, min_vel_x=-0.5,
+              max_vel_y=0.2, min_vel_y=-0.2, max_vel_trans=0.5, max_vel_theta=0.6, min_vel_theta=-0.6,
+              prediction_horizon=0.5),
+    "f": dict(w_trans=0.4, w_orient=0.4, w_control=0.6, w_terminal=0.4, w_costmap=0.08, max_vel_x=0.6, min_vel_x=-0.6,
+              max_vel_y=0.6, min_vel_y=-0.6, max_vel_trans=0.6, max_vel_theta=0.6, min_vel_theta=-0.6,
+              prediction_horizon=0.9, opt_tolerance=1e-4),
+}
+G12_STEPS = (3, 4, 6, 10)
+
+
+def _g12_group(args):
+    si, name, n_steps = args
+    mod = ros_stubs.load_reference()
+    with contextlib.redirect_stdout(io.StringIO()):
+        grp = _g3_group(mod, n_steps, G10_COUNT, 12000 + 100 * si + n_steps, G12_SETS[name], map_size=300, map_seed=171 + si)
+    return name, n_steps, grp
+
+
+def gen_g12(mod):
+    """G12: G10's protocol (cold solves as shipped and run to the end, every other case on an all-free map) at three MORE
+    parameter sets, control_steps 3, 4, 6, 10, drawn after the search and its thresholds were frozen."""
+    import multiprocessing as mp
+    t0 = time.time()
+    jobs = [(si, name, n) for si, name in enumerate(sorted(G12_SETS)) for n in G12_STEPS]
+    out = dict(versions=np.array(repr(versions())), param_keys=np.array(PARAM_KEYS), sets=np.array(sorted(G12_SETS)),
+               steps=np.array(G12_STEPS))
+    with mp.Pool(max(1, min(len(jobs), (os.cpu_count() or 2) - 1))) as pool:
+        for name, n_steps, grp in sorted(pool.imap_unordered(_g12_group, jobs), key=lambda r: (r[0], r[1])):
+            out.update({"%s_n%d_%s" % (name, n_steps, k): v for k, v in grp.items()})
+    np.savez_compressed(os.path.join(OUT, "g12_after_tuning.npz"), **out)
+    print("G12: %d groups x %d cold solves in %.0fs" % (len(jobs), G10_COUNT, time.time() - t0), flush=True)
+
+
+def gen_g13(mod):
+    """G13: G11's protocol (episodes of the reference run to convergence on an all-free map) at G10's set "a" weights and
+    limits -- heavy control weight, box cutting the disc -- at control_steps 3 and 5, drawn after the tuning stopped."""
+    over = dict(G10_SETS["a"], opt_tolerance=1e-12)
+    gen_g4(mod, n_steps=3, n_ep=16, n_calls=40, fname="g13_warm_converged_set_a.npz", overrides=over, free_map=True, maxiter=500,
+           seed_base=13440)
+    gen_g4(mod, n_steps=5, n_ep=10, n_calls=30, fname="g13_warm_converged_set_a_n5.npz", overrides=over, free_map=True, maxiter=500,
+           seed_base=13540)
+
+
 def gen_g11(mod):
     """G11: optimizer() episodes of the reference RUN TO CONVERGENCE -- `opt_tolerance` 1e-12 (py:72, 364) and SLSQP's
     iteration cap raised to 500 inside the call of py:363-364 -- on an all-free map (unique minimisers): the converged
@@ -623,6 +672,8 @@ def main():
     gen_g3n32(mod)
     gen_g10(mod)
     gen_g11(mod)
+    gen_g12(mod)
+    gen_g13(mod)
 
 
 if __name__ == "__main__":

@@ -453,6 +453,33 @@ def test_g11_warm_commands_against_the_converged_reference(fixture):
     assert dv.max() <= 3e-3
 
 
+@pytest.mark.parametrize("name,n_steps", util.G12_GROUPS)
+def test_g12_parameter_sets_drawn_after_the_tuning_stopped(name, n_steps):
+    """G12: G10's protocol at three more parameter sets and control_steps 3 / 4 / 6 / 10, generated AFTER the last change
+    of round 4 to the search or to a threshold (nothing was adjusted on it): P3 on every case, P2 <= 3e-4 where the
+    reference reached the minimiser, <= 1e-3 where SLSQP at ftol 1e-12 stalled above the build's objective."""
+    m = util.check_held_out_group(_cold_solve, name, n_steps, fixture="g12_after_tuning.npz", min_ok=16)
+    print("G12 %s N=%d (mirror): P2 %.2e (%d cases with the reference above the build), P3 margin free %.2e map %.2e, iterations %.1f / %.1f"
+          % (name, n_steps, m["p2"], m["ref_short"], m["p3_free"], m["p3_map"], m["it_free"], m["it_map"]))
+
+
+@pytest.mark.parametrize("fixture", util.G13_FIXTURES)
+def test_g13_warm_gate_at_another_parameter_set(fixture):
+    """G13: G11's protocol at G10's set "a" (heavy control weight, box cutting the disc), control_steps 3 and 5, generated
+    after the tuning stopped."""
+    def solve(params, cmap, rows, st, wm):
+        cm, x, _ = c_oracle.solve_batch(params, cmap, rows, st, wm)
+        return cm, x
+
+    def post(params, cmap, rows, st, wm, x, success):
+        c_oracle.postprocess_batch(params, cmap, rows, st, wm, x, success)
+    dv, du, its = util.warm_gate(solve, post, fixture)
+    above, above_at_min, short = util.assert_warm_gate(dv, fixture)
+    print("G13 %s (mirror): %d ticks, |command diff| p99 %.2e max %.2e, above 1e-3: %d (%d where the reference is at the minimiser; "
+          "it stalled above the build's objective on %d ticks); iterations %.2f"
+          % (fixture, dv.size, np.percentile(dv, 99), dv.max(), above, above_at_min, short, its.mean()))
+
+
 @pytest.mark.parametrize("fixture", util.EPISODE_FIXTURES)
 def test_p3_on_the_reference_warm_starts_mirror(fixture):
     """P3w on the CPU mirror (the GPU test of the same name runs K1): every call of the recorded episodes solved from the

@@ -1054,3 +1054,42 @@ def test_fleet_allgather_example_through_the_c_abi(tmp_path):
     rec = json.loads(out.stdout.strip().splitlines()[-1])
     assert rec["gathered_equals_local"] is True and rec["n_gpus"] >= 1 and rec["max_speed"] <= 0.7 + 1e-9
     print(rec)
+
+
+@pytest.mark.parametrize("name,n_steps", util.G12_GROUPS)
+def test_g12_parameter_sets_drawn_after_the_tuning_stopped(solver_mod, name, n_steps):
+    """G12 through the C-ABI on the GPU: three parameter sets and control_steps 3 / 4 / 6 / 10 generated after the last
+    change of round 4 to the search or a threshold (see the mirror's test of the same name)."""
+    def solve(params, cmap, pr):
+        st, warm = synthetic.make_states(pr, params["control_steps"])
+        with _solver(solver_mod, params, cmap) as s:
+            return s.solve(pr, st, warm)
+    m = util.check_held_out_group(solve, name, n_steps, fixture="g12_after_tuning.npz", min_ok=16)
+    print("G12 %s N=%d: P2 %.2e (%d cases with the reference above the build), P3 margin free %.2e map %.2e, iterations %.1f / %.1f"
+          % (name, n_steps, m["p2"], m["ref_short"], m["p3_free"], m["p3_map"], m["it_free"], m["it_map"]))
+
+
+@pytest.mark.parametrize("fixture", util.G13_FIXTURES)
+def test_g13_warm_gate_at_another_parameter_set(solver_mod, fixture):
+    """G13: the warm gate (G11's protocol) at G10's set "a", control_steps 3 and 5, generated after the tuning stopped."""
+    solvers = {}
+
+    def get(params, cmap):
+        if "s" not in solvers:
+            solvers["s"] = _solver(solver_mod, params, cmap)
+        return solvers["s"]
+
+    def solve(params, cmap, rows, st, wm):
+        return get(params, cmap).solve(rows, st, wm)
+
+    def post(params, cmap, rows, st, wm, x, success):
+        get(params, cmap).postprocess(rows, st, wm, x, success)
+    try:
+        dv, du, its = util.warm_gate(solve, post, fixture)
+    finally:
+        if "s" in solvers:
+            solvers["s"].close()
+    above, above_at_min, short = util.assert_warm_gate(dv, fixture)
+    print("G13 %s: %d ticks, |command diff| p99 %.2e max %.2e, above 1e-3: %d (%d where the reference is at the minimiser; it "
+          "stalled above the build's objective on %d ticks); iterations %.2f"
+          % (fixture, dv.size, np.percentile(dv, 99), dv.max(), above, above_at_min, short, its.mean()))

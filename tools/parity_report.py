@@ -255,17 +255,24 @@ def held_out_sets():
         with BatchSolver(params) as s:
             s.set_costmap(*cmap)
             return s.solve(pr, st, warm)
-    for name, n in util.G10_GROUPS:
-        m = util.check_held_out_group(solve, name, n, p2_bar=1e-3)
-        print("set %s control_steps %2d: P2 max|u0 - u0(SLSQP 1e-12)| %.2e ; P3 max f - f(SLSQP as shipped): all-free map %.2e costmap %.2e ; "
-              "iterations %.1f / %.1f" % (name, n, m["p2"], m["p3_free"], m["p3_map"], m["it_free"], m["it_map"]))
+    for fixture, groups, min_ok in (("g10_heldout.npz", util.G10_GROUPS, 20), ("g12_after_tuning.npz", util.G12_GROUPS, 16)):
+        if fixture.startswith("g12"):
+            print("\n# G12: three more parameter sets (d, e, f), control_steps 3 / 4 / 6 / 10 -- generated AFTER the last change "
+                  "of round 4 to the search or a threshold")
+        for name, n in groups:
+            m = util.check_held_out_group(solve, name, n, p2_bar=1e-3, fixture=fixture, min_ok=min_ok)
+            print("set %s control_steps %2d: P2 max|u0 - u0(SLSQP 1e-12)| %.2e (reference above the build's objective on %d cases) ; "
+                  "P3 max f - f(SLSQP as shipped): all-free map %.2e costmap %.2e ; iterations %.1f / %.1f"
+                  % (name, n, m["p2"], m["ref_short"], m["p3_free"], m["p3_map"], m["it_free"], m["it_map"]))
 
 
 def warm_gate():
     """G11: the deployed (warm-started) mode against the reference run to convergence (round 4)."""
     print("\n# G11 warm-started ticks: K1 at the README tolerance from the reference's own state vs the reference's CONVERGED command "
           "(opt_tolerance 1e-12, maxiter 500, all-free map)")
-    for fixture in util.G11_FIXTURES:
+    for fixture in util.G11_FIXTURES + util.G13_FIXTURES:
+        if fixture == util.G13_FIXTURES[0]:
+            print("# G13: the same protocol at G10's set \"a\" (heavy control weight, box cutting the disc), generated after the tuning stopped")
         solvers = {}
 
         def get(params, cmap):
@@ -277,7 +284,10 @@ def warm_gate():
                                      lambda p, c, r, st, wm, x, ok: get(p, c).postprocess(r, st, wm, x, ok), fixture)
         solvers["s"].close()
         print("%s: %d ticks the reference converged on" % (fixture, dv.size))
-        print("|command - reference command|_inf : %s ; above 1e-3: %d (%.3f %%)" % (pct(dv), (dv > 1e-3).sum(), 100.0 * (dv > 1e-3).mean()))
+        short = util.warm_gate.ref_short
+        print("|command - reference command|_inf : %s ; above 1e-3: %d (%.3f %%) -- %d of them on the %d ticks where the reference's "
+              "objective is more than 1e-6 above the build's (SLSQP stalled)"
+              % (pct(dv), (dv > 1e-3).sum(), 100.0 * (dv > 1e-3).mean(), (dv[short] > 1e-3).sum(), short.sum()))
         print("|u0 - reference u0|_inf           : %s ; above 1e-3: %d" % (pct(du), (du > 1e-3).sum()))
         print("iterations: mean %.2f max %d" % (its.mean(), its.max()))
 
