@@ -217,7 +217,7 @@ void derive(neo_mpc_handle* h) {
   // the control_steps == 3 specialisations carve LDS at compile time with 4 pair slots; the host
   // must reserve exactly that layout whenever launch_solve() will pick them
   const bool specialised = n == 3 && (d.newton == 1 || (d.newton == 0 && d.mem == 4));
-  l = make_lds_layout(n, specialised ? 4 : (d.newton ? 0 : d.mem), d.newton == 2);
+  l = make_lds_layout(n, specialised ? 4 : (d.newton ? 0 : d.mem), d.newton == 2, !d.disc_in_box);
   const int off = l.tile;
   l.tile_w = 0; l.tile_h = 0; l.reach = 0;
   if (h->has_map) {

@@ -70,6 +70,7 @@ struct LdsLayout {
   int32_t cs, sn, dxs, dys, rx, ry, rt, nx, ny, mode;  // per-step scratch
   int32_t hess;        // Newton: (3N)^2 Hessian, only when 3N <= 24
   int32_t ric;         // Riccati: float32 stage records (28 N floats; the gains overwrite part of them), riccati.h
+  int32_t keep;        // Riccati: the 12 N floats the gains overwrite, kept for a second sweep (riccati_keep_linear_terms)
   int32_t tile;        // byte tile starts here (double index)
   int32_t total_bytes;
   int32_t tile_w;      // row stride of the tile in bytes (power of two), 0: no tile
@@ -80,7 +81,9 @@ struct LdsLayout {
 // The carve-up depends on control_steps and the L-BFGS memory only, so the control_steps
 // specialisations of K1 evaluate it at compile time (offsets become immediates); the host uses the
 // same function and adds the reach tile geometry.
-constexpr LdsLayout make_lds_layout(int n, int mem, bool riccati) {
+// corners: the feasible set has corners (the vx/vy box cuts the max_vel_trans disc) -- the Riccati kernel then keeps room
+// for a second sweep with another active set.
+constexpr LdsLayout make_lds_layout(int n, int mem, bool riccati, bool corners = false) {
   LdsLayout l{};
   const int nv = 3 * n;
   int off = 0;
@@ -111,6 +114,7 @@ constexpr LdsLayout make_lds_layout(int n, int mem, bool riccati) {
     l.hess = off;
     off = (off + 1) & ~1;                   // (16-byte aligned: the records are read as 16-byte words)
     l.ric = off; off += 14 * n;             // 28 floats per stage, riccati.h
+    l.keep = off; off += corners ? 6 * n : 0;   // (16-byte aligned: 14 n is even)
   } else {
     l.u_prev = off; off += nv;
     l.gt_prev = off; off += nv;
@@ -130,6 +134,7 @@ constexpr LdsLayout make_lds_layout(int n, int mem, bool riccati) {
     l.mode = off; off += 2 * n;  // int[4n]: mode, omega-frozen, near-kink, near-kink at the previous iterate
     l.hess = off; off += (nv <= 24) ? nv * nv : 0;
     l.ric = off;
+    l.keep = off;
   }
   off = (off + 1) & ~1;        // 16-byte align the tile
   l.tile = off;

@@ -56,6 +56,7 @@ constexpr int kBlockedRun = NEO_RULE_BLOCKED_RUN;
 constexpr double kBlockedStep = NEO_RULE_BLOCKED_STEP;
 constexpr double kFinalFracGaussNewton = NEO_RULE_FINAL_FRAC_GN;
 constexpr double kWindowStep = NEO_RULE_WINDOW_STEP;
+constexpr int kClosingRun = NEO_RULE_CLOSING_RUN;
 constexpr int kLateIteration = NEO_RULE_LATE_ITERATION;
 
 // Study build (make timing -> libneo_mpc_timing.so): shader-clock stamps at the phase boundaries of
@@ -102,6 +103,44 @@ constexpr int kLateIteration = NEO_RULE_LATE_ITERATION;
 constexpr int kNewtonMaxSteps = 8;
 
 // ---------------------------------------------------------------- K1
+// One-sided slides (second-order directions, round 4).  A block in a CORNER of the feasible set -- two constraints active
+// -- that slides along one of them can only slide away from the other.  A Newton step that sends it the other way is
+// stopped by the projection of every candidate while all the other blocks take the step that counted on it: the
+// direction is then no descent direction at any length (held-out fuzz, box cutting the disc at control_steps 10: a search
+// that crept for 20 iterations on proximal steps alone and stopped 1.4e-2 short).  Such blocks are pinned (mode 2, reduced
+// gradient zero, projector / stage case of a pinned block) and the caller computes the direction once more: one round of
+// a QP solver's active-set step.  Returns whether any block was pinned (wave-uniform).
+template <bool kRiccati, int kNewtonRecord>
+__device__ __forceinline__ bool repin_corner_blocks(const SolveArgs& a, double* L, int n, int lane) {
+  int* AMODE = reinterpret_cast<int*>(L + a.lds.mode);
+  const double* d = L + a.lds.d;
+  const double* u = L + a.lds.u;
+  double* gr = L + a.lds.gr;
+  bool any = false;
+  for (int i = lane; i < n; i += kLanes) {
+    int* am = AMODE + 4 * i;
+    const int other = (am[1] >> 2) & 7;
+    if (am[0] != 1 || other == 0 || (kRiccati && am[3])) continue;
+    const double d0 = d[3 * i], d1 = d[3 * i + 1];
+    const int kind = other & 3;
+    const double outward = kind == 3 ? d0 * u[3 * i] + d1 * u[3 * i + 1] : (kind == 1 ? d0 : d1) * ((other & 4) ? -1.0 : 1.0);
+    if (!(outward > 0.0)) continue;
+    any = true;
+    am[0] = 2; gr[3 * i] = 0.0; gr[3 * i + 1] = 0.0;
+    if (kRiccati) {
+      float* rs = reinterpret_cast<float*>(L + a.lds.ric) + kRicStage * i;
+      const int flags = (int)rs[RS_FLAGS], kase = flags & RF_CASE;
+      rs[RS_FLAGS] = (float)((flags & ~RF_CASE) | (kase == RC_SLIDE_W ? RC_W : kase == RC_SLIDE ? RC_NONE : kase));
+    } else {
+      float* nb = reinterpret_cast<float*>(L + a.lds.cs) + kNewtonRecord * i;
+      nb[0] = 0.0f; nb[1] = 0.0f; nb[2] = 0.0f;
+    }
+  }
+  const bool redo = __ballot(any) != 0ull;
+  WAVE_SYNC();
+  return redo;
+}
+
 // kSteps > 0: specialisation for control_steps == kSteps -- every lane keeps its candidate's controls
 // and sin/cos in registers, so the winner is stored without being recomputed and the next adjoint
 // sweep needs no trigonometry.  kSteps == 0: any control_steps (LDS-only path).
@@ -480,6 +519,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     NEO_PHASE(1);
     // ---- total gradient (control norm: minimal-norm subgradient at the kink), tangent-cone
     //      reduction at active bounds; lanes take steps
+    bool my_corner = false;   // a block of this lane slides along one constraint in a corner of the feasible set
     for (int i = lane; i < n; i += kLanes) {
       const double u0 = u[3 * i], u1 = u[3 * i + 1], u2 = u[3 * i + 2];
       const double g0 = gs[3 * i], g1 = gs[3 * i + 1], g2 = gs[3 * i + 2];
@@ -565,7 +605,16 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       gr[3 * i] = r0; gr[3 * i + 1] = r1; gr[3 * i + 2] = wfroz ? 0.0 : t2;
       // (slot 1: omega frozen | 2 x "the slide is along the disc" -- a block sliding along a box bound stops at the corner
       // where the bound meets the disc, feasible_set.h candidate_block)
-      ANX[i] = mnx; ANY[i] = mny; AMODE[4 * i] = mode; AMODE[4 * i + 1] = wfroz | ((mode == 1 && mslot == 2) ? 2 : 0); AMODE[4 * i + 2] = 0;
+      // (bits 2-4, second-order directions: the OTHER constraint active at a sliding block's position -- the slide is
+      // one-sided there, see repin_corner_blocks: 1 vx bound, 2 vy bound, 3 disc, + 4 for a lower bound)
+      int other = 0;
+      if (kSecond && !kTame && mode == 1) {
+        if (v2 && mslot != 2) other = 3;
+        else if (v0 && mslot != 0) other = 1 | (nx0 < 0.0 ? 4 : 0);
+        else if (v1 && mslot != 1) other = 2 | (ny1 < 0.0 ? 4 : 0);
+        my_corner = my_corner || other != 0;
+      }
+      ANX[i] = mnx; ANY[i] = mny; AMODE[4 * i] = mode; AMODE[4 * i + 1] = wfroz | ((mode == 1 && mslot == 2) ? 2 : 0) | (other << 2); AMODE[4 * i + 2] = 0;
       if (kNewton) {
         // Block record of the Newton system, float32: the projector onto the tangent cone's face
         // (P00 P01 P11 PW) and the block's own curvature C (3x3): the control norm's Hessian
@@ -592,6 +641,9 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       if (kRiccati) ARTF[2 * i] = (mode == 1 && mslot == 2) ? (float)(mlam * rcp_fast(p.r)) : 0.0f;
     }
     WAVE_SYNC();
+    // (in free space only -- no costmap term under the iterate's rollout: next to a cost step the Newton model is off either
+    // way; the dense kernel knows that sum from the previous iteration's winner)
+    const bool corner_any = kSecond && !kTame && __ballot(my_corner) != 0ull && (kRiccati ? free_path : (it > 0 && u_term == 0.0));
     NEO_PHASE(2);
     if (p.max_it == kDumpGradient) {
       // test hook (neo_mpc_gradient_batch): hand back the total gradient this kernel variant works with at
@@ -609,12 +661,20 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     } else if (kRiccati) {
       riccati_prepare(a, c, L, n, lane, v_feasible, (float)TOL[T_MU]);
       WAVE_SYNC();
+      if (corner_any) riccati_keep_linear_terms(a, L, n, lane, true);   // (the sweep writes its gains over them)
+      auto sweep = [&]() {
 #ifdef NEO_MPC_RICCATI_F64   // (study build: the same recursion in float64 on the float32 records)
-      riccati_sweep<double>(a, L, n, lane);
+        riccati_sweep<double>(a, L, n, lane);
 #else
-      riccati_sweep<float, (kMinWavesPerSimd < 4)>(a, L, n, lane);
+        riccati_sweep<float, (kMinWavesPerSimd < 4)>(a, L, n, lane);
 #endif
-      riccati_finish(a, c, L, n, lane);
+        riccati_finish(a, c, L, n, lane);
+      };
+      sweep();
+      if (!kTame && corner_any && repin_corner_blocks<true, 0>(a, L, n, lane)) {   // (one-sided slides: once more, those blocks pinned)
+        riccati_keep_linear_terms(a, L, n, lane, false);
+        sweep();
+      }
     } else if (kNewton) {
       // From here on the Newton system lives in float32: it only yields a search direction (the arc
       // search and the float64 objective decide), and single precision halves registers, readlanes
@@ -624,6 +684,15 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       const int kv = lane < nvr ? lane : 0, kb = (kv * 11) >> 5, kq = kv - 3 * kb;   // kv / 3 for kv < 32
       const int hs = nvr;  // row stride of the system in LDS
       const float* own = NB + kNewtonRecord * kb;
+      // (a block sliding in a corner of the feasible set: the finite-difference columns are kept -- behind the system,
+      // in the float64-sized half of its LDS slot -- in case the system has to be solved once more with that block pinned)
+      float* Hraw = Hm + hs * hs;
+      if (!kTame && corner_any && lane < nvr) {
+#pragma unroll
+        for (int j = 0; j < kVars; ++j)
+          if (kSteps || j < nvr) Hraw[j * hs + lane] = hc[j];
+      }
+      auto solve_on_the_face = [&]() {
       // ---- lane k < 3N holds Hessian column k: add column kq of its block's curvature, apply P on
       //      the row index, store the column
       {
@@ -713,6 +782,27 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       if (lane < nvr) d[lane] = (double)sol;
       newton_sol = sol;
       WAVE_SYNC();
+      };
+      auto columns_again = [&]() {
+        if (lane < nvr) {
+#pragma unroll
+          for (int j = 0; j < kVars; ++j)
+            if (kSteps || j < nvr) hc[j] = Hraw[j * hs + lane];
+        }
+      };
+      // one-sided slides (repin_corner_blocks): once more with those blocks pinned.  control_steps specialisations: a second
+      // copy of the solve behind a branch, so that the first keeps its straight-line code (as a loop the general
+      // control_steps-3 kernel lost a quarter of its rate); the run-time-sized kernel: one copy in a two-trip loop
+      if constexpr (kSteps != 0) {
+        solve_on_the_face();
+        if (!kTame && corner_any && repin_corner_blocks<false, kNewtonRecord>(a, L, n, lane)) { columns_again(); solve_on_the_face(); }
+      } else {
+        for (int pass = 0;; ++pass) {
+          solve_on_the_face();
+          if (kTame || pass == 1 || !corner_any || !repin_corner_blocks<false, kNewtonRecord>(a, L, n, lane)) break;
+          columns_again();
+        }
+      }
     }
     NEO_PHASE(3);
     // ---- new curvature pair
@@ -974,7 +1064,11 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     bool creeping = wtol > 0.0 && gain + gain1 + gain2 <= wtol * fscale && window_on;
     // ... and so does a step below stall_step whose gain halved twice in a row: the search is closing in on a
     // costmap cell edge (or the kink) geometrically; what is left to gain is less than the last gain
-    creeping = creeping || (wtol0 > 0.0 && (double)stepmax <= TOL[T_STALL] && gain <= 0.5 * gain1 && gain1 <= 0.5 * gain2 && window_on);
+    // (dense and L-BFGS directions: only behind kClosingRun blocked iterations -- the gains of a Newton search that converges
+    // quadratically halve twice in a row as well, and one blocked iteration after them, a bound about to become active, is
+    // no sign of creeping: random parameter sets, 1 solve in 3000 stopped 5e-3 short)
+    creeping = creeping || (wtol0 > 0.0 && (double)stepmax <= TOL[T_STALL] && gain <= 0.5 * gain1 && gain1 <= 0.5 * gain2 &&
+                            (kRiccati ? window_on : nblocked >= kClosingRun));
     // Blocked-run stop rule (dense Newton).  kBlockedRun iterations in a row not won by a decent Newton step that
     // together gain less than 0.1 x opt_tolerance (0.03 x with no costmap term under the new iterate's rollout): something
     // the quadratic model does not see is in the way -- a costmap cell edge, or blocks hovering next to the control norm's
@@ -993,6 +1087,9 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     }
     gain2 = gain1; gain1 = gain;
     f = fb;
+    // the last-step rule rests on the Newton model having held: an iteration announced as the last but WON by a proximal
+    // step or a short Newton step (a bound about to become active, the kink) is not the last
+    if (nblocked != 0) final_step = false;
     if (kNewton) u_term = lane_value(cterm, best);
     // (a hop that won says nothing about step lengths: damping and proximal step stay as they are)
     if (kRiccati && !(it == 0 && cold) && !hop_won) {   // (an iteration that had a Newton direction)

@@ -134,6 +134,19 @@ __device__ __forceinline__ void riccati_prepare(const SolveArgs& a, const Ctx& c
   rs[RS_C00] = c00; rs[RS_C01] = c01; rs[RS_C02] = c02; rs[RS_C11] = c11; rs[RS_C12] = c12; rs[RS_C22] = c22;
 }
 
+// The backward sweep writes each stage's gains over the linear terms of its record (RS_GAIN .. the end).  A sweep that may
+// have to be repeated with another active set (k_solve: repin_corner_blocks) keeps those twelve floats per stage aside
+// (save) and puts them back (!save); lane = stage.
+__device__ __forceinline__ void riccati_keep_linear_terms(const SolveArgs& a, double* L, int n, int lane, bool save) {
+  ric_f4* rec = reinterpret_cast<ric_f4*>(reinterpret_cast<float*>(L + a.lds.ric) + kRicStage * lane + RS_GAIN);
+  ric_f4* keep = reinterpret_cast<ric_f4*>(L + a.lds.keep) + 3 * lane;
+  for (int i = lane; i < n; i += kLanes, rec += 7 * kLanes, keep += 3 * kLanes) {
+    if (save) { keep[0] = rec[0]; keep[1] = rec[1]; keep[2] = rec[2]; }
+    else { rec[0] = keep[0]; rec[1] = keep[1]; rec[2] = keep[2]; }
+  }
+  WAVE_SYNC();
+}
+
 // Backward + forward sweep in displacement coordinates, wave-uniform.  The record of stage i - 1 is fetched
 // (seven 16-byte LDS reads) while stage i is worked on: nothing in it depends on the recursion.  Output: w_i
 // in d (float64 slots), and per block tokink (AMODE slot 3): the stage model's minimiser is the kink itself.

@@ -383,6 +383,8 @@ typedef struct orc_active {
   int riccati;              /* the Riccati kernel's candidate rules apply (per-block prox step) */
   int longshots;            /* lanes 61-63 are step lengths 8, 16, 32 (Newton directions) */
   uint8_t rest[ORC_MAXN];   /* near block exactly on the kink whose smooth gradient keeps it there */
+  uint8_t corner[ORC_MAXN]; /* mode 1 with a SECOND constraint active at u_i (outward normal n2): the slide is one-sided */
+  double n2x[ORC_MAXN], n2y[ORC_MAXN];
 } orc_active;
 
 
@@ -391,8 +393,11 @@ typedef struct orc_active {
  * Out: the reduced gradient gr[3] and the face (wfroz, mode 0/1/2, outward normal, disc flag, multiplier). */
 static int orc_near_reduced = 1;
 void orc_set_near_reduced(int m) { orc_near_reduced = m; }
+static _Thread_local double orc_tangent_n2[2];
+static _Thread_local int orc_tangent_corner;
 static void orc_tangent(const orc_ctx* c, const double* ui, const double* gi, double* gr, uint8_t* wfroz, uint8_t* mode,
                         double* nxo, double* nyo, uint8_t* disc, double* lambda) {
+  orc_tangent_corner = 0;
   gr[0] = gi[0]; gr[1] = gi[1]; gr[2] = gi[2];
   /* omega: plain bound */
   *wfroz = (ui[2] <= c->lo[2] && gi[2] > 0.0) || (ui[2] >= c->hi[2] && gi[2] < 0.0);
@@ -430,6 +435,7 @@ static void orc_tangent(const orc_ctx* c, const double* ui, const double* gi, do
       double dn = nx[bestk] * dx + ny[bestk] * dy;
       *mode = 1; *nxo = nx[bestk]; *nyo = ny[bestk];
       *disc = (uint8_t)isdisc[bestk]; *lambda = dn;
+      for (int j = 0; j < na; ++j) if (j != bestk && !orc_tangent_corner) { orc_tangent_corner = 1; orc_tangent_n2[0] = nx[j]; orc_tangent_n2[1] = ny[j]; }
       gr[0] = -(dx - dn * nx[bestk]);
       gr[1] = -(dy - dn * ny[bestk]);
     } else {
@@ -465,6 +471,7 @@ static void orc_reduce(const orc_ctx* c, const double* u, double* gs, double* gt
       a->rest[i] = ne == 0.0 && gsi[0] * gsi[0] + gsi[1] * gsi[1] + gsi[2] * gsi[2] <= c->wc_n * c->wc_n;
       for (int k = 0; k < 3; ++k) { gt[3 * i + k] = 0.0; gr[3 * i + k] = 0.0; }
       a->wfroz[i] = 0; a->mode[i] = 0; a->nx[i] = 0.0; a->ny[i] = 0.0; a->disc[i] = 0; a->lambda[i] = 0.0;
+      a->corner[i] = 0;
       continue;
     }
     a->rest[i] = 0;
@@ -478,6 +485,7 @@ static void orc_reduce(const orc_ctx* c, const double* u, double* gs, double* gt
     }
     for (int k = 0; k < 3; ++k) gt[3 * i + k] = gi[k];
     orc_tangent(c, ui, gi, gr + 3 * i, &a->wfroz[i], &a->mode[i], &a->nx[i], &a->ny[i], &a->disc[i], &a->lambda[i]);
+    a->corner[i] = (uint8_t)orc_tangent_corner; a->n2x[i] = orc_tangent_n2[0]; a->n2y[i] = orc_tangent_n2[1];
   }
 }
 
@@ -1040,6 +1048,14 @@ static double orc_lane_scale(int lane, int longshots) {
  * point beyond that corner slides DOWN the disc, away from the bound, so a Newton step along the bound was cut to the
  * fraction that reaches the corner and every other block's step with it (held-out set "a", control_steps 12: searches
  * jammed at the corner for 20 iterations).  A/B hook: orc_set_corner_stop(0). */
+static int orc_final_confirm = 1;
+void orc_set_final_confirm(int m) { orc_final_confirm = m; }
+static int orc_closing_need = NEO_RULE_CLOSING_RUN;
+void orc_set_closing_need(int m) { orc_closing_need = m; }
+static int orc_repin = 1;
+void orc_set_repin(int m) { orc_repin = m; }
+static long orc_repin_count = 0;
+long orc_get_repin_count(void) { return orc_repin_count; }
 static int orc_corner_stop = 1;
 void orc_set_corner_stop(int m) { orc_corner_stop = m; }
 static int orc_exit_hops = 1;
@@ -1307,6 +1323,28 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
       else if (riccati) orc_riccati_direction(&c, u, gs, gt, &act, d);
       else orc_newton_direction(&c, u, gs, gr, &act, d);
       orc_apply_active(&c, &act, d);
+      if (orc_repin && (riccati || orc_repin == 1) && !(it == 0 && cold) &&
+          (orc_repin == 3 || (riccati ? orc_free_path(&c, u) : (it > 0 && orc_term_sum(&c, u) == 0.0)))) {
+        /* (round 4) one-sided slides: a block in a corner of the feasible set (two constraints active) that slides along
+         * one of them can only slide AWAY from the other -- a Newton step that sends it the other way is stopped by the
+         * projection while every other block takes the step that counted on it.  Such blocks are pinned and the direction
+         * is computed once more (the active-set step of a QP solver, one round of it).  In free space only (no costmap term
+         * under the iterate's rollout): next to a cost step the Newton model is off either way and what finds the way on is
+         * the spread of the candidates -- pinning changed which basin one recorded episode of the reference ended in. */
+        int redo = 0;
+        for (int i = 0; i < n; ++i)
+          if (act.mode[i] == 1 && act.corner[i] && !act.tokink[i] && d[3 * i] * act.n2x[i] + d[3 * i + 1] * act.n2y[i] > 0.0) {
+            if (orc_trace) fprintf(stderr, "      repin block %d: d %.3e %.3e n2 %.3f %.3f\n", i, d[3 * i], d[3 * i + 1], act.n2x[i], act.n2y[i]);
+            act.mode[i] = 2; gr[3 * i] = 0.0; gr[3 * i + 1] = 0.0; redo = 1;
+          }
+        if (redo) {
+          ++orc_repin_count;
+          if (riccati && orc_disp) { orc_mu = mu; orc_riccati_direction_disp_tau(&c, u, gs, gt, &act, d, exact_step ? 1.0 : 0.0); orc_mu = 0.0; }
+          else if (riccati) orc_riccati_direction(&c, u, gs, gt, &act, d);
+          else orc_newton_direction(&c, u, gs, gr, &act, d);
+          orc_apply_active(&c, &act, d);
+        }
+      }
       if (it > 0) { /* the full Newton step is already below the step tolerance: u is the answer
                      * (the prox-moved blocks next to the kink are not covered by d) */
         double dm = 0.0;
@@ -1458,11 +1496,16 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
     /* ... and so does a step below stall_step whose gain halved twice in a row: the search is closing in on a
      * costmap cell edge (or the kink) geometrically, what is left to gain is less than the last gain (part of the
      * window rule: off with it).  -3 % iterations at control_steps 3 and 32, no command moves by 1e-3. */
-    const int closing_in = wtol > 0.0 && step <= stall_step && decrease <= 0.5 * gain1 && gain1 <= 0.5 * gain2 && (orc_rule_mode < 1 || !riccati || nblocked >= 3);
+    const int closing_in = wtol > 0.0 && step <= stall_step && decrease <= 0.5 * gain1 && gain1 <= 0.5 * gain2 && (orc_rule_mode < 1 || (riccati ? nblocked >= 3 : nblocked >= orc_closing_need));
     int blocked_stop = 0;
     if (newton && !riccati && orc_blocked_rule && wtol > 0.0 && blocked_run >= ORC_BLOCKED_RUN)
       blocked_stop = decrease + gain1 + gain2 <= (orc_term_sum(&c, u) == 0.0 ? rules.btol_free : rules.btol_map);
     gain2 = gain1; gain1 = decrease;
+    /* (round 4) the last-step rule rests on the Newton model having held: an iteration announced as the last but WON by a
+     * proximal step or a short Newton step (the model was off: a bound about to become active, the kink) is not the last */
+    if (orc_final_confirm && final && !(best >= 32 && orc_lane_scale(best, act.longshots) >= NEO_RULE_WINDOW_STEP)) final = 0;
+    if (orc_trace) fprintf(stderr, "      rules: step %.3e (xtol %.1e stall_step %.1e) decrease %.3e stall %d creeping %d closing_in %d final %d blocked_stop %d (run %d) nblocked %d\n",
+                           step, xtol, stall_step, decrease, stall, creeping, closing_in, final, blocked_stop, blocked_run, nblocked);
     if (step < xtol || stall >= ORC_STALL_ITERATIONS || creeping || closing_in || final || blocked_stop) { status = NEO_MPC_STATUS_CONVERGED; ++it; goto exit_check; }
     continue;
   exit_check:

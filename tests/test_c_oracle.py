@@ -480,6 +480,10 @@ def test_g13_warm_gate_at_another_parameter_set(fixture):
           % (fixture, dv.size, np.percentile(dv, 99), dv.max(), above, above_at_min, short, its.mean()))
 
 
+def test_one_sided_slides_and_the_closing_in_rule_mirror():
+    print("stop-rule regressions (mirror): (|du0| of the instance, max over 256, iterations)", util.check_stop_rule_regressions(_cold_solve))
+
+
 @pytest.mark.parametrize("fixture", util.EPISODE_FIXTURES)
 def test_p3_on_the_reference_warm_starts_mirror(fixture):
     """P3w on the CPU mirror (the GPU test of the same name runs K1): every call of the recorded episodes solved from the

@@ -1093,3 +1093,14 @@ def test_g13_warm_gate_at_another_parameter_set(solver_mod, fixture):
     print("G13 %s: %d ticks, |command diff| p99 %.2e max %.2e, above 1e-3: %d (%d where the reference is at the minimiser; it "
           "stalled above the build's objective on %d ticks); iterations %.2f"
           % (fixture, dv.size, np.percentile(dv, 99), dv.max(), above, above_at_min, short, its.mean()))
+
+
+def test_one_sided_slides_and_the_closing_in_rule(solver_mod):
+    """Two searches the random-parameter fuzz found stopping short (util.check_stop_rule_regressions), through the C-ABI:
+    the general (non-tame) stage-wise kernel's second sweep with corner blocks pinned, and the dense kernel's closing-in
+    rule."""
+    def solve(params, cmap, pr):
+        st, warm = synthetic.make_states(pr, params["control_steps"])
+        with _solver(solver_mod, params, cmap) as s:
+            return s.solve(pr, st, warm)
+    print("stop-rule regressions: (|du0| of the instance, max over 256, iterations)", util.check_stop_rule_regressions(solve))

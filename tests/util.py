@@ -214,3 +214,45 @@ def assert_warm_gate(dv, fixture):
     assert (at_min <= 1e-3).mean() >= 0.999, (fixture, (at_min > 1e-3).sum(), at_min.size, at_min.max())
     assert (dv <= 1e-3).mean() >= 0.99 and dv.max() <= 5e-3, (fixture, (dv > 1e-3).sum(), dv.size, dv.max())
     return int((dv > 1e-3).sum()), int((at_min > 1e-3).sum()), int(short.sum())
+
+
+#: (round 4) two searches the random-parameter fuzz found stopping short; the values are the fuzz's draws
+CORNER_SET = dict(control_steps=10, max_vel_x=0.8074363686083792, min_vel_x=-0.6529286462016756, max_vel_y=0.6821757373561252,
+                  min_vel_y=-0.6821757373561252, max_vel_trans=0.8190297446276567, max_vel_theta=1.311122200647496,
+                  min_vel_theta=-1.046923033825679, w_trans=1.851846062907643, w_orient=1.0654822176259133,
+                  w_control=0.07955025485374233, w_terminal=0.014261579164782094, w_costmap=0.22656099959405637,
+                  prediction_horizon=0.6553971944084013)
+CLOSING_SET = dict(control_steps=3, max_vel_x=0.4687266244102684, min_vel_x=-0.13636412838390244, max_vel_y=0.23990841075303393,
+                   min_vel_y=-0.23990841075303393, max_vel_trans=0.6346691128830954, max_vel_theta=1.0744619081196514,
+                   min_vel_theta=-0.7455525260186087, w_trans=1.624981170062613, w_orient=0.9471912249885202,
+                   w_control=0.35504224630224157, w_terminal=0.29155579279540883, w_costmap=0.24117871887188674,
+                   prediction_horizon=0.7451387226351949)
+CORNER3_SET = dict(control_steps=3, max_vel_x=0.896726222782037, min_vel_x=-0.526036149425443, max_vel_y=0.42580420912603656,
+                   min_vel_y=-0.42580420912603656, max_vel_trans=0.98382188609014, max_vel_theta=1.5369900040891644,
+                   min_vel_theta=-1.0561500863189393, w_trans=1.7833138660348593, w_orient=0.6860036735692177,
+                   w_control=0.047025036947067854, w_terminal=0.052826917579506354, w_costmap=0.042441839011586456,
+                   prediction_horizon=0.7327823311689736)
+
+
+def check_stop_rule_regressions(solve):
+    """`solve(params, cmap, problems) -> (commands, x)`, cold.  (a) One-sided slides: with the box cutting the disc, blocks
+    sit in corners of the feasible set; a Newton step that sent one of them out of its corner was no descent direction at
+    any length and the search crept on proximal steps (instance 233: 21 iterations, stopped 1.4e-2 short) -- such blocks
+    are pinned and the direction computed once more.  (b) The closing-in rule fired on a quadratically converging Newton
+    search followed by ONE blocked iteration (instance 2: 4.8e-3 short).  Both against the same search run to the end."""
+    from neo_mpc_planner2_amd import synthetic
+    out = {}
+    for tag, pset, seed, inst, it_cap in (("corner", CORNER_SET, 110, 233, 15), ("closing", CLOSING_SET, 115, 2, 8),
+                                          ("corner, dense direction", CORNER3_SET, 117, 151, 9)):   # (instance 151: 1.2e-2 short)
+        params = orc.make_params(**pset)
+        _, cmap, probs, _, _ = synthetic.make_workload("C2", seed=seed, batch=256)
+        free = (np.zeros_like(cmap[0]),) + tuple(cmap[1:])
+        tight = dict(params, window_tolerance=-1.0, step_tolerance=1e-10, cost_tolerance=1e-14, max_iterations=400)
+        c1, x1 = solve(params, free, probs)
+        c2, x2 = solve(tight, free, probs)
+        du = np.abs(x1[:, :3] - x2[:, :3]).max(axis=1)
+        assert du[inst] <= 1e-3 and c1["iterations"][inst] <= it_cap, (tag, du[inst], c1["iterations"][inst])
+        assert (du > 1e-3).sum() <= 1 and du.max() <= 2.5e-3, (tag, np.sort(du)[-3:])
+        assert (c1["cost"] <= c2["cost"] + 1e-5).all()
+        out[tag] = (du[inst], du.max(), int(c1["iterations"][inst]))
+    return out
