@@ -46,6 +46,11 @@
 #include "feasible_set.h"
 #include "rollout.h"
 #include "riccati.h"
+#include "adjoint.h"
+#include "tangent_cone.h"
+#include "dense_newton.h"
+#include "lbfgs.h"
+#include "exit_hop.h"
 
 namespace neo_mpc {
 namespace {
@@ -103,44 +108,6 @@ constexpr int kLateIteration = NEO_RULE_LATE_ITERATION;
 constexpr int kNewtonMaxSteps = 8;
 
 // ---------------------------------------------------------------- K1
-// One-sided slides (second-order directions, round 4).  A block in a CORNER of the feasible set -- two constraints active
-// -- that slides along one of them can only slide away from the other.  A Newton step that sends it the other way is
-// stopped by the projection of every candidate while all the other blocks take the step that counted on it: the
-// direction is then no descent direction at any length (held-out fuzz, box cutting the disc at control_steps 10: a search
-// that crept for 20 iterations on proximal steps alone and stopped 1.4e-2 short).  Such blocks are pinned (mode 2, reduced
-// gradient zero, projector / stage case of a pinned block) and the caller computes the direction once more: one round of
-// a QP solver's active-set step.  Returns whether any block was pinned (wave-uniform).
-template <bool kRiccati, int kNewtonRecord>
-__device__ __forceinline__ bool repin_corner_blocks(const SolveArgs& a, double* L, int n, int lane) {
-  int* AMODE = reinterpret_cast<int*>(L + a.lds.mode);
-  const double* d = L + a.lds.d;
-  const double* u = L + a.lds.u;
-  double* gr = L + a.lds.gr;
-  bool any = false;
-  for (int i = lane; i < n; i += kLanes) {
-    int* am = AMODE + 4 * i;
-    const int other = (am[1] >> 2) & 7;
-    if (am[0] != 1 || other == 0 || (kRiccati && am[3])) continue;
-    const double d0 = d[3 * i], d1 = d[3 * i + 1];
-    const int kind = other & 3;
-    const double outward = kind == 3 ? d0 * u[3 * i] + d1 * u[3 * i + 1] : (kind == 1 ? d0 : d1) * ((other & 4) ? -1.0 : 1.0);
-    if (!(outward > 0.0)) continue;
-    any = true;
-    am[0] = 2; gr[3 * i] = 0.0; gr[3 * i + 1] = 0.0;
-    if (kRiccati) {
-      float* rs = reinterpret_cast<float*>(L + a.lds.ric) + kRicStage * i;
-      const int flags = (int)rs[RS_FLAGS], kase = flags & RF_CASE;
-      rs[RS_FLAGS] = (float)((flags & ~RF_CASE) | (kase == RC_SLIDE_W ? RC_W : kase == RC_SLIDE ? RC_NONE : kase));
-    } else {
-      float* nb = reinterpret_cast<float*>(L + a.lds.cs) + kNewtonRecord * i;
-      nb[0] = 0.0f; nb[1] = 0.0f; nb[2] = 0.0f;
-    }
-  }
-  const bool redo = __ballot(any) != 0ull;
-  WAVE_SYNC();
-  return redo;
-}
-
 // kSteps > 0: specialisation for control_steps == kSteps -- every lane keeps its candidate's controls
 // and sin/cos in registers, so the winner is stored without being recomputed and the next adjoint
 // sweep needs no trigonometry.  kSteps == 0: any control_steps (LDS-only path).
@@ -248,26 +215,12 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   double* u_prev = L + a.lds.u_prev;
   double* gt_prev = L + a.lds.gt_prev;
   double* u_new = L + a.lds.u_new;
-  double* Sm = L + a.lds.S;
-  double* Ym = L + a.lds.Y;
-  double* rho = L + a.lds.rho;
   double* ACS = L + a.lds.cs;
   double* ASN = L + a.lds.sn;
-  double* ADX = L + a.lds.dxs;
-  double* ADY = L + a.lds.dys;
-  double* ARX = L + a.lds.rx;
-  double* ARY = L + a.lds.ry;
-  double* ART = L + a.lds.rt;
-  float* ARTF = reinterpret_cast<float*>(L + a.lds.rt);   // Riccati: [2 i] disc curvature lambda / r of block i, [2 i + 1] tau x SX_i (riccati.h)
-  double* ANX = L + a.lds.nx;
-  double* ANY = L + a.lds.ny;
   int* AMODE = reinterpret_cast<int*>(L + a.lds.mode);  // [4n]: mode, wfroz, near, near_prev
   // Newton: one float32 record per control block (projector + block curvature), written by the
   // tangent-cone pass; it lives in the cs..rt step arrays, which the Newton kernel does not use
-  constexpr int kNewtonRecord = 13;
   static_assert(2 * 7 >= kNewtonRecord, "Newton records do not fit the step arrays");
-  float* NB = reinterpret_cast<float*>(L + a.lds.cs);
-  float* RS = reinterpret_cast<float*>(L + a.lds.ric);   // Riccati: float32 stage records (then the gains, riccati.h)
 
   // x0 clipped to the feasible set (SciPy clips x0 to the bounds, _slsqp_py.py:268)
   for (int i = lane; i < n; i += kLanes) project_block<kTame>(p, u[3 * i], u[3 * i + 1], u[3 * i + 2]);
@@ -364,8 +317,8 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     int nhops = 0;            // Riccati: hop candidates of this iteration (wave-uniform; the table is in the tolerance block)
     float hc[kVars];     // Newton: column `lane` of the Hessian, then row `lane` (float32, see below)
     float newton_sol = 0.0f;  // Newton: entry `lane` of the direction
-    double hcol[kSteps ? kVars : 1];  // control_steps specialisation: gradient of this lane's perturbed copy
     if (kNewton) {
+      double hcol[kSteps ? kVars : 1];  // control_steps specialisation: gradient of this lane's perturbed copy
       // Every lane runs the rollout + adjoint sweep on its own copy of u: lane k < 3N perturbs
       // coordinate k by h, the other lanes leave u alone.  One pass therefore yields the gradient
       // (any unperturbed lane) and all 3N Hessian columns by forward differences -- the sweep
@@ -375,7 +328,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       // while it unwinds x, y, theta (fewer live registers -> one more wave per SIMD)
       double pcs[kNwSteps], psn[kNwSteps];
       double x = 0.0, y = 0.0, th = 0.0;
-#pragma unroll
+    #pragma unroll
       for (int i = 0; i < kNwSteps; ++i) {
         if (kSteps || i < n) {
           const double vx = u[3 * i] + (lane == 3 * i ? hstep : 0.0);
@@ -388,7 +341,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         }
       }
       double SX = 0.0, SY = 0.0, ST = 0.0;
-#pragma unroll
+    #pragma unroll
       for (int k = kNwSteps - 1; k >= 0; --k) {
         if (kSteps || k < n) {
           const double vx = u[3 * k] + (lane == 3 * k ? hstep : 0.0);
@@ -418,7 +371,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         }
       }
       if (kSteps) {
-#pragma unroll
+    #pragma unroll
         for (int j = 0; j < kVars; ++j) {
           const double base = lane_value(hcol[j], 63);
           if (lane == 63) gs[j] = base;
@@ -426,220 +379,13 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         }
       }
       WAVE_SYNC();
-    } else if (!kSteps) {
-      // (L-BFGS and Riccati) any control_steps <= 64: lane i owns step i; the rollout recursion (py:230-232) is three
-      // prefix sums, the adjoint three suffix sums -- one sincos per lane instead of N in a row
-      const bool on = lane < n;
-      const double vx = on ? u[3 * lane] : 0.0, vy = on ? u[3 * lane + 1] : 0.0, w = on ? u[3 * lane + 2] : 0.0;
-      const double th = wave_scan(w * p.dt);
-      double sn, cs;
-      sincos_heading<kTame>(th, &sn, &cs);
-      const double ddx = (vx * cs - vy * sn) * p.dt, ddy = (vx * sn + vy * cs) * p.dt;
-      const double x = wave_scan(ddx), y = wave_scan(ddy);
-      double rt = on ? -2.0 * p.wo_n * (c.tyaw - th) : 0.0;
-      if (lane == n - 1) rt += -2.0 * p.wterm_o * (c.fyaw - th);
-      const double rx = on ? -2.0 * p.wt_n * (c.cx - x) : 0.0, ry = on ? -2.0 * p.wt_n * (c.cy - y) : 0.0;
-      // suffix sums: S_k = sum_{i >= k} r_i = total - prefix_k + r_k
-      const double px = wave_scan(rx), py = wave_scan(ry);
-      const double SX = lane_value(px, 63) - px + rx, SY = lane_value(py, 63) - py + ry;
-      const double tt = on ? rt - ddy * SX + ddx * SY : 0.0;
-      const double pt = wave_scan(tt);
-      const double ST = lane_value(pt, 63) - pt + tt;
-      int raw_here = 0;
-      bool has_hop = false;
-      float hop_x = 0.0f, hop_y = 0.0f;
-      if (on) {
-        gs[3 * lane] = p.dt * (cs * SX + sn * SY);
-        gs[3 * lane + 1] = p.dt * (-sn * SX + cs * SY);
-        gs[3 * lane + 2] = p.dt * ST;
-        if (kRiccati) {
-          // stage record of the Riccati sweep (float32): trigonometry, position increments and the
-          // wall-sliding penalty on the stage position (costmap.h)
-          float* rs = RS + kRicStage * lane;
-          rs[RS_CS] = (float)cs; rs[RS_SN] = (float)sn; rs[RS_PX] = (float)ddx; rs[RS_PY] = (float)ddy;
-          double wxx, wxy, wyy, wlx, wly;
-          raw_here = edge_stickiness(a, c, L, x, y, cs, sn, wxx, wxy, wyy, wlx, wly, has_hop, hop_x, hop_y);
-          rs[RS_WXX] = (float)wxx; rs[RS_WXY] = (float)wxy; rs[RS_WYY] = (float)wyy;
-          rs[RS_WLX] = (float)wlx; rs[RS_WLY] = (float)wly;
-          // position costates of this stage, for the second-order terms of the rollout step (riccati.h): only behind an
-          // iteration won by a decent Newton step (the model held there) -- far from the minimiser the exact Hessian is
-          // indefinite and the Gauss-Newton direction is the safer one
-          rs[RS_SY] = exact_step ? (float)SY : 0.0f;
-          ARTF[2 * lane + 1] = exact_step ? (float)SX : 0.0f;
-        }
-      }
-      if (kRiccati) {
-        free_path = __ballot(raw_here != 0) == 0ull;
-        // hop table of this iteration: the first kHopLanes stages with a cheaper cell a hop away (lanes 1.. of the search)
-        const unsigned long long hmask = __ballot(has_hop);
-        const int rank = __popcll(hmask & ((1ull << lane) - 1ull));
-        double* t = L + a.lds.tol;
-        if (has_hop && rank < kHopLanes) {
-          reinterpret_cast<int*>(t + T_HOP_STAGE)[rank] = lane;
-          reinterpret_cast<float*>(t + T_HOP_VEC)[2 * rank] = hop_x;
-          reinterpret_cast<float*>(t + T_HOP_VEC)[2 * rank + 1] = hop_y;
-        }
-        nhops = min(__popcll(hmask), (int)kHopLanes);
-        if (lane == 0) reinterpret_cast<int*>(t + T_HOP_STAGE)[kHopLanes] = nhops;
-      }
-      WAVE_SYNC();
-    } else {
-      // specialisations: all lanes walk the same short sweep, reusing the winner's sin/cos
-      double x = 0.0, y = 0.0, th = 0.0;
-#pragma unroll
-      for (int i = 0; i < n; ++i) {
-        const double vx = u[3 * i], vy = u[3 * i + 1], w = u[3 * i + 2];
-        th += w * p.dt;
-        double sn, cs;
-        if (kSteps && have_trig) { sn = ASN[i]; cs = ACS[i]; }
-        else sincos_heading<kTame>(th, &sn, &cs);
-        const double ddx = (vx * cs - vy * sn) * p.dt, ddy = (vx * sn + vy * cs) * p.dt;
-        x += ddx; y += ddy;
-        double rt = -2.0 * p.wo_n * (c.tyaw - th);
-        if (i == n - 1) rt += -2.0 * p.wterm_o * (c.fyaw - th);
-        if (lane == 0) {
-          ACS[i] = cs; ASN[i] = sn; ADX[i] = ddx; ADY[i] = ddy;
-          ARX[i] = -2.0 * p.wt_n * (c.cx - x); ARY[i] = -2.0 * p.wt_n * (c.cy - y); ART[i] = rt;
-        }
-      }
-      WAVE_SYNC();
-      double SX = 0.0, SY = 0.0, ST = 0.0;
-#pragma unroll
-      for (int k = n - 1; k >= 0; --k) {
-        SX += ARX[k]; SY += ARY[k];
-        ST += ART[k] - ADY[k] * SX + ADX[k] * SY;
-        if (lane == 0) {
-          gs[3 * k] = p.dt * (ACS[k] * SX + ASN[k] * SY);
-          gs[3 * k + 1] = p.dt * (-ASN[k] * SX + ACS[k] * SY);
-          gs[3 * k + 2] = p.dt * ST;
-        }
-      }
-      WAVE_SYNC();
     }
+    else if (!kSteps) adjoint_by_scans<kTame, kRiccati>(a, c, L, exact_step, lane, n, free_path, nhops);
+    else adjoint_short_sweep<kSteps, kTame>(a, c, L, have_trig, lane, n);
     NEO_PHASE(1);
-    // ---- total gradient (control norm: minimal-norm subgradient at the kink), tangent-cone
-    //      reduction at active bounds; lanes take steps
-    bool my_corner = false;   // a block of this lane slides along one constraint in a corner of the feasible set
-    for (int i = lane; i < n; i += kLanes) {
-      const double u0 = u[3 * i], u1 = u[3 * i + 1], u2 = u[3 * i + 2];
-      const double g0 = gs[3 * i], g1 = gs[3 * i + 1], g2 = gs[3 * i + 2];
-      const double e0 = u0 - c.v0, e1 = u1 - c.v1, e2 = u2 - c.v2;
-      // |e| and 1/|e| from one reciprocal square root (a shorter dependent chain than sqrt, then rcp)
-      const double ne2 = e0 * e0 + e1 * e1 + e2 * e2;
-      const double ine = ne2 > 0.0 ? rsq_fast(ne2) : 0.0;
-      const double ne = ne2 * ine;
-      double t0, t1, t2;
-      if (ne2 > 0.0) {
-        const double wn = p.wc_n * ine;
-        t0 = g0 + wn * e0; t1 = g1 + wn * e1; t2 = g2 + wn * e2;
-      } else {
-        const double ng2 = g0 * g0 + g1 * g1 + g2 * g2;
-        const double sh = (ng2 > p.wc_n * p.wc_n) ? 1.0 - p.wc_n * rsq_fast(ng2) : 0.0;
-        t0 = g0 * sh; t1 = g1 * sh; t2 = g2 * sh;
-      }
-      if (!kRiccati) AMODE[4 * i + 3] = AMODE[4 * i + 2];   // (Riccati: slot 3 is its to-the-kink flag)
-      // next to the kink: prox-only block, outside the quasi-Newton model.  Its SMOOTH gradient is reduced on the tangent
-      // cone below (same code path as every other block's total gradient) and written back to gs: the proximal step of
-      // such a block is taken on its face -- a component that pushes omega into its bound, or the velocity out of the
-      // disc, used to dominate the step's shrink factor and keep the block from landing on the kink (projection and prox
-      // do not commute).
-      const bool near = ne < TOL[T_KINK];
-      if (near) { t0 = g0; t1 = g1; t2 = g2; }
-      else { gt[3 * i] = t0; gt[3 * i + 1] = t1; gt[3 * i + 2] = t2; }
-      const int wfroz = ((u2 <= p.lo[2] && t2 > 0.0) || (u2 >= p.hi[2] && t2 < 0.0)) ? 1 : 0;
-      double r0 = t0, r1 = t1;
-      // outward normals of the constraints active at u: slot 0 = vx bound, 1 = vy bound, 2 = disc
-      // (fixed slots + validity flags: no dynamically indexed private arrays, i.e. no scratch)
-      double nx0 = 0.0, ny0 = 0.0, nx1 = 0.0, ny1 = 0.0, nx2 = 0.0, ny2 = 0.0;
-      bool v0 = false, v1 = false, v2 = false;
-      if (!kTame && !p.disc_in_box) {  // (inside the box a bound can only touch where the disc touches too)
-        if (u0 <= p.lo[0]) { nx0 = -1.0; v0 = true; }
-        else if (u0 >= p.hi[0]) { nx0 = 1.0; v0 = true; }
-        if (u1 <= p.lo[1]) { ny1 = -1.0; v1 = true; }
-        else if (u1 >= p.hi[1]) { ny1 = 1.0; v1 = true; }
-      }
-      const double nvv2 = u0 * u0 + u1 * u1, rlim = p.r * (1.0 - 1e-12);
-      if (nvv2 > 0.0 && nvv2 >= rlim * rlim) { const double iv = rsq_fast(nvv2); nx2 = u0 * iv; ny2 = u1 * iv; v2 = true; }
-      const double dx = -t0, dy = -t1;
-      const double dn0 = nx0 * dx + ny0 * dy, dn1 = nx1 * dx + ny1 * dy, dn2 = nx2 * dx + ny2 * dy;
-      int mode = 0, mslot = -1;
-      double mnx = 0.0, mny = 0.0, mlam = 0.0;
-      if ((v0 && dn0 > 0.0) || (v1 && dn1 > 0.0) || (v2 && dn2 > 0.0)) {
-        // slide along one violated constraint if that keeps the others satisfied; longest slide wins
-        double bestn = -1.0;
-        mode = 2;
-#define NEO_TRY_SLIDE(sk, vk, dnk, nxk, nyk, va, nxa, nya, vb, nxb, nyb)                               \
-        if (vk && dnk > 0.0) {                                                                         \
-          const double px = dx - dnk * nxk, py = dy - dnk * nyk;                                       \
-          const double tol = 1e-14 * (fabs(px) + fabs(py));                                            \
-          const bool ok = !(va && nxa * px + nya * py > tol) && !(vb && nxb * px + nyb * py > tol);    \
-          const double pn = px * px + py * py;                                                         \
-          if (ok && pn > bestn) {                                                                      \
-            bestn = pn; mode = 1; mnx = nxk; mny = nyk; r0 = -px; r1 = -py; mslot = sk; mlam = dnk;     \
-          }                                                                                            \
-        }
-        // (the disc first: where a bound touches the disc with the same normal -- max_vel_x = max_vel_trans, README -- the
-        // slide is the disc's, with its curvature and without the corner stop of a bound slide)
-        NEO_TRY_SLIDE(2, v2, dn2, nx2, ny2, v0, nx0, ny0, v1, nx1, ny1)
-        NEO_TRY_SLIDE(0, v0, dn0, nx0, ny0, v1, nx1, ny1, v2, nx2, ny2)
-        NEO_TRY_SLIDE(1, v1, dn1, nx1, ny1, v0, nx0, ny0, v2, nx2, ny2)
-#undef NEO_TRY_SLIDE
-        if (mode == 2) { r0 = 0.0; r1 = 0.0; }
-      }
-      if (near) {
-        const double s2 = wfroz ? 0.0 : t2;
-        gs[3 * i] = r0; gs[3 * i + 1] = r1; gs[3 * i + 2] = s2;
-        gt[3 * i] = 0.0; gt[3 * i + 1] = 0.0; gt[3 * i + 2] = 0.0;
-        gr[3 * i] = 0.0; gr[3 * i + 1] = 0.0; gr[3 * i + 2] = 0.0;
-        // (2: exactly ON the kink with a REDUCED smooth gradient inside the norm's subdifferential, |g_s| <= w_control/N --
-        // the block stays there under every proximal step: at rest, it does not hold up the Newton stop tests)
-        const int at_rest = (ne2 == 0.0 && r0 * r0 + r1 * r1 + s2 * s2 <= p.wc_n * p.wc_n) ? 2 : 1;
-        ANX[i] = 0.0; ANY[i] = 0.0; AMODE[4 * i] = 0; AMODE[4 * i + 1] = 0; AMODE[4 * i + 2] = at_rest;
-        if (kNewton) {
-#pragma unroll
-          for (int k = 0; k < kNewtonRecord; ++k) NB[kNewtonRecord * i + k] = 0.0f;  // P = 0: row/column of I
-        }
-        if (kRiccati) ARTF[2 * i] = 0.0f;
-        continue;
-      }
-      gr[3 * i] = r0; gr[3 * i + 1] = r1; gr[3 * i + 2] = wfroz ? 0.0 : t2;
-      // (slot 1: omega frozen | 2 x "the slide is along the disc" -- a block sliding along a box bound stops at the corner
-      // where the bound meets the disc, feasible_set.h candidate_block)
-      // (bits 2-4, second-order directions: the OTHER constraint active at a sliding block's position -- the slide is
-      // one-sided there, see repin_corner_blocks: 1 vx bound, 2 vy bound, 3 disc, + 4 for a lower bound)
-      int other = 0;
-      if (kSecond && !kTame && mode == 1) {
-        if (v2 && mslot != 2) other = 3;
-        else if (v0 && mslot != 0) other = 1 | (nx0 < 0.0 ? 4 : 0);
-        else if (v1 && mslot != 1) other = 2 | (ny1 < 0.0 ? 4 : 0);
-        my_corner = my_corner || other != 0;
-      }
-      ANX[i] = mnx; ANY[i] = mny; AMODE[4 * i] = mode; AMODE[4 * i + 1] = wfroz | ((mode == 1 && mslot == 2) ? 2 : 0) | (other << 2); AMODE[4 * i + 2] = 0;
-      if (kNewton) {
-        // Block record of the Newton system, float32: the projector onto the tangent cone's face
-        // (P00 P01 P11 PW) and the block's own curvature C (3x3): the control norm's Hessian
-        // (w/|e|)(I - e e^T/|e|^2) plus lambda/r t t^T of a binding disc, t = (-ny, nx)
-        float* nb = NB + kNewtonRecord * i;
-        nb[0] = mode == 0 ? 1.0f : mode == 1 ? (float)(1.0 - mnx * mnx) : 0.0f;
-        nb[1] = mode == 1 ? (float)(-mnx * mny) : 0.0f;
-        nb[2] = mode == 0 ? 1.0f : mode == 1 ? (float)(1.0 - mny * mny) : 0.0f;
-        nb[3] = wfroz ? 0.0f : 1.0f;
-        const float f0 = (float)e0, f1 = (float)e1, f2 = (float)e2;
-        const float fn2 = f0 * f0 + f1 * f1 + f2 * f2;
-        const float ine = fn2 > 0.0f ? __builtin_amdgcn_rsqf(fn2) : 0.0f;
-        const float sN = (float)p.wc_n * ine, h0 = f0 * ine, h1 = f1 * ine, h2 = f2 * ine;
-        const float k2 = (mode == 1 && mslot == 2) ? (float)(mlam * rcp_fast(p.r)) : 0.0f;
-        const float tx = -(float)mny, ty = (float)mnx;
-        const float c00 = sN * (1.0f - h0 * h0) + k2 * tx * tx, c01 = -sN * h0 * h1 + k2 * tx * ty,
-                    c02 = -sN * h0 * h2, c11 = sN * (1.0f - h1 * h1) + k2 * ty * ty, c12 = -sN * h1 * h2,
-                    c22 = sN * (1.0f - h2 * h2);
-        nb[4] = c00; nb[5] = c01; nb[6] = c02;
-        nb[7] = c01; nb[8] = c11; nb[9] = c12;
-        nb[10] = c02; nb[11] = c12; nb[12] = c22;
-      }
-      // Riccati: curvature lambda/r of a binding disc (the rest of the block's record is made by riccati_prepare)
-      if (kRiccati) ARTF[2 * i] = (mode == 1 && mslot == 2) ? (float)(mlam * rcp_fast(p.r)) : 0.0f;
-    }
+    // ---- total gradient (control norm: minimal-norm subgradient at the kink), tangent-cone reduction at active bounds,
+    //      face records of the second-order directions (tangent_cone.h)
+    const bool my_corner = tangent_cone_pass<kTame, kNewton, kRiccati>(a, c, L, TOL[T_KINK], lane, n);
     WAVE_SYNC();
     // (in free space only -- no costmap term under the iterate's rollout: next to a cost step the Newton model is off either
     // way; the dense kernel knows that sum from the previous iteration's winner)
@@ -671,233 +417,16 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         riccati_finish(a, c, L, n, lane);
       };
       sweep();
-      if (!kTame && corner_any && repin_corner_blocks<true, 0>(a, L, n, lane)) {   // (one-sided slides: once more, those blocks pinned)
+      if (!kTame && corner_any && repin_corner_blocks<true>(a, L, n, lane)) {   // (one-sided slides: once more, those blocks pinned)
         riccati_keep_linear_terms(a, L, n, lane, false);
         sweep();
       }
     } else if (kNewton) {
-      // From here on the Newton system lives in float32: it only yields a search direction (the arc
-      // search and the float64 objective decide), and single precision halves registers, readlanes
-      // and VALU time of this section.
-      float* Hm = reinterpret_cast<float*>(L + a.lds.hess);
-      // this lane's own block (lane = variable index 3 * kb + kq) and that block's record
-      const int kv = lane < nvr ? lane : 0, kb = (kv * 11) >> 5, kq = kv - 3 * kb;   // kv / 3 for kv < 32
-      const int hs = nvr;  // row stride of the system in LDS
-      const float* own = NB + kNewtonRecord * kb;
-      // (a block sliding in a corner of the feasible set: the finite-difference columns are kept -- behind the system,
-      // in the float64-sized half of its LDS slot -- in case the system has to be solved once more with that block pinned)
-      float* Hraw = Hm + hs * hs;
-      if (!kTame && corner_any && lane < nvr) {
-#pragma unroll
-        for (int j = 0; j < kVars; ++j)
-          if (kSteps || j < nvr) Hraw[j * hs + lane] = hc[j];
-      }
-      auto solve_on_the_face = [&]() {
-      // ---- lane k < 3N holds Hessian column k: add column kq of its block's curvature, apply P on
-      //      the row index, store the column
-      {
-        const float cn0 = own[4 + kq], cn1 = own[7 + kq], cn2 = own[10 + kq];  // (C is symmetric)
-#pragma unroll
-        for (int bk = 0; bk < kNwSteps; ++bk) {
-          if (kSteps || bk < n) {
-            const float* nb = NB + kNewtonRecord * bk;
-            const bool mine = lane < nvr && kb == bk;
-            const float hx = hc[3 * bk] + (mine ? cn0 : 0.0f), hy = hc[3 * bk + 1] + (mine ? cn1 : 0.0f);
-            hc[3 * bk] = nb[0] * hx + nb[1] * hy;
-            hc[3 * bk + 1] = nb[1] * hx + nb[2] * hy;
-            hc[3 * bk + 2] = (hc[3 * bk + 2] + (mine ? cn2 : 0.0f)) * nb[3];
-          }
-        }
-      }
-      if (lane < nvr) {
-#pragma unroll
-        for (int j = 0; j < kVars; ++j)
-          if (kSteps || j < nvr) Hm[j * hs + lane] = hc[j];
-      }
-      WAVE_SYNC();
-      // ---- lane j < 3N holds row j: apply P on the column index, add I - P, eliminate
-      float rhsf = 0.0f, diag = 0.0f;
-#pragma unroll
-      for (int q = 0; q < kVars; ++q) hc[q] = (lane < nvr && (kSteps || q < nvr)) ? Hm[lane * hs + q] : 0.0f;
-      if (lane < nvr) rhsf = -(float)gr[lane];
-      {
-        // row kq of I - P of this lane's block
-        const float p00 = own[0], p01 = own[1], p11 = own[2], pw = own[3];
-        const float a0 = kq == 0 ? 1.0f - p00 : kq == 1 ? -p01 : 0.0f;
-        const float a1 = kq == 0 ? -p01 : kq == 1 ? 1.0f - p11 : 0.0f;
-        const float a2 = kq == 2 ? 1.0f - pw : 0.0f;
-#pragma unroll
-        for (int bk = 0; bk < kNwSteps; ++bk) {
-          if (kSteps || bk < n) {
-            const float* nb = NB + kNewtonRecord * bk;
-            const bool mine = lane < nvr && kb == bk;
-            const float hx = hc[3 * bk], hy = hc[3 * bk + 1];
-            hc[3 * bk] = hx * nb[0] + hy * nb[1] + (mine ? a0 : 0.0f);
-            hc[3 * bk + 1] = hx * nb[1] + hy * nb[2] + (mine ? a1 : 0.0f);
-            hc[3 * bk + 2] = hc[3 * bk + 2] * nb[3] + (mine ? a2 : 0.0f);
-            if (mine) diag = kq == 0 ? hc[3 * bk] : kq == 1 ? hc[3 * bk + 1] : hc[3 * bk + 2];
-          }
-        }
-      }
-      const float deltaf = fmaxf(1e-6f * wave_max_f(fabsf(diag)), 1e-30f);
-      auto lane_f = [](float v, int src) {
-        return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
-      };
-      float own_pinv = 0.0f;  // lane pv keeps the reciprocal of its own pivot
-#pragma unroll
-      for (int pv = 0; pv < kVars; ++pv) {  // Gaussian elimination, rows in registers, pivot row by readlane
-        if (kSteps || pv < nvr) {
-          float piv = lane_f(hc[pv], pv);
-          if (!(piv > deltaf)) piv = fmaxf(fabsf(piv), deltaf);
-          const float pinv = __builtin_amdgcn_rcpf(piv);
-          if (lane == pv) own_pinv = pinv;
-          const float fac = (lane > pv && lane < nvr) ? hc[pv] * pinv : 0.0f;
-          if (kSteps) {
-#pragma unroll
-            for (int q = pv + 1; q < kVars; ++q) hc[q] -= fac * lane_f(hc[q], pv);
-          } else {
-#pragma unroll
-            for (int qb = pv / 3; qb < kNwSteps; ++qb) {   // (whole blocks of three columns at a time)
-              if (qb < n) {
-#pragma unroll
-                for (int q = 3 * qb; q < 3 * qb + 3; ++q)
-                  if (q > pv) hc[q] -= fac * lane_f(hc[q], pv);
-              }
-            }
-          }
-          rhsf -= fac * lane_f(rhsf, pv);
-        }
-      }
-      // back substitution, column by column: x_pv leaves lane pv and every row above takes its
-      // share off its right-hand side (one readlane + one fma per unknown)
-      float sol = 0.0f;
-#pragma unroll
-      for (int pv = kVars - 1; pv >= 0; --pv) {
-        if (kSteps || pv < nvr) {
-          const float x = lane_f(rhsf * own_pinv, pv);
-          if (lane == pv) sol = x;
-          rhsf -= hc[pv] * x;
-        }
-      }
-      if (lane < nvr) d[lane] = (double)sol;
-      newton_sol = sol;
-      WAVE_SYNC();
-      };
-      auto columns_again = [&]() {
-        if (lane < nvr) {
-#pragma unroll
-          for (int j = 0; j < kVars; ++j)
-            if (kSteps || j < nvr) hc[j] = Hraw[j * hs + lane];
-        }
-      };
-      // one-sided slides (repin_corner_blocks): once more with those blocks pinned.  control_steps specialisations: a second
-      // copy of the solve behind a branch, so that the first keeps its straight-line code (as a loop the general
-      // control_steps-3 kernel lost a quarter of its rate); the run-time-sized kernel: one copy in a two-trip loop
-      if constexpr (kSteps != 0) {
-        solve_on_the_face();
-        if (!kTame && corner_any && repin_corner_blocks<false, kNewtonRecord>(a, L, n, lane)) { columns_again(); solve_on_the_face(); }
-      } else {
-        for (int pass = 0;; ++pass) {
-          solve_on_the_face();
-          if (kTame || pass == 1 || !corner_any || !repin_corner_blocks<false, kNewtonRecord>(a, L, n, lane)) break;
-          columns_again();
-        }
-      }
+      newton_sol = dense_newton_direction<kSteps, kNwSteps, kTame>(a, L, hc, corner_any, lane, n, nvr);   // (dense_newton.h)
     }
     NEO_PHASE(3);
-    // ---- new curvature pair
-    if (!kSecond && it > 0) {
-      double* s = Sm + head * nv;
-      double* yv = Ym + head * nv;
-      double sy = 0.0, ss = 0.0, yy = 0.0;
-      for (int k = lane; k < nv; k += kLanes) {
-        const int blk = k / 3;
-        const bool skip = (AMODE[4 * blk + 2] | AMODE[4 * blk + 3]) != 0;
-        const double sk = skip ? 0.0 : u[k] - u_prev[k], yk = skip ? 0.0 : gt[k] - gt_prev[k];
-        s[k] = sk; yv[k] = yk;
-        sy += sk * yk; ss += sk * sk; yy += yk * yk;
-      }
-      sy = wave_sum(sy); ss = wave_sum(ss); yy = wave_sum(yy);
-      const int ok = uniform_int((ss > 0.0 && sy > 1e-10 * sqrt_fast(ss * yy)) ? 1 : 0);
-      if (ok) {
-        if (lane == 0) rho[head] = rcp_fast(sy);
-        head = (head + 1) % mem;
-        if (npairs < mem) ++npairs;
-      }
-      WAVE_SYNC();
-    }
-    // ---- L-BFGS two-loop recursion on the reduced gradient; lanes take vector elements.
-    //      Pair slots are walked with compile-time indices so the alphas stay in registers.
-    if (!kSecond) {
-      constexpr bool kWide = (kSteps == 0) || (3 * kSteps > 64);  // more than 64 variables
-      double al[kPairs];
-      double q0 = lane < nv ? gr[lane] : 0.0;
-      double q1 = (kWide && lane + 64 < nv) ? gr[lane + 64] : 0.0;
-      double q2 = (kWide && lane + 128 < nv) ? gr[lane + 128] : 0.0;
-#pragma unroll
-      for (int j = 0; j < kPairs; ++j) {
-        if (j < npairs) {
-          const int idx = (head - 1 - j + 2 * mem) % mem;
-          const double* s = Sm + idx * nv;
-          const double* yv = Ym + idx * nv;
-          double part = 0.0;
-          if (lane < nv) part += s[lane] * q0;
-          if (kWide && lane + 64 < nv) part += s[lane + 64] * q1;
-          if (kWide && lane + 128 < nv) part += s[lane + 128] * q2;
-          al[j] = rho[idx] * wave_sum(part);
-          if (lane < nv) q0 -= al[j] * yv[lane];
-          if (kWide && lane + 64 < nv) q1 -= al[j] * yv[lane + 64];
-          if (kWide && lane + 128 < nv) q2 -= al[j] * yv[lane + 128];
-        }
-      }
-      if (npairs > 0) {
-        const int idx = (head - 1 + mem) % mem;
-        const double* yv = Ym + idx * nv;
-        double part = 0.0;
-        if (lane < nv) part += yv[lane] * yv[lane];
-        if (kWide && lane + 64 < nv) part += yv[lane + 64] * yv[lane + 64];
-        if (kWide && lane + 128 < nv) part += yv[lane + 128] * yv[lane + 128];
-        const double gamma = rcp_fast(rho[idx] * wave_sum(part));
-        q0 *= gamma; q1 *= gamma; q2 *= gamma;
-      }
-#pragma unroll
-      for (int j = kPairs - 1; j >= 0; --j) {
-        if (j < npairs) {
-          const int idx = (head - 1 - j + 2 * mem) % mem;
-          const double* s = Sm + idx * nv;
-          const double* yv = Ym + idx * nv;
-          double part = 0.0;
-          if (lane < nv) part += yv[lane] * q0;
-          if (kWide && lane + 64 < nv) part += yv[lane + 64] * q1;
-          if (kWide && lane + 128 < nv) part += yv[lane + 128] * q2;
-          const double be = rho[idx] * wave_sum(part);
-          if (lane < nv) q0 += s[lane] * (al[j] - be);
-          if (kWide && lane + 64 < nv) q1 += s[lane + 64] * (al[j] - be);
-          if (kWide && lane + 128 < nv) q2 += s[lane + 128] * (al[j] - be);
-        }
-      }
-      if (lane < nv) d[lane] = -q0;
-      if (lane + 64 < nv) d[lane + 64] = -q1;
-      if (lane + 128 < nv) d[lane + 128] = -q2;
-      WAVE_SYNC();
-    }
-    if (!kSecond) {
-      // (the Newton system is built on the face: H_r = P H P + (I - P) with a right-hand side inside
-      // it, so its solution needs no restriction -- what rounding leaves outside is removed by the
-      // projection of every candidate)
-      for (int i = lane; i < n; i += kLanes) {  // restrict the direction to the tangent cone's face
-        if (AMODE[4 * i + 2]) { d[3 * i] = 0.0; d[3 * i + 1] = 0.0; d[3 * i + 2] = 0.0; continue; }
-        if (AMODE[4 * i + 1] & 1) d[3 * i + 2] = 0.0;
-        const int mode = AMODE[4 * i];
-        if (mode == 1) {
-          const double dot = d[3 * i] * ANX[i] + d[3 * i + 1] * ANY[i];
-          d[3 * i] -= dot * ANX[i]; d[3 * i + 1] -= dot * ANY[i];
-        } else if (mode == 2) {
-          d[3 * i] = 0.0; d[3 * i + 1] = 0.0;
-        }
-      }
-      WAVE_SYNC();
-    }
+    // ---- projected L-BFGS: newest curvature pair, two-loop recursion on the reduced gradient, restriction to the face
+    if (!kSecond) lbfgs_direction<kSteps, kPairs>(a, L, it, mem, head, npairs, lane, n);   // (lbfgs.h)
     if (kSecond && it > 0) {
       // the full Newton step is already below the step tolerance: u is the answer (blocks next to
       // the kink are moved by the prox step, which d does not describe -- keep iterating then)
@@ -1109,71 +638,10 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     if ((double)stepmax < TOL[T_XTOL] || stall >= kStallIterations || creeping || final_step || blocked_stop) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
   }
 
-  // ---- Dense direction: a search that has ENDED looks once for a cheaper costmap cell a hop away -- the hop candidates
-  // the stage-wise direction tries in every iteration (costmap.h edge_stickiness).  A search that closed in on a cell edge
-  // from the expensive side ends a millimetre short of a cost step no descent direction sees (held-out parameter set "a",
-  // w_costmap / w_trans = 0.08: one such step is worth 2e-3, P3 failed on 1 of 24 cases).  A hop that lowers the objective is
-  // taken; the search is not taken up again (measured on the mirror: restarting it gains 7e-6 per instance on average
-  // and lengthens the slowest searches of a launch by two iterations).  Skipped when no stage of the iterate has a costmap
-  // term under it: nothing is cheaper next door.
-  if (kNewton && status == NEO_MPC_STATUS_CONVERGED && u_term != 0.0 && !(c.tile_geom & kTileFree) && p.max_it < kDumpGradient) {
-    bool has_hop = false;
-    float hop_x = 0.0f, hop_y = 0.0f;
-    {
-      // lane i < n: position and heading of stage i at u
-      double x = 0.0, y = 0.0, th = 0.0, cs = 1.0, sn = 0.0;
-#pragma unroll
-      for (int k = 0; k < (kNewton ? (kSteps ? kSteps : kNewtonMaxSteps) : 1); ++k) {
-        if ((kSteps || k < n) && k <= lane) {
-          th += u[3 * k + 2] * p.dt;
-          sincos_heading<kTame>(th, &sn, &cs);
-          x += (u[3 * k] * cs - u[3 * k + 1] * sn) * p.dt;
-          y += (u[3 * k] * sn + u[3 * k + 1] * cs) * p.dt;
-        }
-      }
-      if (lane < n) {
-        double wxx, wxy, wyy, wlx, wly;
-        (void)edge_stickiness(a, c, L, x, y, cs, sn, wxx, wxy, wyy, wlx, wly, has_hop, hop_x, hop_y);
-      }
-    }
-    const unsigned long long hmask = __ballot(has_hop);
-    if (hmask != 0ull) {   // (wave-uniform)
-      const int rank = __popcll(hmask & ((1ull << lane) - 1ull));
-      double* t = L + a.lds.tol;
-      if (has_hop && rank < kHopLanes) {
-        reinterpret_cast<int*>(t + T_HOP_STAGE)[rank] = lane;
-        reinterpret_cast<float*>(t + T_HOP_VEC)[2 * rank] = hop_x;
-        reinterpret_cast<float*>(t + T_HOP_VEC)[2 * rank + 1] = hop_y;
-      }
-      const int nh = min(__popcll(hmask), (int)kHopLanes);
-      WAVE_SYNC();
-      // lane h < nh: the current point with the block of hop stage h changed
-      int hs = -1;
-      float hx = 0.0f, hy = 0.0f;
-      if (lane < nh) {
-        hs = reinterpret_cast<const int*>(t + T_HOP_STAGE)[lane];
-        hx = reinterpret_cast<const float*>(t + T_HOP_VEC)[2 * lane];
-        hy = reinterpret_cast<const float*>(t + T_HOP_VEC)[2 * lane + 1];
-      }
-      double hb0 = 0.0, hb1 = 0.0;
-      double fh = rollout_cost<kSteps, kTame>(
-          a, c, L,
-          [&](int i, double& b0, double& b1, double& b2) {
-            b0 = u[3 * i]; b1 = u[3 * i + 1]; b2 = u[3 * i + 2];
-            if (i == hs) { b0 += (double)hx; b1 += (double)hy; project_block<kTame>(p, b0, b1, b2); hb0 = b0; hb1 = b1; }
-          });
-      if (!(fh == fh) || lane >= nh) fh = INFINITY;
-      int hbest = lane;
-      wave_argmin(fh, hbest);
-      ++nfev;
-      WAVE_SYNC();
-      if (fh < f) {
-        if (lane == hbest) { u[3 * hs] = hb0; u[3 * hs + 1] = hb1; }
-        f = fh;
-        WAVE_SYNC();
-      }
-    }
-  }
+  // ---- dense direction: a search that has ENDED looks once for a cheaper costmap cell a hop away (exit_hop.h); skipped
+  //      when no stage of the iterate has a costmap term under it
+  if (kNewton && status == NEO_MPC_STATUS_CONVERGED && u_term != 0.0 && !(c.tile_geom & kTileFree) && p.max_it < kDumpGradient)
+    exit_hop<kSteps, kNwSteps, kTame>(a, c, L, f, nfev, lane, n);
 
   NEO_SEGMENT(1);
 #ifndef NEO_MPC_PHASE_TIMING
