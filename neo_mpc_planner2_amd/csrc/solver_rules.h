@@ -19,6 +19,7 @@
 #define NEO_RULE_BLOCKED_TOL_MAP 0.1    /* ... which fires when they gained less than this x opt_tolerance together (costmap term under the rollout) */
 #define NEO_RULE_BLOCKED_TOL_FREE 0.03  /* ... (no costmap term under the rollout) */
 #define NEO_RULE_LATE_ITERATION 20      /* from here on the three-iteration window is the control_steps-3 one */
+#define NEO_RULE_CORNER_ROOM 1e-9        /* second-order directions: a sliding block this close (m/s) to ANOTHER constraint sits in a corner of the feasible set (repin_corner_blocks) */
 #define NEO_RULE_CLOSING_RUN 2           /* dense / L-BFGS: blocked iterations in a row before the closing-in rule may end the search */
 #define NEO_RULE_WINDOW_STEP 0.5        /* stage-wise direction: an iteration won by a Newton step of at least this length is not "blocked" */
 #define NEO_RULE_FINAL_FRAC_GN 0.3      /* a Gauss-Newton (not exact) full step has to be this much shorter than opt_tolerance to be the last */

@@ -8,11 +8,12 @@
 // curvature for the stage-wise sweep.  Blocks within kink_radius of the kink u_i = v_cur are "near": moved by the
 // proximal step only, their SMOOTH gradient reduced on the cone and written back to gs.
 // LDS in: u, gs.  LDS out: gt, gr, (gs of near blocks), nx, ny, mode[4 i .. 4 i + 2], Newton records / disc curvature.
-// Returns whether a block of this lane slides in a CORNER of the feasible set (k_solve: repin_corner_blocks).
+// Returns whether a block of this lane slides along a constraint of a feasible set that has corners (repin_corner_blocks).
 #pragma once
 #include "neo_mpc_device.h"
 #include "fast_math.h"
 #include "solver_context.h"
+#include "solver_rules.h"
 #include "riccati.h"
 
 namespace neo_mpc {
@@ -119,16 +120,14 @@ __device__ __forceinline__ bool tangent_cone_pass(const SolveArgs& a, const Ctx&
     gr[3 * i] = r0; gr[3 * i + 1] = r1; gr[3 * i + 2] = wfroz ? 0.0 : t2;
     // (slot 1: omega frozen | 2 x "the slide is along the disc" -- a block sliding along a box bound stops at the corner
     // where the bound meets the disc, feasible_set.h candidate_block)
-    // (bits 2-4, second-order directions: the OTHER constraint active at a sliding block's position -- the slide is
-    // one-sided there, see repin_corner_blocks: 1 vx bound, 2 vy bound, 3 disc, + 4 for a lower bound)
-    int other = 0;
-    if (kSecond && !kTame && mode == 1) {
-      if (v2 && mslot != 2) other = 3;
-      else if (v0 && mslot != 0) other = 1 | (nx0 < 0.0 ? 4 : 0);
-      else if (v1 && mslot != 1) other = 2 | (ny1 < 0.0 ? 4 : 0);
-      my_corner = my_corner || other != 0;
+    // (second-order directions, box cutting the disc: a sliding block with no room left towards ANOTHER constraint sits in
+    // a corner of the feasible set -- repin_corner_blocks looks at where the direction sends it)
+    if (kSecond && !kTame && !p.disc_in_box && mode == 1) {
+      const double room = NEO_RULE_CORNER_ROOM, rin = p.r - room;
+      my_corner = my_corner || (mslot != 0 && (u0 - p.lo[0] <= room || p.hi[0] - u0 <= room)) ||
+                  (mslot != 1 && (u1 - p.lo[1] <= room || p.hi[1] - u1 <= room)) || (mslot != 2 && nvv2 >= rin * rin);
     }
-    ANX[i] = mnx; ANY[i] = mny; AMODE[4 * i] = mode; AMODE[4 * i + 1] = wfroz | ((mode == 1 && mslot == 2) ? 2 : 0) | (other << 2); AMODE[4 * i + 2] = 0;
+    ANX[i] = mnx; ANY[i] = mny; AMODE[4 * i] = mode; AMODE[4 * i + 1] = wfroz | ((mode == 1 && mslot == 2) ? 2 : 0); AMODE[4 * i + 2] = 0;
     if (kNewton) {
       // Block record of the Newton system, float32: the projector onto the tangent cone's face
       // (P00 P01 P11 PW) and the block's own curvature C (3x3): the control norm's Hessian
@@ -170,15 +169,24 @@ __device__ __forceinline__ bool repin_corner_blocks(const SolveArgs& a, double* 
   const double* d = L + a.lds.d;
   const double* u = L + a.lds.u;
   double* gr = L + a.lds.gr;
+  const DevParams& p = a.p;
   bool any = false;
   for (int i = lane; i < n; i += kLanes) {
     int* am = AMODE + 4 * i;
-    const int other = (am[1] >> 2) & 7;
-    if (am[0] != 1 || other == 0 || (kRiccati && am[3])) continue;
-    const double d0 = d[3 * i], d1 = d[3 * i + 1];
-    const int kind = other & 3;
-    const double outward = kind == 3 ? d0 * u[3 * i] + d1 * u[3 * i + 1] : (kind == 1 ? d0 : d1) * ((other & 4) ? -1.0 : 1.0);
-    if (!(outward > 0.0)) continue;
+    if (am[0] != 1 || (kRiccati && am[3])) continue;
+    // the OTHER constraints of the block (it slides along the disc, or along the vx or the vy bound): does the step approach
+    // one of them with no room left (NEO_RULE_CORNER_ROOM: the projection's rounding leaves a block 1e-16 inside a bound
+    // it sat on)?
+    const double u0 = u[3 * i], u1 = u[3 * i + 1], d0 = d[3 * i], d1 = d[3 * i + 1];
+    const bool on_disc = (am[1] & 2) != 0, on_x = !on_disc && L[a.lds.nx + i] != 0.0, on_y = !on_disc && !on_x;
+    bool blocked = false;
+    if (!on_x) blocked = blocked || (d0 != 0.0 && (d0 > 0.0 ? p.hi[0] - u0 : u0 - p.lo[0]) <= NEO_RULE_CORNER_ROOM);
+    if (!on_y) blocked = blocked || (d1 != 0.0 && (d1 > 0.0 ? p.hi[1] - u1 : u1 - p.lo[1]) <= NEO_RULE_CORNER_ROOM);
+    if (!on_disc) {
+      const double rin = p.r - NEO_RULE_CORNER_ROOM;
+      blocked = blocked || (d0 * u0 + d1 * u1 > 0.0 && u0 * u0 + u1 * u1 >= rin * rin);
+    }
+    if (!blocked) continue;
     any = true;
     am[0] = 2; gr[3 * i] = 0.0; gr[3 * i + 1] = 0.0;
     if (kRiccati) {

@@ -383,8 +383,6 @@ typedef struct orc_active {
   int riccati;              /* the Riccati kernel's candidate rules apply (per-block prox step) */
   int longshots;            /* lanes 61-63 are step lengths 8, 16, 32 (Newton directions) */
   uint8_t rest[ORC_MAXN];   /* near block exactly on the kink whose smooth gradient keeps it there */
-  uint8_t corner[ORC_MAXN]; /* mode 1 with a SECOND constraint active at u_i (outward normal n2): the slide is one-sided */
-  double n2x[ORC_MAXN], n2y[ORC_MAXN];
 } orc_active;
 
 
@@ -393,11 +391,8 @@ typedef struct orc_active {
  * Out: the reduced gradient gr[3] and the face (wfroz, mode 0/1/2, outward normal, disc flag, multiplier). */
 static int orc_near_reduced = 1;
 void orc_set_near_reduced(int m) { orc_near_reduced = m; }
-static _Thread_local double orc_tangent_n2[2];
-static _Thread_local int orc_tangent_corner;
 static void orc_tangent(const orc_ctx* c, const double* ui, const double* gi, double* gr, uint8_t* wfroz, uint8_t* mode,
                         double* nxo, double* nyo, uint8_t* disc, double* lambda) {
-  orc_tangent_corner = 0;
   gr[0] = gi[0]; gr[1] = gi[1]; gr[2] = gi[2];
   /* omega: plain bound */
   *wfroz = (ui[2] <= c->lo[2] && gi[2] > 0.0) || (ui[2] >= c->hi[2] && gi[2] < 0.0);
@@ -435,7 +430,6 @@ static void orc_tangent(const orc_ctx* c, const double* ui, const double* gi, do
       double dn = nx[bestk] * dx + ny[bestk] * dy;
       *mode = 1; *nxo = nx[bestk]; *nyo = ny[bestk];
       *disc = (uint8_t)isdisc[bestk]; *lambda = dn;
-      for (int j = 0; j < na; ++j) if (j != bestk && !orc_tangent_corner) { orc_tangent_corner = 1; orc_tangent_n2[0] = nx[j]; orc_tangent_n2[1] = ny[j]; }
       gr[0] = -(dx - dn * nx[bestk]);
       gr[1] = -(dy - dn * ny[bestk]);
     } else {
@@ -471,7 +465,6 @@ static void orc_reduce(const orc_ctx* c, const double* u, double* gs, double* gt
       a->rest[i] = ne == 0.0 && gsi[0] * gsi[0] + gsi[1] * gsi[1] + gsi[2] * gsi[2] <= c->wc_n * c->wc_n;
       for (int k = 0; k < 3; ++k) { gt[3 * i + k] = 0.0; gr[3 * i + k] = 0.0; }
       a->wfroz[i] = 0; a->mode[i] = 0; a->nx[i] = 0.0; a->ny[i] = 0.0; a->disc[i] = 0; a->lambda[i] = 0.0;
-      a->corner[i] = 0;
       continue;
     }
     a->rest[i] = 0;
@@ -485,7 +478,6 @@ static void orc_reduce(const orc_ctx* c, const double* u, double* gs, double* gt
     }
     for (int k = 0; k < 3; ++k) gt[3 * i + k] = gi[k];
     orc_tangent(c, ui, gi, gr + 3 * i, &a->wfroz[i], &a->mode[i], &a->nx[i], &a->ny[i], &a->disc[i], &a->lambda[i]);
-    a->corner[i] = (uint8_t)orc_tangent_corner; a->n2x[i] = orc_tangent_n2[0]; a->n2y[i] = orc_tangent_n2[1];
   }
 }
 
@@ -1324,6 +1316,7 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
       else orc_newton_direction(&c, u, gs, gr, &act, d);
       orc_apply_active(&c, &act, d);
       if (orc_repin && (riccati || orc_repin == 1) && !(it == 0 && cold) &&
+          !(c.lo[0] <= -c.r && c.hi[0] >= c.r && c.lo[1] <= -c.r && c.hi[1] >= c.r) &&   /* (the box cuts the disc: there are corners) */
           (orc_repin == 3 || (riccati ? orc_free_path(&c, u) : (it > 0 && orc_term_sum(&c, u) == 0.0)))) {
         /* (round 4) one-sided slides: a block in a corner of the feasible set (two constraints active) that slides along
          * one of them can only slide AWAY from the other -- a Newton step that sends it the other way is stopped by the
@@ -1332,11 +1325,31 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
          * under the iterate's rollout): next to a cost step the Newton model is off either way and what finds the way on is
          * the spread of the candidates -- pinning changed which basin one recorded episode of the reference ended in. */
         int redo = 0;
-        for (int i = 0; i < n; ++i)
-          if (act.mode[i] == 1 && act.corner[i] && !act.tokink[i] && d[3 * i] * act.n2x[i] + d[3 * i + 1] * act.n2y[i] > 0.0) {
-            if (orc_trace) fprintf(stderr, "      repin block %d: d %.3e %.3e n2 %.3f %.3f\n", i, d[3 * i], d[3 * i + 1], act.n2x[i], act.n2y[i]);
+        for (int i = 0; i < n; ++i) {
+          if (act.mode[i] != 1 || act.near[i] || act.tokink[i]) continue;
+          /* the OTHER constraints of the block (it slides along the disc, or along the vx or the vy bound): does the step
+           * approach one of them with no room left (NEO_RULE_CORNER_ROOM: the projection's rounding leaves a block 1e-16
+           * inside a bound it sat on)? */
+          const double u0 = u[3 * i], u1 = u[3 * i + 1], d0 = d[3 * i], d1 = d[3 * i + 1];
+          const int on_x = !act.disc[i] && act.nx[i] != 0.0, on_y = !act.disc[i] && act.nx[i] == 0.0;
+          int blocked = 0;
+          if (!on_x) {
+            const double rate = fabs(d0), room = d0 > 0.0 ? c.hi[0] - u0 : u0 - c.lo[0];
+            blocked |= rate > 0.0 && room <= NEO_RULE_CORNER_ROOM;
+          }
+          if (!on_y) {
+            const double rate = fabs(d1), room = d1 > 0.0 ? c.hi[1] - u1 : u1 - c.lo[1];
+            blocked |= rate > 0.0 && room <= NEO_RULE_CORNER_ROOM;
+          }
+          if (!act.disc[i]) {
+            const double rin = c.r - NEO_RULE_CORNER_ROOM;
+            blocked |= d0 * u0 + d1 * u1 > 0.0 && u0 * u0 + u1 * u1 >= rin * rin;
+          }
+          if (blocked) {
+            if (orc_trace) fprintf(stderr, "      repin block %d: d %.3e %.3e\n", i, d0, d1);
             act.mode[i] = 2; gr[3 * i] = 0.0; gr[3 * i + 1] = 0.0; redo = 1;
           }
+        }
         if (redo) {
           ++orc_repin_count;
           if (riccati && orc_disp) { orc_mu = mu; orc_riccati_direction_disp_tau(&c, u, gs, gt, &act, d, exact_step ? 1.0 : 0.0); orc_mu = 0.0; }
