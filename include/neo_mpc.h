@@ -45,7 +45,9 @@ extern "C" {
  *      u-dependent part of the objective; blocks next to the control norm's kink take their proximal step on their face
  *      and sit every other Newton candidate out; a block sliding along a box bound stops at the disc corner; the dense
  *      direction tries a hop to a cheaper costmap cell where its search is about to end; state records are written back
- *      field by field (old_goal only when it changed).
+ *      field by field (old_goal only when it changed).  Blocks in a corner of the feasible set that a Newton step sends
+ *      outward are pinned and the direction is computed once more; the closing-in stop rule of the dense / L-BFGS
+ *      directions waits for two blocked iterations; a step below opt_tolerance ends the search only if it won its iteration.
  * method = NEO_MPC_METHOD_NEWTON / _LBFGS / _RICCATI pins a direction. */
 #define NEO_MPC_BEHAVIOUR_VERSION 4
 
