@@ -98,7 +98,9 @@ __device__ __forceinline__ float dense_newton_direction(const SolveArgs& a, doub
       if (!(piv > deltaf)) piv = fmaxf(fabsf(piv), deltaf);
       const float pinv = __builtin_amdgcn_rcpf(piv);
       if (lane == pv) own_pinv = pinv;
-      const float fac = (lane > pv && lane < nvr) ? hc[pv] * pinv : 0.0f;
+      // (control_steps specialisations: Gauss-Jordan -- the rows ABOVE the pivot are reduced too, the same instructions in
+      // lockstep, and the back substitution with its 3N dependent lane reads falls away)
+      const float fac = ((kSteps ? lane != pv : lane > pv) && lane < nvr) ? hc[pv] * pinv : 0.0f;
       if (kSteps) {
 #pragma unroll
         for (int q = pv + 1; q < kVars; ++q) hc[q] -= fac * lane_f(hc[q], pv);
@@ -118,12 +120,15 @@ __device__ __forceinline__ float dense_newton_direction(const SolveArgs& a, doub
   // back substitution, column by column: x_pv leaves lane pv and every row above takes its
   // share off its right-hand side (one readlane + one fma per unknown)
   float sol = 0.0f;
+  if (kSteps) sol = rhsf * own_pinv;   // (own_pinv is 0 in the lanes that hold no row)
+  else {
 #pragma unroll
-  for (int pv = kVars - 1; pv >= 0; --pv) {
-    if (kSteps || pv < nvr) {
-      const float x = lane_f(rhsf * own_pinv, pv);
-      if (lane == pv) sol = x;
-      rhsf -= hc[pv] * x;
+    for (int pv = kVars - 1; pv >= 0; --pv) {
+      if (pv < nvr) {
+        const float x = lane_f(rhsf * own_pinv, pv);
+        if (lane == pv) sol = x;
+        rhsf -= hc[pv] * x;
+      }
     }
   }
   if (lane < nvr) d[lane] = (double)sol;
