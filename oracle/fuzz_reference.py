@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Random parameter sets against the REFERENCE ITSELF (development container only: imports /root/reference under the ROS
+stand-ins, like gen_golden.py).  For every seed a parameter set is drawn (weights, limits with the box cutting the disc or
+not, horizon, control_steps 3..10, opt_tolerance), 24 cold problems are solved by the reference's SLSQP as shipped and run
+to the end (gen_golden._g3_group: every other case on an all-free map), and the CPU mirror of the build's search is held
+to G10's gates: P3 on every case, P2 on the all-free-map cases the reference converged on -- where SLSQP's "converged"
+objective is above the build's, the distance is the reference's error and is reported apart.
+Test infrastructure: nothing here is shipped.   usage: fuzz_reference.py <first seed> <last seed + 1>"""
+import contextlib
+import io
+import multiprocessing as mp
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def draw(seed):
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([3, 3, 4, 5, 6, 8, 10]))
+    vmax = rng.uniform(0.3, 1.2)
+    lim = dict(max_vel_x=vmax * rng.uniform(0.5, 1.1), min_vel_x=-vmax * rng.uniform(0.1, 1.1),
+               max_vel_y=vmax * rng.uniform(0.2, 1.1), max_vel_trans=vmax, max_vel_theta=rng.uniform(0.4, 1.6))
+    lim["min_vel_y"] = -lim["max_vel_y"]
+    lim["min_vel_theta"] = -lim["max_vel_theta"] * rng.uniform(0.5, 1.0)
+    wt = rng.uniform(0.2, 2.0)
+    w = dict(w_trans=wt, w_orient=rng.uniform(0.1, 1.5), w_control=10 ** rng.uniform(-2, -0.2), w_terminal=10 ** rng.uniform(-2, 0),
+             w_costmap=wt * rng.uniform(0.01, 0.24), prediction_horizon=rng.uniform(0.4, 1.6),
+             opt_tolerance=float(rng.choice([1e-3, 1e-3, 1e-4])))
+    return n, {k: float(v) for k, v in {**lim, **w}.items()}
+
+
+def work(seed):
+    from oracle import gen_golden, ros_stubs
+    mod = ros_stubs.load_reference()
+    n, over = draw(seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        grp = gen_golden._g3_group(mod, n, 24, 20000 + seed, over, map_size=300, map_seed=500 + seed)
+    return seed, n, over, grp
+
+
+if __name__ == "__main__":
+    import util
+    from neo_mpc_planner2_amd import synthetic
+    from oracle import c_oracle, gen_golden
+    seeds = list(range(int(sys.argv[1]), int(sys.argv[2])))
+    with mp.Pool(max(1, (os.cpu_count() or 2) - 1)) as pool:
+        results = pool.map(work, seeds)
+    cases = {"free": 0, "map": 0}
+    p3_miss = {"free": 0, "map": 0}
+    ref_worse = {"free": 0, "map": 0}
+    p2_miss = p2_cases = ref_short = 0
+    for seed, n, over, grp in results:
+        params = util.params_from(np.array(gen_golden.PARAM_KEYS), grp["params"])
+        probs = util.problems_from(grp["problems"])
+        hm = grp["has_map"].astype(bool)
+        line, flag = "seed %d control_steps %d:" % (seed, n), False
+        for tag, mask, cells in (("free", ~hm, np.zeros_like(grp["cells"])), ("map", hm, grp["cells"])):
+            cmap = (cells,) + tuple(grp["map_meta"])
+            st, warm = synthetic.make_states(probs[mask], n)
+            cm, x, _ = c_oracle.solve_batch(params, cmap, probs[mask], st, warm)
+            worse = cm["cost"] - grp["f_loose"][mask]
+            cases[tag] += int(mask.sum())
+            p3_miss[tag] += int((worse > 1e-3).sum())
+            ref_worse[tag] += int((worse < -1e-3).sum())
+            line += " P3 %s %.1e" % (tag, worse.max())
+            flag |= bool((worse > 1e-3).any())
+            if tag == "free":
+                ok = grp["status_tight"][mask] == 0
+                du0 = np.abs(x[:, :3] - grp["x_tight"][mask][:, :3]).max(axis=1)
+                short = ok & (cm["cost"] < grp["f_tight"][mask] - 1e-9)
+                at = ok & ~short
+                p2_cases += int(at.sum())
+                p2_miss += int((du0[at] > 1e-3).sum())
+                ref_short += int(short.sum())
+                line += " | P2 %.1e (reference above the build on %d cases: %.1e there)" % (
+                    du0[at].max() if at.any() else 0.0, short.sum(), du0[short].max() if short.any() else 0.0)
+                flag |= bool((du0[at] > 1e-3).any())
+        if flag:
+            print(line, {k: round(v, 3) for k, v in over.items()})
+    print("%d parameter sets: P3 misses (build more than 1e-3 above SLSQP as shipped) %d of %d all-free-map cases, %d of %d costmap cases -- "
+          "SLSQP as shipped more than 1e-3 above the build: %d and %d; P2 misses %d of %d cases the reference converged on (its "
+          "objective above the build's on %d more)" % (len(results), p3_miss["free"], cases["free"], p3_miss["map"], cases["map"],
+                                                       ref_worse["free"], ref_worse["map"], p2_miss, p2_cases, ref_short))
