@@ -44,6 +44,10 @@ def work(seed):
 
 
 if __name__ == "__main__":
+    import ctypes as C
+    from oracle import c_oracle as _co
+    for kv in filter(None, os.environ.get("HOOKS","").split(",")):
+        k_, v_ = kv.split("="); getattr(_co.load(), "orc_set_" + k_)(C.c_int(int(v_)))
     import util
     from neo_mpc_planner2_amd import synthetic
     from oracle import c_oracle, gen_golden
