@@ -43,20 +43,26 @@ __device__ __forceinline__ int raw_occupancy(int raw) {
 __device__ __forceinline__ double raw_cost(int raw) { return (double)raw_occupancy(raw) / 100.0; }
 
 // raw cost of cell (mx, my): from the LDS reach tile when it covers the cell, else a bounds-checked global read
+// kCovered: the tile is there and covers every cell a feasible rollout can reach, and their neighbours (capi: R =
+// ceil(max_vel_trans x horizon / resolution) + 1 cells around the robot's cell; every candidate is projected onto the
+// feasible set) -- the static-tile kernels: no bounds test, no global fallback, and the map's geometry words stay out of
+// the scalar registers of the solver loop.
+template <bool kCovered = false>
 __device__ __forceinline__ int cell_raw(const SolveArgs& a, const Ctx& c, const double* L, int mx, int my) {
   const unsigned tx = (unsigned)(mx - c.tile_x0), ty = (unsigned)(my - c.tile_y0);
   const int lg = c.tile_geom & 31;  // (one scalar register for the tile geometry; unpacking is scalar ALU work)
-  if ((tx >> lg) == 0u && ty < (unsigned)(c.tile_geom >> 8))
+  if (kCovered || ((tx >> lg) == 0u && ty < (unsigned)(c.tile_geom >> 8)))
     return reinterpret_cast<const uint8_t*>(L + a.lds.tile)[(ty << lg) + tx];
   return map_raw(a.map, mx, my);
 }
 
+template <bool kCovered = false>
 __device__ __forceinline__ double step_term(const SolveArgs& a, const Ctx& c, const double* L, double x, double y) {
   if (c.tile_geom & kTileFree) return L[a.lds.term];   // free neighbourhood (load_tile): the term of a free cell, no lookup
   const double X = c.X0 + (c.c0 * x - c.s0 * y), Y = c.Y0 + (c.s0 * x + c.c0 * y);
   const int mx = cell_of(X, a.map.origin_x, a.map.resolution, a.map.inv_resolution);
   const int my = cell_of(Y, a.map.origin_y, a.map.resolution, a.map.inv_resolution);
-  return L[a.lds.term + cell_raw(a, c, L, mx, my)];
+  return L[a.lds.term + cell_raw<kCovered>(a, c, L, mx, my)];
 }
 
 // Wall model of the stage-wise direction (Riccati kernel).  A stage whose position (x, y: rollout frame) sits within
@@ -80,6 +86,7 @@ constexpr double kSticky = NEO_RULE_STICKY, kWall = NEO_RULE_WALL, kStickyDist =
 // kHopMargin cells inside the cheaper neighbour (every later stage shifts with it); lanes 1-4 of the search try the
 // current point with one such block changed (feasible_set.h).
 constexpr double kHopMargin = NEO_RULE_HOP_MARGIN;   // (well inside kStickyDist: a stage that has just hopped must not sit ON the edge of the sticky zone; deeper costs objective)
+template <bool kCovered = false>
 __device__ __forceinline__ int edge_stickiness(const SolveArgs& a, const Ctx& c, const double* L, double x, double y,
                                                double cs, double sn, double& wxx, double& wxy, double& wyy, double& lx,
                                                double& ly, bool& hop, float& hop_x, float& hop_y) {
@@ -92,7 +99,7 @@ __device__ __forceinline__ int edge_stickiness(const SolveArgs& a, const Ctx& c,
   // (position inside the cell, in cells: by the reciprocal -- distances to an edge are compared with 0.01 ... 0.25)
   const double fx = (X - a.map.origin_x) * a.map.inv_resolution - (double)mx;
   const double fy = (Y - a.map.origin_y) * a.map.inv_resolution - (double)my;
-  const int raw_here = cell_raw(a, c, L, mx, my);
+  const int raw_here = cell_raw<kCovered>(a, c, L, mx, my);
   const double here = L[a.lds.term + raw_here];
   // (saturated cell indices -- positions far outside every map -- wrap in mx +- 1; such cells read lethal
   // on both sides, so no edge is sticky there)
@@ -105,7 +112,7 @@ __device__ __forceinline__ int edge_stickiness(const SolveArgs& a, const Ctx& c,
   double rx = 0.0, ry = 0.0, pbx = 0.0, pby = 0.0;
   double drop = L[a.lds.tol + T_HOP_DROP], hwx = 0.0, hwy = 0.0;   // best drop so far, hop in world axes (metres)
   if (xlo || xhi) {
-    const int raw_n = cell_raw(a, c, L, xlo ? mx - 1 : mx + 1, my);
+    const int raw_n = cell_raw<kCovered>(a, c, L, xlo ? mx - 1 : mx + 1, my);
     const double dist = xlo ? fx : 1.0 - fx, there = L[a.lds.term + raw_n];
     const bool wall = raw_n == 254 && raw_here != 254;
     if (wall) { if (dist < kWallDist) { rx = kWall * 2.0 * a.p.wt_n; pbx = (xlo ? kWallDist - dist : dist - kWallDist) * a.map.resolution; } }
@@ -116,7 +123,7 @@ __device__ __forceinline__ int edge_stickiness(const SolveArgs& a, const Ctx& c,
     }
   }
   if (ylo || yhi) {
-    const int raw_n = cell_raw(a, c, L, mx, ylo ? my - 1 : my + 1);
+    const int raw_n = cell_raw<kCovered>(a, c, L, mx, ylo ? my - 1 : my + 1);
     const double dist = ylo ? fy : 1.0 - fy, there = L[a.lds.term + raw_n];
     const bool wall = raw_n == 254 && raw_here != 254;
     if (wall) { if (dist < kWallDist) { ry = kWall * 2.0 * a.p.wt_n; pby = (ylo ? kWallDist - dist : dist - kWallDist) * a.map.resolution; } }

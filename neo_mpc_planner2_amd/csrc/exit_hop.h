@@ -20,7 +20,7 @@ namespace {
 // In: the final iterate u (LDS) and its objective f.  Out: u with ONE block changed and the lower f, or both as they were;
 // nfev counts the evaluation.  (The caller skips it when no stage of the iterate has a costmap term under it, or the
 // whole reach tile is free.)
-template <int kSteps, int kNwSteps, bool kTame>
+template <int kSteps, int kNwSteps, bool kTame, bool kCovered>
 __device__ __forceinline__ void exit_hop(const SolveArgs& a, const Ctx& c, double* L, double& f, int& nfev, int lane, int n) {
   const DevParams& p = a.p;
   double* u = L + a.lds.u;
@@ -40,7 +40,7 @@ __device__ __forceinline__ void exit_hop(const SolveArgs& a, const Ctx& c, doubl
     }
     if (lane < n) {
       double wxx, wxy, wyy, wlx, wly;
-      (void)edge_stickiness(a, c, L, x, y, cs, sn, wxx, wxy, wyy, wlx, wly, has_hop, hop_x, hop_y);
+      (void)edge_stickiness<kCovered>(a, c, L, x, y, cs, sn, wxx, wxy, wyy, wlx, wly, has_hop, hop_x, hop_y);
     }
   }
   const unsigned long long hmask = __ballot(has_hop);
@@ -63,7 +63,7 @@ __device__ __forceinline__ void exit_hop(const SolveArgs& a, const Ctx& c, doubl
       hy = reinterpret_cast<const float*>(t + T_HOP_VEC)[2 * lane + 1];
     }
     double hb0 = 0.0, hb1 = 0.0;
-    double fh = rollout_cost<kSteps, kTame>(
+    double fh = rollout_cost<kSteps, kTame, kCovered>(
         a, c, L,
         [&](int i, double& b0, double& b1, double& b2) {
           b0 = u[3 * i]; b1 = u[3 * i + 1]; b2 = u[3 * i + 2];

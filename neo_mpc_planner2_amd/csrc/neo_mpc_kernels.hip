@@ -125,6 +125,7 @@ constexpr int kNewtonMaxSteps = 8;
 // (above), 2 projected Newton solved stage by stage (riccati.h; kSteps == 0 only, any control_steps).
 template <int kMinWavesPerSimd, int kSteps, int kDir = 0, bool kTame = false, int kStaticTile = 0>
 __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveArgs args) {
+  constexpr bool kCovered = kStaticTile > 0;   // the reach tile is there and covers every lookup (costmap.h cell_raw)
   constexpr bool kNewton = kDir == 1;    // dense system in registers
   constexpr bool kRiccati = kDir == 2;   // stage-wise recursion
   constexpr bool kSecond = kDir != 0;    // either: Newton stop rules, no quasi-Newton state
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   // ever (K2).  Closed loop of 4096 robots: 6.2 -> 4.2 iterations per warm tick.
   if (!cold && n > 1 && !(p.compat & kCompatNoUnshift) && p.max_it < kDumpGradient) {   // (not in the test hooks: they dump AT the given point)
     double ts = 0.0;
-    const double fs = rollout_cost<kSteps, kTame>(
+    const double fs = rollout_cost<kSteps, kTame, kCovered>(
         a, c, L,
         [&](int i, double& b0, double& b1, double& b2) {
           const int src = lane == 1 ? (i == 0 ? n - 1 : i - 1) : i;
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       hop_x = reinterpret_cast<const float*>(t + T_HOP_VEC)[2 * (lane - 1)];
       hop_y = reinterpret_cast<const float*>(t + T_HOP_VEC)[2 * (lane - 1) + 1];
     }
-    double fc = rollout_cost<kSteps, kTame>(
+    double fc = rollout_cost<kSteps, kTame, kCovered>(
         a, c, L,
         [&](int i, double& b0, double& b1, double& b2) {
           candidate_block<kTame, kRiccati>(a, c, L, lane, step, pstep, i, b0, b1, b2, hop_stage, hop_x, hop_y);
@@ -641,7 +642,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   // ---- dense direction: a search that has ENDED looks once for a cheaper costmap cell a hop away (exit_hop.h); skipped
   //      when no stage of the iterate has a costmap term under it
   if (kNewton && status == NEO_MPC_STATUS_CONVERGED && u_term != 0.0 && !(c.tile_geom & kTileFree) && p.max_it < kDumpGradient)
-    exit_hop<kSteps, kNwSteps, kTame>(a, c, L, f, nfev, lane, n);
+    exit_hop<kSteps, kNwSteps, kTame, kCovered>(a, c, L, f, nfev, lane, n);
 
   NEO_SEGMENT(1);
 #ifndef NEO_MPC_PHASE_TIMING
@@ -931,7 +932,8 @@ void launch_solve(const SolveArgs& a, const LaunchTuning& tuning, void* stream, 
   const bool generic = tuning.generic_steps || a.p.mem != 4;  // A/B: LDS-only path
   const bool disc = a.p.tame != 0 && !tuning.no_tame;
   const size_t lds = a.lds.total_bytes;
-  const bool small_tile = a.lds.tile_w * a.lds.tile_h <= 1024 && !tuning.dynamic_lds;
+  // (the static-tile kernels count on the tile being there: no tile at all -- a reach of 60 cells and more -- is not "small")
+  const bool small_tile = a.lds.tile_w * a.lds.tile_h > 0 && a.lds.tile_w * a.lds.tile_h <= 1024 && !tuning.dynamic_lds;
   // with events: hipExtLaunchKernel stamps them from the dispatch packet itself (no barrier packets in
   // front of and behind the kernel, which is what separate hipEventRecord calls put on the queue)
   hipEvent_t e0 = (hipEvent_t)ev_start, e1 = (hipEvent_t)ev_stop;

@@ -22,7 +22,7 @@ struct NoRecord {
 // kSteps > 0: control_steps known at compile time (loops unroll); Record(i, sin, cos) lets the caller
 // keep the rollout's trigonometry (the winner's is reused by the next adjoint sweep)
 // term_sum (optional): the sum of the costmap terms alone -- 0.0 exactly when every stage sits in a free cell
-template <int kSteps = 0, bool kTame = false, class Block, class Record = NoRecord>
+template <int kSteps = 0, bool kTame = false, bool kCovered = false, class Block, class Record = NoRecord>
 __device__ __forceinline__ double rollout_cost(const SolveArgs& a, const Ctx& c, const double* L, Block block,
                                                Record record = Record(), double* term_sum = nullptr) {
   const DevParams& p = a.p;
@@ -42,7 +42,7 @@ __device__ __forceinline__ double rollout_cost(const SolveArgs& a, const Ctx& c,
     const double e0 = c.v0 - vx, e1 = c.v1 - vy, e2 = c.v2 - w;
     f += p.wt_n * (dx * dx + dy * dy) + p.wo_n * (et * et);   // py:252
     f += p.wc_n * sqrt_fast(e0 * e0 + e1 * e1 + e2 * e2);      // py:253-254
-    const double term = step_term(a, c, L, x, y);              // py:246-247, 257-260
+    const double term = step_term<kCovered>(a, c, L, x, y);    // py:246-247, 257-260
     f += term;
     if (term_sum) ts += term;
   }
