@@ -418,6 +418,35 @@ def gen_g13(mod):
            seed_base=13540)
 
 
+G14_SEEDS = 48
+
+
+def _g14_group(seed):
+    from oracle import fuzz_reference
+    mod = ros_stubs.load_reference()
+    n, over = fuzz_reference.draw(seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        grp = _g3_group(mod, n, 24, 20000 + seed, over, map_size=300, map_seed=500 + seed)
+    return seed, n, grp
+
+
+def gen_g14(mod):
+    """G14: the first G14_SEEDS draws of oracle/fuzz_reference.py -- RANDOM parameter sets (weights, limits with and without
+    the box cutting the disc, horizons, control_steps 3..10, opt_tolerance), 24 cold problems each under G10's protocol.
+    The fixture that puts a number on how often the gates fail away from hand-picked sets (keys s<seed>_*)."""
+    import multiprocessing as mp
+    t0 = time.time()
+    out = dict(versions=np.array(repr(versions())), param_keys=np.array(PARAM_KEYS), seeds=np.arange(G14_SEEDS))
+    steps = []
+    with mp.Pool(max(1, (os.cpu_count() or 2) - 1)) as pool:
+        for seed, n, grp in sorted(pool.imap_unordered(_g14_group, range(G14_SEEDS)), key=lambda r: r[0]):
+            steps.append(n)
+            out.update({"s%d_%s" % (seed, k): v for k, v in grp.items()})
+    out["steps"] = np.array(steps)
+    np.savez_compressed(os.path.join(OUT, "g14_random_sets.npz"), **out)
+    print("G14: %d random parameter sets x 24 cold solves in %.0fs" % (G14_SEEDS, time.time() - t0), flush=True)
+
+
 def gen_g11(mod):
     """G11: optimizer() episodes of the reference RUN TO CONVERGENCE -- `opt_tolerance` 1e-12 (py:72, 364) and SLSQP's
     iteration cap raised to 500 inside the call of py:363-364 -- on an all-free map (unique minimisers): the converged
@@ -674,6 +703,7 @@ def main():
     gen_g11(mod)
     gen_g12(mod)
     gen_g13(mod)
+    gen_g14(mod)
 
 
 if __name__ == "__main__":

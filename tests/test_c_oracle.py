@@ -480,6 +480,12 @@ def test_g13_warm_gate_at_another_parameter_set(fixture):
           % (fixture, dv.size, np.percentile(dv, 99), dv.max(), above, above_at_min, short, its.mean()))
 
 
+def test_g14_random_parameter_sets_miss_rates_mirror():
+    m = util.random_sets_miss_rates(_cold_solve)
+    print("G14 (mirror):", m)
+    util.assert_random_sets(m)
+
+
 def test_one_sided_slides_and_the_closing_in_rule_mirror():
     print("stop-rule regressions (mirror): (|du0| of the instance, max over 256, iterations)", util.check_stop_rule_regressions(_cold_solve))
 

@@ -1104,3 +1104,15 @@ def test_one_sided_slides_and_the_closing_in_rule(solver_mod):
         with _solver(solver_mod, params, cmap) as s:
             return s.solve(pr, st, warm)
     print("stop-rule regressions: (|du0| of the instance, max over 256, iterations)", util.check_stop_rule_regressions(solve))
+
+
+def test_g14_random_parameter_sets_miss_rates(solver_mod):
+    """G14 through the C-ABI on the GPU: 48 random parameter sets x 24 cold problems against the reference, miss COUNTS
+    (util.random_sets_miss_rates)."""
+    def solve(params, cmap, pr):
+        st, warm = synthetic.make_states(pr, params["control_steps"])
+        with _solver(solver_mod, params, cmap) as s:
+            return s.solve(pr, st, warm)
+    m = util.random_sets_miss_rates(solve)
+    print("G14:", m)
+    util.assert_random_sets(m)
