@@ -292,6 +292,23 @@ def warm_gate():
         print("iterations: mean %.2f max %d" % (its.mean(), its.max()))
 
 
+def random_sets():
+    """G14: miss counts over 48 random parameter sets (round 4)."""
+    print("\n# G14: 48 RANDOM parameter sets x 24 cold problems against the reference (miss counts, tests/util.random_sets_miss_rates)")
+
+    def solve(params, cmap, pr):
+        st, warm = synthetic.make_states(pr, params["control_steps"])
+        with BatchSolver(params) as s:
+            s.set_costmap(*cmap)
+            return s.solve(pr, st, warm)
+    m = util.random_sets_miss_rates(solve)
+    print("P3 misses (objective more than 1e-3 above SLSQP as shipped): %d of %d all-free-map cases, %d of %d costmap cases; SLSQP as "
+          "shipped more than 1e-3 above the build: %d of %d" % (m["p3_miss_free"], m["cases_free"], m["p3_miss_map"], m["cases_map"],
+                                                               m["ref_worse"], m["cases_free"] + m["cases_map"]))
+    print("P2 misses (first control more than 1e-3 from SLSQP run to the end): %d of %d cases (worst %.2e); the reference's converged "
+          "objective is above the build's on %d more" % (m["p2_miss"], m["p2_cases"], m["p2_worst"], m["ref_short"]))
+
+
 if __name__ == "__main__":
     cold_starts()
     long_horizon_unique_minimisers()
@@ -303,3 +320,4 @@ if __name__ == "__main__":
     warm_drift()
     held_out_sets()
     warm_gate()
+    random_sets()
