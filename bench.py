@@ -444,6 +444,8 @@ def main():
                          "the kernel (a stamped launch costs ~7 us of event handling on the stream; with --gpus > 1 every "
                          "launch is stamped, the all-gather waits on the stop event); 0 = every 8th, more often when "
                          "that would leave fewer than five timed launches")
+    ap.add_argument("--settle-ms", type=float, default=40.0,
+                    help="untimed launches for this many milliseconds ahead of the warm-up steps (clock ramp after idle; 0 = off)")
     ap.add_argument("--streams", type=int, default=1,
                     help="study knob (NOT the headline): consecutive steps alternate over this many streams, so "
                          "the next batch starts while the previous one's stragglers finish (independent fleets)")
@@ -572,6 +574,19 @@ def main():
         if pair is not None:
             pair[0].record(stream)
             pair[1].record(stream)
+    # Device settle (untimed, ahead of the W warm-up steps, reported as `settle`): after an idle period the GPU needs some
+    # tens of milliseconds of work to reach its running clock -- the first ~100 launches last 0.090-0.091 ms against 0.087
+    # -- and a run of `--steps 20 --warmup 5` would report that ramp instead of the kernel (42.6 M against 45.3 M solves/s
+    # at 200 steps, same build, same box).  Nothing of it is inside the timed region; --settle-ms 0 switches it off.
+    settle_launches = 0
+    if args.settle_ms > 0:
+        t_settle = time.perf_counter()
+        while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+            for _ in range(16):
+                b = warm_sets[settle_launches % len(warm_sets)]
+                solver.solve_device(base.problems, b.states, b.warm, b.commands, velocities=b.vel)
+                settle_launches += 1
+            torch.cuda.synchronize()
     for i in range(args.warmup):
         b = warm_sets[i % len(warm_sets)]
         solver.solve_device(base.problems, b.states, b.warm, b.commands, velocities=b.vel)
@@ -639,6 +654,8 @@ def main():
                        if world > 1 else "single GPU"},
             "roofline": roof,
             "valu_issue": valu_issue(pmc, k_ms),
+            "settle": {"ms": args.settle_ms, "launches": settle_launches,
+                       "what": "untimed launches ahead of the W warm-up steps: the clock ramp after idle (--settle-ms 0: off)"},
             **({"study_streams": args.streams} if args.streams > 1 else {}),
             "solver": {"mean_iterations": float(cmds["iterations"].mean()),
                        "max_iterations_seen": int(cmds["iterations"].max()),
