@@ -578,15 +578,23 @@ def main():
     # tens of milliseconds of work to reach its running clock -- the first ~100 launches last 0.090-0.091 ms against 0.087
     # -- and a run of `--steps 20 --warmup 5` would report that ramp instead of the kernel (42.6 M against 45.3 M solves/s
     # at 200 steps, same build, same box).  Nothing of it is inside the timed region; --settle-ms 0 switches it off.
+    # (every settle launch is the SAME cold solve as a timed step -- the sets are put back to the cold state before they are
+    # used again -- so a kernel trace or a counter pass over this command averages one workload, not a mix with warm starts)
     settle_launches = 0
     if args.settle_ms > 0:
+        def cold_again():
+            for b in warm_sets:
+                b.states.copy_(base.states)
+                b.warm.copy_(base.warm)
+            torch.cuda.synchronize()
         t_settle = time.perf_counter()
         while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
-            for _ in range(16):
-                b = warm_sets[settle_launches % len(warm_sets)]
+            cold_again()
+            for b in warm_sets:
                 solver.solve_device(base.problems, b.states, b.warm, b.commands, velocities=b.vel)
                 settle_launches += 1
             torch.cuda.synchronize()
+        cold_again()
     for i in range(args.warmup):
         b = warm_sets[i % len(warm_sets)]
         solver.solve_device(base.problems, b.states, b.warm, b.commands, velocities=b.vel)
@@ -687,7 +695,7 @@ def main():
                     [("C2", GENERAL_SETS[k], k) for k in sorted(GENERAL_SETS)]:
                 try:
                     # (4096-instance launches last 0.1-0.3 ms: a dozen of them, so that the wall-clock rate is the stream's)
-                    others.append(other_workload(name, dev, local_rank, steps=12 if over else 3, params_over=over, label=label))
+                    others.append(other_workload(name, dev, local_rank, steps=12 if over else 8, params_over=over, label=label))
                 except Exception as e:
                     others.append({"workload": label or name, "error": str(e)})
             out["other_workloads"] = others

@@ -21,7 +21,7 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_W
            "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT" \
            "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   n=$(echo $set | cut -d" " -f1)
-  rocprofv3 --pmc $set --output-format csv -d $OUT -o pmc_$n -- python $R/bench.py --workload $W --steps $PSTEPS --warmup 1 --no-cpu-baseline --no-pcie --no-others > $OUT/pmc_$n.log 2>&1
+  rocprofv3 --pmc $set --output-format csv -d $OUT -o pmc_$n -- python $R/bench.py --workload $W --steps $PSTEPS --warmup 1 --settle-ms 0 --no-cpu-baseline --no-pcie --no-others > $OUT/pmc_$n.log 2>&1
 done
 cd $R
 python tools/rocprof_summary.py kernels $OUT/trace_results.db > $OUT/kernels.txt 2>&1
