@@ -680,6 +680,27 @@ def main():
                                          "value": cfg["batch"] * args.steps / e} for r, (e, k) in enumerate(per_rank)],
                            "what": "one all-gather of (vx, vy, w) per step on a side stream, overlapped with the next "
                                    "step's solve; gather_ms = its own duration (events on the side stream)"}
+        if world == 1 and args.streams == 1 and not args.no_others:
+            # Two independent batches in flight (NOT the headline, which is one stream, one batch after the other): the same
+            # K launches again, alternating over two streams -- a launch of 4096 instances is one residency round whose last
+            # third runs on half-empty SIMDs, and the next batch's waves fill them (two fleets served by one GPU).
+            try:
+                s2 = torch.cuda.Stream(device=dev)
+                for b in sets:
+                    b.states.copy_(base.states)
+                    b.warm.copy_(base.warm)
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                for i, b in enumerate(sets):
+                    solver.solve_device(base.problems, b.states, b.warm, b.commands, velocities=b.vel,
+                                        stream=s2.cuda_stream if i % 2 else None)
+                torch.cuda.synchronize()
+                e2 = time.perf_counter() - t2
+                out["two_streams"] = {"value": cfg["batch"] * args.steps / e2, "unit": "solves/s", "ms_per_step": 1e3 * e2 / args.steps,
+                                      "what": "the same %d cold launches alternating over two streams (two independent fleets); "
+                                              "study figure, not `value`" % args.steps}
+            except Exception as e:
+                out["two_streams"] = {"error": str(e)}
         if world == 1 and not args.no_pcie:
             out["pcie_inclusive"] = pcie_inclusive(solver, probs, st, warm, n)
             # SURVEY 8d's own metric (H2D of the requests and D2H of the results inside the clock), first class beside
