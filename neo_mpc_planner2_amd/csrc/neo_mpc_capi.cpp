@@ -190,6 +190,8 @@ void derive(neo_mpc_handle* h) {
   d.stall_step = r.stall_step;
   d.hop_min_drop = r.hop_min_drop;
   d.hop_range = h->has_map ? neo_rules_hop_range(d.dt, h->map.resolution) : NEO_RULE_HOP_DIST;
+  d.scan_resume_gain = r.scan_resume_gain;
+  d.scan_reach = h->has_map ? neo_rules_reach_cells(&p, h->map.resolution) : 0;
   d.max_it = r.max_iterations;
   d.mem = r.lbfgs_memory;
   d.compat = (p.compat_flags & NEO_MPC_COMPAT_ODOM_YAW_GOAL_W) |
@@ -221,12 +223,8 @@ void derive(neo_mpc_handle* h) {
   const int off = l.tile;
   l.tile_w = 0; l.tile_h = 0; l.reach = 0;
   if (h->has_map) {
-    const double bx = std::fmax(std::fabs(p.min_vel_x), std::fabs(p.max_vel_x));
-    const double by = std::fmax(std::fabs(p.min_vel_y), std::fabs(p.max_vel_y));
-    const double vmax = std::fmin(p.max_vel_trans, std::hypot(bx, by));
-    const double cells = std::ceil(vmax * p.prediction_horizon / h->map.resolution);
-    if (cells < 60.0) {
-      const int R = (int)cells + 1;
+    const int R = neo_rules_reach_cells(&p, h->map.resolution);   // (solver_rules.h: the cell scan's radius too)
+    if (R <= 60) {
       int w = 4;
       while (w < 2 * R + 4) w <<= 1;
       if (w <= kMaxTileWidth) { l.reach = R; l.tile_w = w; l.tile_h = 2 * R + 1; }

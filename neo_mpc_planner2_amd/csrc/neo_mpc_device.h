@@ -39,12 +39,14 @@ struct DevParams {
   double hop_min_drop;       // stage-wise direction: a cheaper neighbour cell is worth a hop candidate when its costmap
                              // term is lower by more than this (0.1 * opt_tolerance)
   double hop_range;          // ... and its edge is closer than this (cells): min(0.25, 0.05 m/s * dt / resolution)
+  double scan_resume_gain;   // cell scan (cell_scan.h): the search is taken up again behind a scan that gained more than this
   int32_t n;                 // control_steps
   int32_t max_it;
   int32_t mem;               // L-BFGS pairs
   int32_t compat;
   int32_t disc_in_box;       // the max_vel_trans disc lies inside the vx/vy box (README params)
   int32_t tame;              // disc_in_box and max|omega| * horizon <= 0.78 rad: the kTame kernels apply
+  int32_t scan_reach;        // cell scan: no cell further than this from the robot's own cell (= the reach tile's radius)
   int32_t newton;            // search direction of lanes 32-63: 0 projected L-BFGS, 1 projected Newton with
                              // the dense system (control_steps <= 8), 2 projected Newton by the Riccati sweep
 };
@@ -89,7 +91,7 @@ constexpr LdsLayout make_lds_layout(int n, int mem, bool riccati, bool corners =
   int off = 0;
   l.prob = off; off += 32;
   l.state = off; off += 16;
-  l.tol = off; off += 22;   // stop tolerances + two cold per-instance constants (read once per iteration; kept out of the scalar
+  l.tol = off; off += 30;   // (= kTolDoubles, solver_context.h) stop tolerances + two cold per-instance constants (read once per iteration; kept out of the scalar
                             // registers), then the hop candidates of the current iteration (solver_context.h)
   l.term = off; off += 256;
   l.u = off; off += nv;

@@ -50,7 +50,7 @@
 #include "tangent_cone.h"
 #include "dense_newton.h"
 #include "lbfgs.h"
-#include "exit_hop.h"
+#include "cell_scan.h"
 
 namespace neo_mpc {
 namespace {
@@ -107,6 +107,51 @@ constexpr int kLateIteration = NEO_RULE_LATE_ITERATION;
 // largest control_steps the run-time-sized Newton kernel takes (a 24 x 24 system: rows in registers)
 constexpr int kNewtonMaxSteps = 8;
 
+// ---------------------------------------------------------------- K1: phases
+// K1 runs in phases -- set-up, search, cell scan, K2 -- and the search can be taken up again behind the scan.  Each phase
+// starts from a FRESH copy of the launch arguments (re-read from the kernarg segment through a pointer the compiler cannot
+// see through) and of the per-instance constants (re-read from the tolerance block of LDS, where the set-up leaves them): the
+// vector-register residents of the solver loop are then dead outside it.  Allocated as ONE live range across the scan they
+// came out spilled -- and reloaded from scratch inside the loop, +20 % on a C2 launch for code that runs once per solve.
+template <int kSteps, int kStaticTile, int kLayoutSteps>
+__device__ __forceinline__ void fresh_args(SolveArgs& a) {
+  auto kp = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();   // (k_solve's only argument: offset 0)
+  asm volatile("" : "+s"(kp));
+  a = *(const SolveArgs*)kp;
+  if (kSteps || kStaticTile) {  // compile-time LDS offsets (lbfgs_memory is 4 in the specialisations' layout)
+    constexpr LdsLayout kStaticLayout = make_lds_layout(kLayoutSteps, kSteps ? 4 : 0, false);
+    const int tile_w = a.lds.tile_w, tile_h = a.lds.tile_h, reach = a.lds.reach;
+    a.lds = kStaticLayout;
+    a.lds.tile_w = tile_w; a.lds.tile_h = tile_h; a.lds.reach = reach;
+    if (kSteps) a.p.n = kSteps;
+  }
+}
+// The parameters the solver loop reads are detached from the wide scalar loads that bring the
+// kernel arguments in: a spilled s_load_dwordx16 tuple comes back whole (16 v_readlane) for every
+// use of one of its members; as values of their own they are reloaded pair by pair.
+__device__ __forceinline__ void own_loop_params(SolveArgs& a) {
+  auto own = [](double& v) { asm volatile("" : "+s"(v)); };
+  own(a.p.dt); own(a.p.wt_n); own(a.p.wo_n); own(a.p.wc_n); own(a.p.wterm_o); own(a.p.r);
+  own(a.p.lo[2]); own(a.p.hi[2]);
+  own(a.map.origin_x); own(a.map.origin_y); own(a.map.resolution); own(a.map.inv_resolution);
+}
+// the per-instance constants as the set-up left them in LDS (request record + tolerance block); wave-uniform: scalar
+// registers -- except, kVectorPose, the four the costmap lookup of every stage of every candidate needs (k_solve says why)
+template <bool kVectorPose>
+__device__ __forceinline__ void ctx_from_lds(const SolveArgs& a, const double* L, Ctx& c) {
+  const double* P = L + a.lds.prob;
+  const double* t = L + a.lds.tol;
+  c.cx = lane_value(P[P_CARROT_X], 0); c.cy = lane_value(P[P_CARROT_Y], 0);
+  c.tyaw = lane_value(t[T_TYAW], 0); c.fyaw = lane_value(t[T_FYAW], 0);
+  c.v0 = lane_value(P[P_VEL], 0); c.v1 = lane_value(P[P_VEL + 1], 0); c.v2 = lane_value(P[P_VEL + 2], 0);
+  c.c0 = t[T_C0]; c.s0 = t[T_S0]; c.X0 = P[P_CUR_X]; c.Y0 = P[P_CUR_Y];
+  if (kVectorPose) asm volatile("" : "+v"(c.c0), "+v"(c.s0), "+v"(c.X0), "+v"(c.Y0));
+  else { c.c0 = lane_value(c.c0, 0); c.s0 = lane_value(c.s0, 0); c.X0 = lane_value(c.X0, 0); c.Y0 = lane_value(c.Y0, 0); }
+  const int* ti = reinterpret_cast<const int*>(t + T_TILE);
+  c.tile_x0 = uniform_int(ti[0]); c.tile_y0 = uniform_int(ti[1]); c.tile_geom = uniform_int(ti[2]);
+  c.konst = 0.0; c.true_yaw = 0.0;   // (inside the search f excludes the constant terms; K2 reads both from the block)
+}
+
 // ---------------------------------------------------------------- K1
 // kSteps > 0: specialisation for control_steps == kSteps -- every lane keeps its candidate's controls
 // and sin/cos in registers, so the winner is stored without being recomputed and the next adjoint
@@ -139,75 +184,121 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   constexpr int kStaticDoubles = kStaticTile ? (kStaticLayout.total_bytes + kStaticTile) / 8 : 2;
   __shared__ __align__(16) double Lstat[kStaticDoubles];
   double* const L = kStaticTile ? Lstat : Ldyn;
-  SolveArgs a = args;
-  if (kSteps || kStaticTile) {  // compile-time LDS offsets (lbfgs_memory is 4 in the specialisations' layout)
-    const int tile_w = args.lds.tile_w, tile_h = args.lds.tile_h, reach = args.lds.reach;
-    a.lds = kStaticLayout;
-    a.lds.tile_w = tile_w; a.lds.tile_h = tile_h; a.lds.reach = reach;
-    if (kSteps) a.p.n = kSteps;
-  }
-  // The parameters the solver loop reads are detached from the wide scalar loads that bring the
-  // kernel arguments in: a spilled s_load_dwordx16 tuple comes back whole (16 v_readlane) for every
-  // use of one of its members; as values of their own they are reloaded pair by pair.
-  {
-    auto own = [](double& v) { asm volatile("" : "+s"(v)); };
-    own(a.p.dt); own(a.p.wt_n); own(a.p.wo_n); own(a.p.wc_n); own(a.p.wterm_o); own(a.p.r);
-    own(a.p.lo[2]); own(a.p.hi[2]);
-    own(a.map.origin_x); own(a.map.origin_y); own(a.map.resolution); own(a.map.inv_resolution);
-  }
-  const int lane = threadIdx.x;
-  const uint32_t b = blockIdx.x;
-  if (b >= a.count) return;
-  NEO_WAVE_START;
-  const DevParams& p = a.p;
-  const int n = kSteps ? kSteps : p.n, nv = 3 * n, mem = p.mem;
-  constexpr int kRegSteps = kSteps ? kSteps : 1;
-  constexpr int kPairs = kSteps ? 4 : NEO_MPC_MAX_LBFGS_MEMORY;  // specialisations: lbfgs_memory <= 4
-  double cand[3 * kRegSteps], cand_sn[kRegSteps], cand_cs[kRegSteps];
-  bool have_trig = false;  // ACS/ASN already hold sin/cos of the rollout at u
-
-  load_records(a, L, b, lane);
-  // no request for this robot this tick (the plugin threw before its service call, cpp:234-236; K4 status 3): the node's
-  // state does not advance: state record and warm start keep their bytes, the outputs say "skipped" (rollout.h)
-  if (uniform_int(reinterpret_cast<const int*>(L + a.lds.prob)[PI_SKIP]) != 0) { skip_instance(a, b, lane); return; }
-  select_map(a.map, L + a.lds.prob);
-  int flags = reset_and_warm(a, L, b, lane) ? NEO_MPC_FLAG_RESET : 0;
-  const double fcost = footprint_cost(a, L, b, lane);
-  Ctx c;
-  make_ctx_wave(p, a.map, L + a.lds.prob, fcost, c, lane);
-  load_tile(a, c, L, lane);
-  // the per-instance constants are wave-uniform: keep them in scalar registers
-  c.cx = lane_value(c.cx, 0); c.cy = lane_value(c.cy, 0); c.tyaw = lane_value(c.tyaw, 0);
-  c.fyaw = lane_value(c.fyaw, 0); c.v0 = lane_value(c.v0, 0);
-  c.v1 = lane_value(c.v1, 0); c.v2 = lane_value(c.v2, 0);
+  constexpr int kLayoutSteps = kSteps ? kSteps : kNewtonMaxSteps;
 #ifdef NEO_GEOMETRY_IN_SGPRS
-  c.c0 = lane_value(c.c0, 0); c.s0 = lane_value(c.s0, 0); c.X0 = lane_value(c.X0, 0); c.Y0 = lane_value(c.Y0, 0);
+  constexpr bool kVectorPose = false;
 #else
-  // ... except the four the costmap lookup of every stage of every candidate needs (world position = X0 + Rot(psi0) (x, y)):
-  // they stay in VECTOR registers (every lane holds the same value).  The scalar file is over-subscribed -- a hundred
+  // the four constants the costmap lookup of every stage of every candidate needs (world position = X0 + Rot(psi0) (x, y))
+  // stay in VECTOR registers (every lane holds the same value).  The scalar file is over-subscribed -- a hundred
   // scalars are spilled to vector lanes -- and each use of a spilled pair costs two v_readlane and a wait state: twelve
   // lane reads per stage.  (Round 4: the three-address polynomial kernels freed nine vector registers.)
   // (the general kernels have no vector register to spare at four waves per SIMD: scalar there, as before)
-  if (kTame) asm volatile("" : "+v"(c.c0), "+v"(c.s0), "+v"(c.X0), "+v"(c.Y0));
-  else { c.c0 = lane_value(c.c0, 0); c.s0 = lane_value(c.s0, 0); c.X0 = lane_value(c.X0, 0); c.Y0 = lane_value(c.Y0, 0); }
+  constexpr bool kVectorPose = kTame;
 #endif
-  c.tile_x0 = uniform_int(c.tile_x0); c.tile_y0 = uniform_int(c.tile_y0); c.tile_geom = uniform_int(c.tile_geom);
-
-  // The stop tolerances are read once per iteration: from LDS, so that they do not sit in (and get
-  // spilled from) scalar registers all through the loop.
-  // So do two per-instance constants the loop has no use for: the request's true yaw (K2 only) and
-  // the part of the objective that does not depend on u -- inside the loop f excludes it.
-  // (layout: solver_context.h)
-  if (lane == 0) {
-    double* t = L + a.lds.tol;
-    t[T_XTOL] = p.xtol; t[T_EARLY] = p.early_tol; t[T_FINAL] = p.final_tol; t[T_FTOL] = p.ftol;
-    t[T_STALL] = p.stall_step; t[T_WTOL] = p.wtol; t[T_WTOL_LATE] = p.wtol_late; t[T_KINK] = p.kink_radius;
-    t[T_KONST] = c.konst; t[T_TRUE_YAW] = c.true_yaw;
-    t[T_HOP_DROP] = p.hop_min_drop; t[T_HOP_RANGE] = p.hop_range;
-    t[T_BTOL_MAP] = p.btol_map; t[T_BTOL_FREE] = p.btol_free;
-    reinterpret_cast<int*>(t + T_HOP_STAGE)[kHopLanes] = 0;   // no hop candidates yet
+  const int lane = threadIdx.x;
+  const uint32_t b = blockIdx.x;
+  if (b >= args.count) return;
+  NEO_WAVE_START;
+  constexpr int kRegSteps = kSteps ? kSteps : 1;
+  constexpr int kPairs = kSteps ? 4 : NEO_MPC_MAX_LBFGS_MEMORY;  // specialisations: lbfgs_memory <= 4
+  int flags;
+  double fcost, f = INFINITY;   // f(x0) comes out of the first candidate pass: lane 0 evaluates x0 itself there
+  bool cold = true;             // x0 == 0 (wave-uniform: every lane scans the same LDS values)
+  // ---- phase 0: set-up.  Records, reset, footprint, reach tile; the per-instance constants and the stop tolerances go to
+  //      the tolerance block of LDS (layout: solver_context.h), where every later phase reads them; x0.
+  {
+    SolveArgs a;
+    fresh_args<kSteps, kStaticTile, kLayoutSteps>(a);
+    const DevParams& p = a.p;
+    const int n = kSteps ? kSteps : p.n, nv = 3 * n;
+    load_records(a, L, b, lane);
+    // no request for this robot this tick (the plugin threw before its service call, cpp:234-236; K4 status 3): the node's
+    // state does not advance: state record and warm start keep their bytes, the outputs say "skipped" (rollout.h)
+    if (uniform_int(reinterpret_cast<const int*>(L + a.lds.prob)[PI_SKIP]) != 0) { skip_instance(a, b, lane); return; }
+    select_map(a.map, L + a.lds.prob);
+    flags = reset_and_warm(a, L, b, lane) ? NEO_MPC_FLAG_RESET : 0;
+    fcost = footprint_cost(a, L, b, lane);
+    Ctx c;
+    make_ctx_wave(p, a.map, L + a.lds.prob, fcost, c, lane);
+    load_tile(a, c, L, lane);
+    // The stop tolerances are read once per iteration: from LDS, so that they do not sit in (and get
+    // spilled from) scalar registers all through the loop.
+    // So do two per-instance constants the loop has no use for: the request's true yaw (K2 only) and
+    // the part of the objective that does not depend on u -- inside the loop f excludes it.
+    if (lane == 0) {
+      double* t = L + a.lds.tol;
+      t[T_XTOL] = p.xtol; t[T_EARLY] = p.early_tol; t[T_FINAL] = p.final_tol; t[T_FTOL] = p.ftol;
+      t[T_STALL] = p.stall_step; t[T_WTOL] = p.wtol; t[T_WTOL_LATE] = p.wtol_late; t[T_KINK] = p.kink_radius;
+      t[T_KONST] = c.konst; t[T_TRUE_YAW] = c.true_yaw;
+      t[T_HOP_DROP] = p.hop_min_drop; t[T_HOP_RANGE] = p.hop_range;
+      t[T_BTOL_MAP] = p.btol_map; t[T_BTOL_FREE] = p.btol_free;
+      reinterpret_cast<int*>(t + T_HOP_STAGE)[kHopLanes] = 0;   // no hop candidates yet
+      t[T_C0] = c.c0; t[T_S0] = c.s0; t[T_TYAW] = c.tyaw; t[T_FYAW] = c.fyaw;
+      int* ti = reinterpret_cast<int*>(t + T_TILE);
+      ti[0] = c.tile_x0; ti[1] = c.tile_y0; ti[2] = c.tile_geom;
+    }
+    double* u = L + a.lds.u;
+    // x0 clipped to the feasible set (SciPy clips x0 to the bounds, _slsqp_py.py:268)
+    for (int i = lane; i < n; i += kLanes) project_block<kTame>(p, u[3 * i], u[3 * i + 1], u[3 * i + 2]);
+    WAVE_SYNC();
+    for (int k = 0; k < nv; ++k) cold = cold && (u[k] == 0.0);
+    ctx_from_lds<false>(a, L, c);
+    // The warm start is the previous solution shifted by a WHOLE control step (py:198-202: block i <- block i + 1, the
+    // filtered first control last) although only one control interval -- an eighth of a step at 30 Hz and the README's
+    // horizon -- has passed: the previous solution itself, i.e. the shift undone, [w_{N-1}, w_0, ..., w_{N-2}], is usually
+    // much closer to this tick's minimiser.  In free space (no costmap term under either rollout: one basin) the search
+    // starts from whichever of the two has the lower objective (lane 0 rolls out the warm start, lane 1 the unshifted
+    // one); on the costmap it starts where the reference starts.  The warm start handed BACK is the reference's shift as
+    // ever (K2).  Closed loop of 4096 robots: 6.2 -> 4.2 iterations per warm tick.
+    if (!cold && n > 1 && !(p.compat & kCompatNoUnshift) && p.max_it < kDumpGradient) {   // (not in the test hooks: they dump AT the given point)
+      double ts = 0.0;
+      const double fs = rollout_cost<kSteps, kTame, kCovered>(
+          a, c, L,
+          [&](int i, double& b0, double& b1, double& b2) {
+            const int src = lane == 1 ? (i == 0 ? n - 1 : i - 1) : i;
+            b0 = u[3 * src]; b1 = u[3 * src + 1]; b2 = u[3 * src + 2];
+          },
+          NoRecord(), &ts);
+      const double f_warm = lane_value(fs, 0), f_alt = lane_value(fs, 1);
+      const bool free_both = lane_value(ts, 0) == 0.0 && lane_value(ts, 1) == 0.0;
+      if (f_alt < f_warm && free_both) {
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0;   // (nv <= 192: up to three elements per lane)
+        const int k0 = lane, k1 = lane + kLanes, k2 = lane + 2 * kLanes;
+        if (k0 < nv) v0 = u[k0 >= 3 ? k0 - 3 : k0 + nv - 3];
+        if (k1 < nv) v1 = u[k1 - 3];
+        if (k2 < nv) v2 = u[k2 - 3];
+        WAVE_SYNC();
+        if (k0 < nv) u[k0] = v0;
+        if (k1 < nv) u[k1] = v1;
+        if (k2 < nv) u[k2] = v2;
+      }
+      WAVE_SYNC();
+    }
   }
-  c.konst = 0.0; c.true_yaw = 0.0;
+  // ---- what the search carries from one iteration to the next -- and across the cell scan when it is taken up again
+  int npairs = 0, head = 0, nfev = 1, it = 0, status = NEO_MPC_STATUS_MAX_ITER, stall = 0;
+  int blocked_run = 0;   // dense Newton: consecutive iterations not won by a decent Newton step
+  int nblocked = 1;      // consecutive iterations not won by a Newton step of at least half its length (or won by a hop)
+  double u_term = 0.0;   // dense Newton: sum of the costmap terms under the current iterate's rollout (0: every stage in a free cell)
+  double gain1 = INFINITY, gain2 = INFINITY;  // objective decrease of the previous two iterations
+  bool final_step = false;
+  double alpha = 1.0;
+  bool scanned = false;   // the cell scan has had its turn (cell_scan.h)
+  const int lane_id = lane;
+  NEO_SEGMENT_DECL;
+  NEO_SEGMENT(0);
+  for (;;) {   // (the search; taken up again behind a cell scan that paid)
+  // ---- phase 1: the search
+  SolveArgs a;
+  fresh_args<kSteps, kStaticTile, kLayoutSteps>(a);
+  own_loop_params(a);
+  select_map(a.map, L + a.lds.prob);
+  const DevParams& p = a.p;
+  const int n = kSteps ? kSteps : p.n, nv = 3 * n, mem = p.mem;
+  double cand[3 * kRegSteps], cand_sn[kRegSteps], cand_cs[kRegSteps];
+  bool have_trig = false;  // ACS/ASN already hold sin/cos of the rollout at u
+  Ctx c;
+  ctx_from_lds<kVectorPose>(a, L, c);
   double* u = L + a.lds.u;
   double* gs = L + a.lds.gs;
   double* gt = L + a.lds.gt;
@@ -223,55 +314,17 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   // tangent-cone pass; it lives in the cs..rt step arrays, which the Newton kernel does not use
   static_assert(2 * 7 >= kNewtonRecord, "Newton records do not fit the step arrays");
 
-  // x0 clipped to the feasible set (SciPy clips x0 to the bounds, _slsqp_py.py:268)
-  for (int i = lane; i < n; i += kLanes) project_block<kTame>(p, u[3 * i], u[3 * i + 1], u[3 * i + 2]);
-  WAVE_SYNC();
-  // f(x0) comes out of the first candidate pass: lane 0 evaluates x0 itself there
-  double f = INFINITY;
-  bool cold = true;  // x0 == 0 (wave-uniform: every lane scans the same LDS values)
-  for (int k = 0; k < nv; ++k) cold = cold && (u[k] == 0.0);
-
-  // The warm start is the previous solution shifted by a WHOLE control step (py:198-202: block i <- block i + 1, the
-  // filtered first control last) although only one control interval -- an eighth of a step at 30 Hz and the README's
-  // horizon -- has passed: the previous solution itself, i.e. the shift undone, [w_{N-1}, w_0, ..., w_{N-2}], is usually
-  // much closer to this tick's minimiser.  In free space (no costmap term under either rollout: one basin) the search
-  // starts from whichever of the two has the lower objective (lane 0 rolls out the warm start, lane 1 the unshifted
-  // one); on the costmap it starts where the reference starts.  The warm start handed BACK is the reference's shift as
-  // ever (K2).  Closed loop of 4096 robots: 6.2 -> 4.2 iterations per warm tick.
-  if (!cold && n > 1 && !(p.compat & kCompatNoUnshift) && p.max_it < kDumpGradient) {   // (not in the test hooks: they dump AT the given point)
-    double ts = 0.0;
-    const double fs = rollout_cost<kSteps, kTame, kCovered>(
-        a, c, L,
-        [&](int i, double& b0, double& b1, double& b2) {
-          const int src = lane == 1 ? (i == 0 ? n - 1 : i - 1) : i;
-          b0 = u[3 * src]; b1 = u[3 * src + 1]; b2 = u[3 * src + 2];
-        },
-        NoRecord(), &ts);
-    const double f_warm = lane_value(fs, 0), f_alt = lane_value(fs, 1);
-    const bool free_both = lane_value(ts, 0) == 0.0 && lane_value(ts, 1) == 0.0;
-    if (f_alt < f_warm && free_both) {
-      double v0 = 0.0, v1 = 0.0, v2 = 0.0;   // (nv <= 192: up to three elements per lane)
-      const int k0 = lane, k1 = lane + kLanes, k2 = lane + 2 * kLanes;
-      if (k0 < nv) v0 = u[k0 >= 3 ? k0 - 3 : k0 + nv - 3];
-      if (k1 < nv) v1 = u[k1 - 3];
-      if (k2 < nv) v2 = u[k2 - 3];
-      WAVE_SYNC();
-      if (k0 < nv) u[k0] = v0;
-      if (k1 < nv) u[k1] = v1;
-      if (k2 < nv) u[k2] = v2;
-    }
-    WAVE_SYNC();
+  if (!scanned) {
+    for (int i = lane; i < n; i += kLanes) { AMODE[4 * i + 2] = 0; AMODE[4 * i + 3] = 0; }
+    // Long horizons (Riccati direction): the curvature of a block falls with 1/N^2, so the proximal step starts
+    // longer; and the Newton step is long along the valleys in which neighbouring blocks trade displacement and
+    // leaves the region where the model holds -- Levenberg-Marquardt damping mu (in units of one stage's tracking
+    // weights, riccati_prepare), relaxed x1/4 after an iteration won by the (nearly) full Newton step, tightened
+    // x4 after one won by a proximal step or a short Newton step.  Nothing of it at control_steps <= 8.
+    alpha = kRiccati ? fmax(1.0, n * 0.125) : 1.0;
+    // (mu lives in the tolerance block of LDS: two scalar registers fewer across the loop)
+    if (kRiccati && lane == 0) L[a.lds.tol + T_MU] = n > 8 ? (double)(n - 8) * 0.125 : 0.0;
   }
-
-  for (int i = lane; i < n; i += kLanes) { AMODE[4 * i + 2] = 0; AMODE[4 * i + 3] = 0; }
-  // Long horizons (Riccati direction): the curvature of a block falls with 1/N^2, so the proximal step starts
-  // longer; and the Newton step is long along the valleys in which neighbouring blocks trade displacement and
-  // leaves the region where the model holds -- Levenberg-Marquardt damping mu (in units of one stage's tracking
-  // weights, riccati_prepare), relaxed x1/4 after an iteration won by the (nearly) full Newton step, tightened
-  // x4 after one won by a proximal step or a short Newton step.  Nothing of it at control_steps <= 8.
-  double alpha = kRiccati ? fmax(1.0, n * 0.125) : 1.0;
-  // (mu lives in the tolerance block of LDS: two scalar registers fewer across the loop)
-  if (kRiccati && lane == 0) L[a.lds.tol + T_MU] = n > 8 ? (double)(n - 8) * 0.125 : 0.0;
   // Riccati: a block may be sent straight onto the kink u_i = v_cur only when v_cur is feasible
   bool v_feasible = false;
   if (kRiccati) {
@@ -279,20 +332,16 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     project_block<kTame>(p, b0, b1, b2);
     v_feasible = b0 == c.v0 && b1 == c.v1 && b2 == c.v2;
   }
-  int npairs = 0, head = 0, nfev = 1, it = 0, status = NEO_MPC_STATUS_MAX_ITER, stall = 0;
-  int blocked_run = 0;   // dense Newton: consecutive iterations not won by a decent Newton step
-  int nblocked = 1;      // consecutive iterations not won by a Newton step of at least half its length (or won by a hop)
-  double u_term = 0.0;   // dense Newton: sum of the costmap terms under the current iterate's rollout (0: every stage in a free cell)
-  double gain1 = INFINITY, gain2 = INFINITY;  // objective decrease of the previous two iterations
-  bool final_step = false;
-  const int lane_id = lane;
   // this lane's step multiplier: the one lane-derived constant worth two registers for the whole loop
   // (half of the table sits in constant memory: re-reading it would put a global load on every
   // iteration's critical path)
-  const double my_scale = kRiccati ? 0.0 : lane_scale<kSecond>(lane);
-  NEO_SEGMENT_DECL;
-  NEO_SEGMENT(0);
-  for (it = 0; it < p.max_it; ++it) {
+  double my_scale;
+  {
+    int l0 = lane_id;
+    asm volatile("" : "+v"(l0));
+    my_scale = kRiccati ? 0.0 : lane_scale<kSecond>(l0);
+  }
+  for (; it < p.max_it; ++it) {
     // The lane index is re-read opaquely every iteration: otherwise the compiler hoists two dozen
     // lane-derived constants (step multipliers, compare masks, LDS addresses) out of the loop and,
     // at 4 waves/SIMD, parks them in scratch -- recomputing them costs a few integer operations.
@@ -639,12 +688,49 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     if ((double)stepmax < TOL[T_XTOL] || stall >= kStallIterations || creeping || final_step || blocked_stop) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
   }
 
-  // ---- dense direction: a search that has ENDED looks once for a cheaper costmap cell a hop away (exit_hop.h); skipped
-  //      when no stage of the iterate has a costmap term under it
-  if (kNewton && status == NEO_MPC_STATUS_CONVERGED && u_term != 0.0 && !(c.tile_geom & kTileFree) && p.max_it < kDumpGradient)
-    exit_hop<kSteps, kNwSteps, kTame, kCovered>(a, c, L, f, nfev, lane, n);
+  // ---- phase 2, second-order directions: a search that has ENDED looks once at the costmap cells around every stage
+  //      (cell_scan.h): cheaper cells up to three cells away, which no descent direction sees -- the term has no gradient --
+  //      and SLSQP's line search samples by accident.  Skipped when the whole reach tile is free or (dense direction: known
+  //      from the winner's rollout) no stage of the iterate has a costmap term under it.  Behind a scan that gained more
+  //      than opt_tolerance the search is taken up again: the other blocks have a new neighbour to adjust to.
+#ifdef NEO_AB_NO_SCAN   // (study build)
+  break;
+#endif
+  if (!kSecond || scanned || status != NEO_MPC_STATUS_CONVERGED || (c.tile_geom & kTileFree) || (kNewton && u_term == 0.0) ||
+      p.max_it >= kDumpGradient)
+    break;
+  scanned = true;
+  const double f_before = f;
+  bool resume;
+  {
+    SolveArgs as;
+    fresh_args<kSteps, kStaticTile, kLayoutSteps>(as);
+    select_map(as.map, L + as.lds.prob);
+    Ctx cs;
+    ctx_from_lds<false>(as, L, cs);
+    int ls = lane_id;
+    asm volatile("" : "+v"(ls));
+    const bool won = cell_scan<kSteps, kTame, kCovered>(as, cs, L, f, kNewton ? &u_term : nullptr, nfev, ls, kSteps ? kSteps : as.p.n);
+    resume = won && f_before - f > as.p.scan_resume_gain && it < as.p.max_it;
+#ifdef NEO_AB_NO_RESUME   // (study build)
+    resume = false;
+#endif
+  }
+  if (!resume) break;
+  status = NEO_MPC_STATUS_MAX_ITER; stall = 0; final_step = false; blocked_run = 0; nblocked = 1;
+  gain1 = INFINITY; gain2 = INFINITY;
+  }
 
+  // ---- phase 3: K2
   NEO_SEGMENT(1);
+  SolveArgs a;
+  fresh_args<kSteps, kStaticTile, kLayoutSteps>(a);
+  select_map(a.map, L + a.lds.prob);
+  const DevParams& p = a.p;
+  const int n = kSteps ? kSteps : p.n, nv = 3 * n;
+  double* u = L + a.lds.u;
+  Ctx c;
+  ctx_from_lds<false>(a, L, c);
 #ifndef NEO_MPC_PHASE_TIMING
   // (test hooks: a search that ended before the dumped iteration keeps the NaN row the host put there)
   if (a.solution && p.max_it < kDumpGradient)

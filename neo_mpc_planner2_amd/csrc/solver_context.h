@@ -27,7 +27,11 @@ enum : int {
 // (dvx, dvy) pairs as float32.
 enum : int { T_XTOL, T_EARLY, T_FINAL, T_FTOL, T_STALL, T_WTOL, T_KINK, T_KONST, T_TRUE_YAW, T_MU, T_WTOL_LATE,
              T_HOP_DROP, T_HOP_RANGE, T_HOP_STAGE = 13 /* int32[6]: stage[4], count, - */, T_HOP_VEC = 16 /* float[8] */,
-             T_BTOL_MAP = 20, T_BTOL_FREE = 21, kHopLanes = 4 /* = NEO_RULE_HOP_LANES (solver_rules.h) */ };
+             T_BTOL_MAP = 20, T_BTOL_FREE = 21,
+             // what the out-of-line cell scan (cell_scan.h) reads instead of taking arguments: the rest of Ctx ...
+             T_C0 = 22, T_S0 = 23, T_TYAW = 24, T_FYAW = 25, T_TILE = 26 /* int32[3]: tile_x0, tile_y0, tile_geom */,
+             T_F = 28 /* ... in: the objective at u; out: the winner's */, T_TERM = 29 /* out: the winner's costmap terms */,
+             kTolDoubles = 30, kHopLanes = 4 /* = NEO_RULE_HOP_LANES (solver_rules.h) */ };
 
 constexpr int kTileFree = 0x80;   // Ctx::tile_geom: every cell of the reach tile is free (raw cost 0)
 

@@ -36,6 +36,9 @@
 #define NEO_RULE_HOP_MARGIN 0.01        /* a hop lands this far inside the cheaper cell (cells) */
 #define NEO_RULE_HOP_MIN_DROP 0.1       /* ... worth it when the term drops by more than this x opt_tolerance */
 #define NEO_RULE_HOP_LANES 4
+/* ---- cell scan (cell_scan.h): what a search that has ended does about cheaper cells further away than a hop */
+#define NEO_RULE_SCAN_CELLS 3           /* the scan looks at the (2 x this + 1)^2 - 1 cells around every stage ... */
+#define NEO_RULE_SCAN_RESUME_GAIN 1.0   /* ... and the search is taken up again behind a scan that gained more than this x opt_tolerance */
 
 /* search direction of lanes 32-63 */
 #define NEO_DIRECTION_LBFGS 0
@@ -53,6 +56,7 @@ typedef struct neo_rules {
   double btol_map, btol_free;   /* blocked-run rule (absolute); 0: off */
   double kink_radius;
   double hop_min_drop;  /* absolute */
+  double scan_resume_gain;   /* absolute */
   double flat;          /* (3 / control_steps)^2 beyond 3 control steps with a Newton direction, else 1 */
 } neo_rules;
 
@@ -71,6 +75,16 @@ static inline double neo_rules_hop_range(double dt, double resolution) {
   return fmin(NEO_RULE_HOP_DIST, NEO_RULE_HOP_MAX_DV * dt / resolution);
 }
 
+/* Cells a feasible rollout can get away from the robot's own cell, + 1: the radius of the LDS reach tile (neo_mpc_capi.cpp) and
+ * of the cell scan -- the scan looks at no cell further than this from the robot's cell (Chebyshev), so that every kernel
+ * variant, tile or no tile, and the CPU mirror consider the same cells. */
+static inline int neo_rules_reach_cells(const neo_mpc_params* p, double resolution) {
+  const double bx = fmax(fabs(p->min_vel_x), fabs(p->max_vel_x)), by = fmax(fabs(p->min_vel_y), fabs(p->max_vel_y));
+  const double vmax = fmin(p->max_vel_trans, hypot(bx, by));
+  const double cells = ceil(vmax * p->prediction_horizon / resolution);
+  return cells < 1e6 ? (int)cells + 1 : 1000001;
+}
+
 /* All thresholds derive from opt_tolerance (the reference's SLSQP ftol, py:364) unless the caller set one explicitly. */
 static inline void neo_rules_derive(const neo_mpc_params* p, neo_rules* r) {
   const int n = p->control_steps;
@@ -84,6 +98,7 @@ static inline void neo_rules_derive(const neo_mpc_params* p, neo_rules* r) {
   r->kink_radius = p->kink_radius > 0.0 ? p->kink_radius
                    : r->direction == NEO_DIRECTION_STAGEWISE ? NEO_RULE_KINK_RADIUS_STAGEWISE : NEO_RULE_KINK_RADIUS;
   r->hop_min_drop = NEO_RULE_HOP_MIN_DROP * p->opt_tolerance;
+  r->scan_resume_gain = NEO_RULE_SCAN_RESUME_GAIN * p->opt_tolerance;
   /* Beyond 3 control steps the objective is flatter per block (the weights are divided by N, and two neighbouring blocks
    * of a long horizon can trade displacement at almost no cost): the gain thresholds of the Newton directions shrink with
    * (3/N)^2, the three-iteration window with (3/N)^3 */

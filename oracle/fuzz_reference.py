@@ -35,11 +35,21 @@ def draw(seed):
 
 
 def work(seed):
+    """The reference's answers for one seed; NEO_FUZZ_CACHE=<dir> keeps them between runs (the reference's SLSQP solves
+    are the slow part; the build's search is what changes between runs)."""
     from oracle import gen_golden, ros_stubs
-    mod = ros_stubs.load_reference()
     n, over = draw(seed)
+    cache = os.environ.get("NEO_FUZZ_CACHE")
+    path = os.path.join(cache, "seed%d.npz" % seed) if cache else None
+    if path and os.path.exists(path):
+        with np.load(path) as z:
+            return seed, n, over, {k: z[k] for k in z.files}
+    mod = ros_stubs.load_reference()
     with contextlib.redirect_stdout(io.StringIO()):
         grp = gen_golden._g3_group(mod, n, 24, 20000 + seed, over, map_size=300, map_seed=500 + seed)
+    if path:
+        os.makedirs(cache, exist_ok=True)
+        np.savez_compressed(path, **grp)
     return seed, n, over, grp
 
 

@@ -1050,8 +1050,6 @@ static long orc_repin_count = 0;
 long orc_get_repin_count(void) { return orc_repin_count; }
 static int orc_corner_stop = 1;
 void orc_set_corner_stop(int m) { orc_corner_stop = m; }
-static int orc_exit_hops = 1;
-void orc_set_exit_hops(int m) { orc_exit_hops = m; }
 static int orc_land_mode = 0;
 void orc_set_land_mode(int m) { orc_land_mode = m; }
 static int orc_near_mode = 1;
@@ -1154,6 +1152,88 @@ static int orc_hops(const orc_ctx* c, const double* u, double min_drop, double h
     any |= has[i];
   }
   return any;
+}
+
+/* (round 5) Cell scan -- mirror of csrc/cell_scan.h.  The costmap term is piecewise constant: no gradient, and the hop
+ * candidates look one cell edge and a quarter of a cell ahead; SLSQP's line search samples the term cells away from its
+ * iterate (py:246-260 through py:363-364) and now and then lands in a cheaper cell one to three cells from where a descent
+ * method ends (random parameter sets against the reference: 12 of the 14 objective misses in 5568 costmap cases).  A search
+ * that has ENDED therefore looks once at the cells around every stage: "lane" L of 64 takes stage L / lps (lps = 64 /
+ * control_steps lanes per stage) and every lps-th of the 48 cells within NEO_RULE_SCAN_CELLS cells of that stage's cell --
+ * none further than the reach tile's radius from the robot's own cell --, keeps the one with the best estimate among those
+ * whose term is lower by more than min_drop (term drop minus the tracking cost of moving that stage alone), and evaluates
+ * the current point with the stage displaced to land ORC_HOP_MARGIN cells inside that cell, exactly, twice: (A) block i
+ * changed alone (every later stage shifts with it), (B) block i changed and block i + 1 changed back (only stage i moves).
+ * Candidates compete by objective value; ties go to the lowest lane, A before B.  Returns 1 when one lowered f (u, *f
+ * updated).  A/B hook: orc_set_scan(0) switches it off. */
+static int orc_scan_on = 1;
+void orc_set_scan(int on) { orc_scan_on = on; }
+static long orc_scan_calls = 0, orc_scan_cands = 0, orc_scan_wins = 0;   /* (development statistics; not exact under OpenMP) */
+long orc_get_scan_stat(int k) { return k == 0 ? orc_scan_calls : k == 1 ? orc_scan_cands : orc_scan_wins; }
+static int orc_cell_scan(const orc_ctx* c, int reach, double* u, double* f, double min_drop, int* nfev) {
+  const orc_map* m = c->map;
+  const int n = c->n, nv = 3 * n, R = NEO_RULE_SCAN_CELLS, W = 2 * R + 1, ncell = W * W - 1;
+  double px[ORC_MAXN], py[ORC_MAXN], pcs[ORC_MAXN], psn[ORC_MAXN];
+  double x = 0.0, y = 0.0, th = 0.0;
+  for (int i = 0; i < n; ++i) {
+    th += u[3 * i + 2] * c->dt;
+    pcs[i] = cos(th); psn[i] = sin(th);
+    x += (u[3 * i] * pcs[i] - u[3 * i + 1] * psn[i]) * c->dt;
+    y += (u[3 * i] * psn[i] + u[3 * i + 1] * pcs[i]) * c->dt;
+    px[i] = x; py[i] = y;
+  }
+  int64_t mx0, my0;
+  orc_world_to_map(m, c->X0, c->Y0, &mx0, &my0);
+  double fbest = *f, best_u[ORC_MAXV], cand[ORC_MAXV];
+  int won = 0;
+  ++orc_scan_calls;
+  *nfev += 2;
+  const int lps = n < ORC_LANES ? ORC_LANES / n : 1;
+  const double idt = 1.0 / c->dt;
+  for (int lane = 0; lane < ORC_LANES; ++lane) {
+    const int i = lane / lps, sct = lane % lps;
+    if (i >= n) continue;
+    const double X = c->X0 + (c->c0 * px[i] - c->s0 * py[i]), Y = c->Y0 + (c->s0 * px[i] + c->c0 * py[i]);
+    int64_t mx, my;
+    orc_world_to_map(m, X, Y, &mx, &my);
+    const double fx = (X - m->origin_x) * (1.0 / m->resolution) - (double)mx, fy = (Y - m->origin_y) * (1.0 / m->resolution) - (double)my;
+    const double here = orc_term_at(c, mx, my);
+    const double ex = c->cx - px[i], ey = c->cy - py[i];
+    double best_score = 0.0, brx = 0.0, bry = 0.0;
+    int have = 0;
+    for (int cc = sct; cc < ncell; cc += lps) {
+      const int c2 = cc < ncell / 2 ? cc : cc + 1, dy = c2 / W - R, dx = c2 - (dy + R) * W - R;
+      if (llabs(mx + dx - mx0) > reach || llabs(my + dy - my0) > reach) continue;
+      const double there = orc_term_at(c, mx + dx, my + dy);
+      if (!(here - there > min_drop)) continue;
+      /* the nearest point of that cell, ORC_HOP_MARGIN cells inside it (cells, relative to the stage) */
+      const double gx = dx < 0 ? (double)(dx + 1) - fx - ORC_HOP_MARGIN : dx > 0 ? (double)dx - fx + ORC_HOP_MARGIN : 0.0;
+      const double gy = dy < 0 ? (double)(dy + 1) - fy - ORC_HOP_MARGIN : dy > 0 ? (double)dy - fy + ORC_HOP_MARGIN : 0.0;
+      const double wx = gx * m->resolution, wy = gy * m->resolution;
+      const double rx = c->c0 * wx + c->s0 * wy, ry = -c->s0 * wx + c->c0 * wy;      /* rollout frame */
+      const double score = (here - there) - c->wt_n * (rx * rx + ry * ry - 2.0 * (rx * ex + ry * ey));
+      if (!have || score > best_score) { have = 1; best_score = score; brx = rx; bry = ry; }
+    }
+    if (!have) continue;
+    for (int type = 0; type < 2; ++type) {
+      if (type == 1 && i == n - 1) continue;
+      memcpy(cand, u, sizeof(double) * nv);
+      double b[3] = {u[3 * i] + (pcs[i] * brx + psn[i] * bry) * idt, u[3 * i + 1] + (-psn[i] * brx + pcs[i] * bry) * idt, u[3 * i + 2]};
+      orc_project(c, b);
+      cand[3 * i] = b[0]; cand[3 * i + 1] = b[1];
+      if (type == 1) {
+        const int j = i + 1;
+        double b2[3] = {u[3 * j] - (pcs[j] * brx + psn[j] * bry) * idt, u[3 * j + 1] - (-psn[j] * brx + pcs[j] * bry) * idt, u[3 * j + 2]};
+        orc_project(c, b2);
+        cand[3 * j] = b2[0]; cand[3 * j + 1] = b2[1];
+      }
+      const double fc = orc_eval(c, cand);
+      ++orc_scan_cands;
+      if (fc < fbest) { fbest = fc; won = 1; memcpy(best_u, cand, sizeof(double) * nv); }
+    }
+  }
+  if (won) { memcpy(u, best_u, sizeof(double) * nv); *f = fbest; ++orc_scan_wins; }
+  return won;
 }
 
 /* test hook: the direction of one iteration of the next orc_pg_solve call (single-threaded use) */
@@ -1289,7 +1369,10 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
   int blocked_run = 0;   /* consecutive iterations not won by a decent Newton step */
   int exact_step = 0;    /* this iteration's stage-wise direction carries the second-order terms */
   int nblocked = 1;      /* consecutive iterations not won by a Newton step of at least half its length */
-  for (it = 0; it < max_it; ++it) {
+  int scanned = 0;   /* the cell scan has had its turn */
+  it = 0;
+resume_search:
+  for (; it < max_it; ++it) {
     orc_grad_smooth(&c, u, gs);
     orc_reduce(&c, u, gs, gt, gr, &act);
     double hop[ORC_MAXN][2];
@@ -1524,31 +1607,17 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
   exit_check:
     break;
   }
-  /* (round 4) Dense direction: a search that has ENDED looks once for a cheaper costmap cell a hop away (the hop
-   * candidates the stage-wise direction tries in every iteration, orc_hops): a search that closed in on a cell edge from
-   * the expensive side ends a millimetre short of a cost step no descent direction sees (held-out set "a", w_costmap /
-   * w_trans = 0.08: one such step is worth 2e-3).  A hop that lowers the objective is taken; the search is not taken up
-   * again (restarting it gains 7e-6 per instance on average and lengthens the slowest searches of a launch by two
-   * iterations).  Skipped when no stage of the iterate has a costmap term under it: nothing is cheaper next door. */
-  if (newton && !riccati && orc_hops_on && orc_exit_hops && status == NEO_MPC_STATUS_CONVERGED && orc_term_sum(&c, u) != 0.0) {
-    double hop2[ORC_MAXN][2];
-    uint8_t has2[ORC_MAXN];
-    if (orc_hops(&c, u, rules.hop_min_drop, hop2, has2)) {
-      double fbest = f;
-      int ibest = -1;
-      double bb[3] = {0, 0, 0};
-      for (int i = 0, k = 0; i < n && k < ORC_HOP_LANES; ++i) {
-        if (!has2[i]) continue;
-        ++k;
-        memcpy(cand, u, sizeof(double) * nv);
-        double b[3] = {u[3 * i] + hop2[i][0], u[3 * i + 1] + hop2[i][1], u[3 * i + 2]};
-        orc_project(&c, b);
-        cand[3 * i] = b[0]; cand[3 * i + 1] = b[1];
-        const double fc = orc_eval(&c, cand);
-        if (fc < fbest) { fbest = fc; ibest = i; bb[0] = b[0]; bb[1] = b[1]; }
-      }
-      ++nfev;
-      if (ibest >= 0) { u[3 * ibest] = bb[0]; u[3 * ibest + 1] = bb[1]; f = fbest; }
+  /* (round 5) Second-order directions: a search that has ENDED looks once at the costmap cells around every stage
+   * (orc_cell_scan; it takes the place of round 4's exit hop of the dense direction, whose candidates are among its own).
+   * Skipped when no stage of the iterate has a costmap term under it.  Behind a scan that gained more than opt_tolerance the
+   * search is taken up again: the other blocks have a new neighbour to adjust to. */
+  if (orc_scan_on && newton && status == NEO_MPC_STATUS_CONVERGED && !scanned && orc_term_sum(&c, u) != 0.0) {
+    scanned = 1;
+    const double f_before = f;
+    if (orc_cell_scan(&c, neo_rules_reach_cells(p, m->resolution), u, &f, rules.hop_min_drop, &nfev) &&
+        f_before - f > rules.scan_resume_gain && it < max_it) {
+      status = NEO_MPC_STATUS_MAX_ITER; stall = 0; final = 0; blocked_run = 0; nblocked = 1; gain1 = INFINITY; gain2 = INFINITY;
+      goto resume_search;
     }
   }
   memcpy(x_out, u, sizeof(double) * nv);

@@ -380,19 +380,24 @@ def test_g3_n32_unique_minimisers(method):
 
 
 def test_hop_candidates_never_hurt_and_find_the_cheaper_cell():
-    """The hop lanes of the stage-wise direction (orc_hops / costmap.h): switched off, the same problems end at the
-    same or a higher objective -- and the two G9 cases that sit a millimetre from a cheaper cell end 3.5e-3 and 1.7e-3
-    above the reference's SLSQP value."""
+    """The hop lanes of the stage-wise direction (orc_hops / costmap.h): switched off -- and the cell scan behind the search
+    (orc_cell_scan / cell_scan.h, round 5) with them --, the same problems end at the same or a higher objective, and the
+    two G9 cases that sit a millimetre from a cheaper cell end 3.5e-3 and 1.7e-3 above the reference's SLSQP value.  The
+    cell scan alone (hop lanes off) rescues both as well: its candidates include the hop's."""
     lib = c_oracle.load()
     g, params, probs, hm = util.solve_group("g9_solves_pydefaults.npz", "n3_")
     cmap = (g["cells"],) + tuple(g["map_meta"])
     on = _cold_solve(params, cmap, probs[hm])[0]
     lib.orc_set_hops(0)
     try:
+        scan_only = _cold_solve(params, cmap, probs[hm])[0]
+        lib.orc_set_scan(0)
         off = _cold_solve(params, cmap, probs[hm])[0]
     finally:
         lib.orc_set_hops(1)
+        lib.orc_set_scan(1)
     assert ((off["cost"] - g["f_loose"][hm]) > 1e-3).sum() == 2 and ((on["cost"] - g["f_loose"][hm]) <= 1e-3).all()
+    assert ((scan_only["cost"] - g["f_loose"][hm]) <= 1e-3).all()
     assert (on["cost"] <= off["cost"] + 1e-9).mean() >= 0.95
 
 

@@ -10,8 +10,8 @@ text = open("/tmp/asm_profile.s").read().split("\n")
 start = next(i for i, l in enumerate(text) if l.startswith("_Z") and key in l and ":" in l)
 end = next(i for i in range(start, len(text)) if ".amdhsa_kernel" in text[i])
 src = open(os.path.join(root, "neo_mpc_planner2_amd/csrc/neo_mpc_kernels.hip")).read().split("\n")
-lo = next(i for i, l in enumerate(src, 1) if "for (it = 0; it < p.max_it; ++it)" in l)
-hi = next(i for i, l in enumerate(src, 1) if i > lo and "if (a.solution && p.max_it" in l)
+lo = next(i for i, l in enumerate(src, 1) if "for (; it < p.max_it; ++it)" in l)
+hi = next(i for i, l in enumerate(src, 1) if i > lo and "a search that has ENDED" in l)
 body = text[start:end]
 spill_regs = collections.Counter(re.search(r"v_writelane_b32 (v\d+),", l).group(1) for l in body if "v_writelane_b32" in l)
 regs = set(spill_regs)
