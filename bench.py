@@ -307,23 +307,37 @@ def valu_issue(entry, k_ms):
 
 
 def roofline(workload, batch, n, k_ms, launches_timed=None, params_over=None):
-    """The HBM object the north star asks for + what actually limits the kernel.  `achieved` = algorithmic bytes per launch
-    over the kernel's mean duration; `traffic` = HBM bytes per launch from the committed PMC passes, CORRECTED with the
-    calibration of the counters on K1's own access shapes (tools/mb_k1_traffic.hip; raw FETCH_SIZE / WRITE_SIZE beside it)."""
+    """The roofline object of K1, named after the resource that binds it: VALU issue -- `achieved` = the
+    launch's vector instructions priced in issue cycles (valu_issue(): the mean of the low and high pricing) over the kernel's
+    mean duration, `peak` = 1024 SIMDs x the clock measured in the PMC pass.  The HBM object the north star asks for rides
+    inside as `hbm`: `achieved` = algorithmic bytes per launch over the kernel's mean duration; `traffic` = HBM bytes per
+    launch from the committed PMC passes, CORRECTED with the calibration of the counters on K1's own access shapes
+    (tools/mb_k1_traffic.hip; raw FETCH_SIZE / WRITE_SIZE beside it).  Without a PMC pass of this build (stale sources, other
+    parameter set) there is no instruction count to price: `bound` falls back to "hbm" and the HBM figures are the object."""
     algo = ALGO_BYTES.get(n, (17 + 3 * n) * 4 + (3 + 3 * n + 1) * 4 + 729)
     achieved = algo * batch / (k_ms * 1e-3) / 1e9
     entry, note = pmc_entry(workload, batch) if not params_over else (None, "other parameter set")
-    r = {"bound": "hbm", "limiting": "valu_issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_note": note, "kernel": "k_solve", "kernel_ms": k_ms,
-         "algorithmic_bytes_per_solve": algo}
+    h = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_note": note, "algorithmic_bytes_per_solve": algo}
+    if entry:
+        h["traffic"] = entry.get("hbm_bytes_calibrated") or entry.get("hbm_bytes")
+        h["traffic_raw"] = entry.get("hbm_bytes")
+        h["traffic_note"] = ("calibrated: " + entry["calibration_note"]) if entry.get("hbm_bytes_calibrated") else \
+            ("raw counters (no calibration entry): " + str(entry.get("note")))
+        h["traffic_over_algorithmic"] = h["traffic"] / (algo * batch) if h["traffic"] else None
+    v = valu_issue(entry, k_ms)
+    if v:
+        peak = v["simds"] * v["clock_ghz"]
+        r = {"bound": "valu_issue", "achieved": v["frac"] * peak, "peak": peak, "unit": "G issue-cycles/s", "frac": v["frac"],
+             "frac_low": v["frac_low"], "frac_high": v["frac_high"],
+             "what": "vector instructions per launch priced in issue cycles by class (bench.VALU_CYCLES; untyped ones at 2 and "
+                     "at 4: frac_low / frac_high) over the kernel's duration, against 1024 SIMDs x the measured clock"}
+    else:
+        r = {k: h[k] for k in ("bound", "achieved", "peak", "unit", "frac")}
+        r["what"] = "no PMC pass of this build and workload to price the instruction stream with (%s): HBM figures" % note
+    r.update({"traffic": h["traffic"], "traffic_note": h["traffic_note"], "kernel": "k_solve", "kernel_ms": k_ms, "hbm": h})
     if launches_timed is not None:
         r["kernel_ms_launches_timed"] = launches_timed
-    if entry:
-        r["traffic"] = entry.get("hbm_bytes_calibrated") or entry.get("hbm_bytes")
-        r["traffic_raw"] = entry.get("hbm_bytes")
-        r["traffic_note"] = ("calibrated: " + entry["calibration_note"]) if entry.get("hbm_bytes_calibrated") else \
-            ("raw counters (no calibration entry): " + str(entry.get("note")))
-        r["traffic_over_algorithmic"] = r["traffic"] / (algo * batch) if r["traffic"] else None
     return r, entry
 
 

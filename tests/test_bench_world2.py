@@ -34,7 +34,7 @@ def test_two_ranks_on_one_device_gather_every_ranks_commands():
     slowest = max(p["ms_per_step"] for p in r["per_rank"])
     assert abs(d["ms_per_step"] - slowest) <= 1e-6 * slowest
     assert abs(d["value"] - 2 * 4096 / (1e-3 * d["ms_per_step"])) <= 1e-6 * d["value"]
-    assert d["solver"]["converged_frac"] == 1.0 and "valu_issue" in d and d["roofline"]["limiting"] == "valu_issue"
+    assert d["solver"]["converged_frac"] == 1.0 and "valu_issue" in d and d["roofline"]["hbm"]["bound"] == "hbm"
 
 
 def test_c4_shards_split_as_design_section_6_says():

@@ -943,7 +943,12 @@ def test_bench_emits_the_contract_line():
     assert rec["n_gpus"] == 1 and rec["higher_is_better"] is True and rec["vs_baseline"] is None
     assert rec["dtype"] == "f64" and rec["data"] == "synthetic" and rec["config"]["workload"].startswith("C2")
     r = rec["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # named after the resource that binds K1 (VALU issue) when a PMC pass of this build prices the instruction stream, the
+    # HBM object otherwise -- and the HBM object rides inside either way
+    assert r["bound"] in ("valu_issue", "hbm") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    h = r["hbm"]
+    assert h["bound"] == "hbm" and h["unit"] == "GB/s" and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-12
+    assert r["bound"] == "hbm" or (0.05 < r["frac_low"] <= r["frac"] <= r["frac_high"] < 1.2)
     assert abs(rec["value"] - 4096 * 5 / (rec["ms_per_step"] * 5e-3)) / rec["value"] < 1e-9
     assert rec["value"] > 1e6            # the north star's floor on one MI355X
     assert rec["solver"]["converged_frac"] == 1.0 and rec["solver"]["status_max_iter"] == 0
