@@ -595,12 +595,31 @@ def main():
     # (every settle launch is the SAME cold solve as a timed step -- the sets are put back to the cold state before they are
     # used again -- so a kernel trace or a counter pass over this command averages one workload, not a mix with warm starts)
     settle_launches = 0
+    value_unsettled = None
     if args.settle_ms > 0:
         def cold_again():
             for b in warm_sets:
                 b.states.copy_(base.states)
                 b.warm.copy_(base.warm)
             torch.cuda.synchronize()
+        if not use_dist and not args.no_others:
+            # what the same command read WITHOUT the settle -- W warm-up steps, K timed steps, as rounds 1-3 reported it --,
+            # kept beside the headline so that rounds stay comparable (`settle.value_without`); every set is put back to
+            # its cold state afterwards
+            for i in range(args.warmup):
+                b = warm_sets[i % len(warm_sets)]
+                solver.solve_device(base.problems, b.states, b.warm, b.commands, velocities=b.vel)
+            torch.cuda.synchronize()
+            t_u = time.perf_counter()
+            for i in range(args.steps):
+                b = sets[i]
+                solver.solve_device(base.problems, b.states, b.warm, b.commands, velocities=b.vel)
+            torch.cuda.synchronize()
+            value_unsettled = cfg["batch"] * args.steps / (time.perf_counter() - t_u)
+            for b in sets:
+                b.states.copy_(base.states)
+                b.warm.copy_(base.warm)
+            cold_again()
         t_settle = time.perf_counter()
         while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
             cold_again()
@@ -676,8 +695,10 @@ def main():
                        if world > 1 else "single GPU"},
             "roofline": roof,
             "valu_issue": valu_issue(pmc, k_ms),
-            "settle": {"ms": args.settle_ms, "launches": settle_launches,
-                       "what": "untimed launches ahead of the W warm-up steps: the clock ramp after idle (--settle-ms 0: off)"},
+            "settle": {"ms": args.settle_ms, "launches": settle_launches, "value_without": value_unsettled,
+                       "what": "untimed launches ahead of the W warm-up steps: the clock ramp after idle (--settle-ms 0: off); "
+                               "value_without = W warm-up and K timed steps BEFORE the settle, "
+                               "as rounds 1-3 reported the metric"},
             **({"study_streams": args.streams} if args.streams > 1 else {}),
             "solver": {"mean_iterations": float(cmds["iterations"].mean()),
                        "max_iterations_seen": int(cmds["iterations"].max()),

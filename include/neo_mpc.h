@@ -48,8 +48,14 @@ extern "C" {
  *      field by field (old_goal only when it changed).  Blocks in a corner of the feasible set that a Newton step sends
  *      outward are pinned and the direction is computed once more; the closing-in stop rule of the dense / L-BFGS
  *      directions waits for two blocked iterations; a step below opt_tolerance ends the search only if it won its iteration.
+ *   5  (round 5) cell scan in place of the dense direction's exit hop, in every direction: a search that has ended looks
+ *      at the costmap cells around every stage (up to 3 cells away, inside the reach of a feasible rollout), evaluates the
+ *      cheapest ones as candidates and is taken up again once when that gained more than opt_tolerance.  A pinned LBFGS /
+ *      NEWTON direction that a neo_mpc_set_params call takes across w_costmap = w_trans / 4 runs the stage-wise
+ *      direction from there on (neo_mpc_effective_method) instead of failing the reconfigure; neo_mpc_create still
+ *      refuses the combination.  neo_mpc_problem.skip: host batches with values other than 0 / 1 are refused.
  * method = NEO_MPC_METHOD_NEWTON / _LBFGS / _RICCATI pins a direction. */
-#define NEO_MPC_BEHAVIOUR_VERSION 4
+#define NEO_MPC_BEHAVIOUR_VERSION 5
 
 /* return codes */
 #define NEO_MPC_OK 0
@@ -89,7 +95,10 @@ extern "C" {
                                    gradient, one column per lane); control_steps <= 8 */
 /* (LBFGS and NEWTON have no wall model for costmap steps: with w_costmap > w_trans / 4 -- where AUTO hands every
  * control_steps to the stage-wise direction -- they end above the reference's SLSQP on a few percent of the costmap cases
- * (G8 "turn", G9), so neo_mpc_create / neo_mpc_set_params refuse that combination with NEO_MPC_ERR_UNSUPPORTED) */
+ * (G8 "turn", G9), so neo_mpc_create refuses that combination with NEO_MPC_ERR_UNSUPPORTED; a LIVE handle reconfigured
+ * across the threshold (neo_mpc_set_params = cb_params, which cannot fail in the reference) keeps working: it runs the
+ * stage-wise direction while the weights stay there -- neo_mpc_get_params still returns the pinned method,
+ * neo_mpc_effective_method what runs) */
 #define NEO_MPC_METHOD_RICCATI 3 /* projected Gauss-Newton, solved stage by stage (Riccati recursion over the
                                    rollout chain, 3x3 blocks, float32): any control_steps, O(control_steps)
                                    per iteration; beyond 8 control steps with adaptive Levenberg-Marquardt
@@ -153,10 +162,12 @@ typedef struct neo_mpc_problem {
                               ignored with a single costmap */
   int32_t switch_opt;      /* request.switch_opt = closer_to_goal (cpp:245); the reference stores it (py:354)
                               and never reads it -- carried so that the record is the request field for field */
-  int32_t skip;            /* != 0: this robot makes NO request this tick -- the plugin threw before its service call
+  int32_t skip;            /* 1: this robot makes NO request this tick -- the plugin threw before its service call
                               (footprint cost 255, cpp:234-236; neo_mpc_select_carrots sets it with every non-zero carrot
-                              status): the solver leaves the robot's state and warm start alone (NEO_MPC_FLAG_SKIPPED) */
-  int32_t reserved_i;
+                              status): the solver leaves the robot's state and warm start alone (NEO_MPC_FLAG_SKIPPED).
+                              Must be 0 or 1: the host entry points refuse anything else (NEO_MPC_ERR_INVALID_ARGUMENT;
+                              the field was reserved[0] in ABI 1), the device entry points act on 1 alone */
+  int32_t reserved_i;      /* reserved fields MUST be zero */
   double reserved[5];      /* (never read by the device: a request is 216 bytes on the wire) */
 } neo_mpc_problem;
 
@@ -169,8 +180,13 @@ typedef struct neo_mpc_state {
   int32_t has_old_goal;        /* 0 before the first call: py:146 compares PoseStamped with Pose */
   int32_t collision;           /* py:148 latch */
   int32_t collision_footprint; /* py:149 */
-  int32_t reserved_i;
-  double reserved[3];
+  int32_t has_prev_u0;         /* (was reserved_i) 1: prev_u0 holds ... */
+  double prev_u0[3];           /* (was reserved[3]) ... the previous solve's first control block as the solver left it, before
+                                  the low-pass of py:366-367 -- the node has no such attribute: it is the build's own hint
+                                  (behaviour version 5), written by every solve / postprocess call and read by the next
+                                  solve, which un-shifts the warm start with it.  It never changes
+                                  what a result means: the point only competes by objective value; zeros (a fresh or an
+                                  ABI-1 caller's record) and garbage are harmless */
 } neo_mpc_state;
 
 /* Optimizer.srv response (`output_vel.twist`, py:375-377, 389-391) + diagnostics.  48 bytes. */
@@ -269,6 +285,10 @@ void neo_mpc_destroy(neo_mpc_handle* handle);
 /* Dynamic reconfigure (`cb_params`, py:405-439).  Unlike the reference every field takes effect. */
 int neo_mpc_set_params(neo_mpc_handle* handle, const neo_mpc_params* params);
 int neo_mpc_get_params(const neo_mpc_handle* handle, neo_mpc_params* params);
+/* The direction the handle's solves run: NEO_MPC_METHOD_LBFGS / _NEWTON / _RICCATI (never AUTO) -- what AUTO resolved to,
+ * or the stage-wise direction in place of a pinned LBFGS / NEWTON above w_costmap = w_trans / 4 (see NEO_MPC_METHOD_*);
+ * < 0 on a null handle. */
+int neo_mpc_effective_method(const neo_mpc_handle* handle);
 
 /* Replaces the node's `Costmap2d(self)` subscription (py:118): raw nav2 costs, row-major
  * cells[my*size_x + mx] (e.g. `costmap_->getCharMap()` in the plugin).  The data is copied before the

@@ -38,8 +38,8 @@ STATE_DTYPE = np.dtype([
     ("has_old_goal", "<i4"),        # 0 until the first call (py:146 PoseStamped != Pose)
     ("collision", "<i4"),           # py:148 latch
     ("collision_footprint", "<i4"), # py:149
-    ("reserved_i", "<i4"),
-    ("reserved", "<f8", (3,)),
+    ("has_prev_u0", "<i4"),           # the build's own hint (no node attribute): 1 = prev_u0 is there
+    ("prev_u0", "<f8", (3,)),         # ... the previous solve's first control block before the low-pass (py:366-367)
 ], align=False)
 assert STATE_DTYPE.itemsize == 128
 

@@ -124,7 +124,7 @@ constexpr size_t kLatencyPathBytes = kLatencyPathMaxCount * (sizeof(neo_mpc_prob
 
 namespace {
 
-int validate(const neo_mpc_params& p) {
+int validate(const neo_mpc_params& p, bool live_handle) {
   if (p.control_steps < 1 || p.control_steps > NEO_MPC_MAX_CONTROL_STEPS)
     return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "control_steps %d outside [1, %d]", p.control_steps,
                 NEO_MPC_MAX_CONTROL_STEPS);
@@ -149,7 +149,9 @@ int validate(const neo_mpc_params& p) {
   // no selectable configuration is knowingly worse than the reference: the L-BFGS and the dense Newton direction have no
   // wall model for costmap steps, and forced onto a heavy costmap weight they end above SLSQP on a few percent of the
   // costmap cases (G8 "turn": up to 1.0 at control_steps 8; G9: 2 of 48 up to 4e-3) -- AUTO never sends them there
-  if ((p.method == NEO_MPC_METHOD_LBFGS || p.method == NEO_MPC_METHOD_NEWTON) && p.w_costmap > 0.25 * p.w_trans)
+  // (neo_mpc_create refuses; a live handle reconfigured across the threshold runs the stage-wise direction instead --
+  // cb_params cannot fail in the reference, and a controller must not lose its solver to a weight change: solver_rules.h)
+  if (!live_handle && (p.method == NEO_MPC_METHOD_LBFGS || p.method == NEO_MPC_METHOD_NEWTON) && p.w_costmap > 0.25 * p.w_trans)
     return fail(NEO_MPC_ERR_UNSUPPORTED, "method %d has no wall model for costmap steps: not offered with w_costmap > w_trans / 4 "
                 "(%g > %g); use NEO_MPC_METHOD_AUTO or NEO_MPC_METHOD_RICCATI", p.method, p.w_costmap, 0.25 * p.w_trans);
   return NEO_MPC_OK;
@@ -261,8 +263,8 @@ int upload_term_table(neo_mpc_handle* h) {
   return NEO_MPC_OK;
 }
 
-int apply_params(neo_mpc_handle* h, const neo_mpc_params* params) {
-  int rc = validate(*params);
+int apply_params(neo_mpc_handle* h, const neo_mpc_params* params, bool live_handle) {
+  int rc = validate(*params, live_handle);
   if (rc) return rc;
   h->params = *params;
   derive(h);
@@ -490,7 +492,7 @@ neo_mpc_handle* neo_mpc_create(const neo_mpc_params* params, int device) {
     h->auto_host_path = !e ? NEO_MPC_HOST_PATH_ZEROCOPY : !strcmp(e, "staged") ? NEO_MPC_HOST_PATH_STAGED
                         : !strcmp(e, "zerocopy_out") ? NEO_MPC_HOST_PATH_ZEROCOPY_OUT : NEO_MPC_HOST_PATH_ZEROCOPY;
   }
-  if (apply_params(h, params) != NEO_MPC_OK) { neo_mpc_destroy(h); return nullptr; }
+  if (apply_params(h, params, false) != NEO_MPC_OK) { neo_mpc_destroy(h); return nullptr; }
   return h;
 }
 
@@ -517,7 +519,13 @@ void neo_mpc_destroy(neo_mpc_handle* h) {
 int neo_mpc_set_params(neo_mpc_handle* h, const neo_mpc_params* params) {
   if (!h || !params) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "null argument");
   HIP_TRY(hipSetDevice(h->device));
-  return apply_params(h, params);
+  return apply_params(h, params, true);
+}
+
+int neo_mpc_effective_method(const neo_mpc_handle* h) {
+  if (!h) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "null handle");
+  const int d = neo_rules_direction(&h->params);
+  return d == NEO_DIRECTION_LBFGS ? NEO_MPC_METHOD_LBFGS : d == NEO_DIRECTION_DENSE ? NEO_MPC_METHOD_NEWTON : NEO_MPC_METHOD_RICCATI;
 }
 
 int neo_mpc_get_params(const neo_mpc_handle* h, neo_mpc_params* params) {
@@ -782,11 +790,23 @@ static int solve_batch_staged_chunks(neo_mpc_handle* h, const neo_mpc_batch* b) 
   return NEO_MPC_OK;
 }
 
+// neo_mpc_problem.skip was reserved[0] in ABI 1, whose header never asked for zeroed reserved bytes: a host batch whose
+// skip fields hold anything but 0 or 1 is refused instead of having robots silently left out (one int per record; device
+// batches cannot be scanned -- K1 and K2 act on skip == 1 alone there).
+static int check_skip_fields(const neo_mpc_batch* batch) {
+  for (size_t i = 0; i < batch->count; ++i)
+    if ((uint32_t)batch->problems[i].skip > 1u)
+      return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "problems[%zu].skip = %d: must be 0 or 1 (reserved fields must be zeroed)", i,
+                  batch->problems[i].skip);
+  return NEO_MPC_OK;
+}
+
 int neo_mpc_solve_batch(neo_mpc_handle* h, const neo_mpc_batch* batch) {
   SolveArgs a;
   int rc = fill_args(h, batch, a);  // validates
   if (rc) return rc;
   if (batch->count == 0) return NEO_MPC_OK;
+  if ((rc = check_skip_fields(batch))) return rc;
   HIP_TRY(hipSetDevice(h->device));
   if (batch->count <= kLatencyPathMaxCount && !batch->footprints)
     return solve_batch_latency_path(h, batch);
@@ -821,6 +841,7 @@ int neo_mpc_solve_batch_begin(neo_mpc_handle* h, const neo_mpc_batch* batch, uin
   int rc = fill_args(h, batch, a);  // validates
   if (rc) return rc;
   if (batch->count == 0) return NEO_MPC_OK;   // (ticket 0: nothing to wait for)
+  if ((rc = check_skip_fields(batch))) return rc;
   HIP_TRY(hipSetDevice(h->device));
   neo_mpc_batch dv;
   if (!batch_page_locked(h, batch, dv))

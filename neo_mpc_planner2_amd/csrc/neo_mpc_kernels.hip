@@ -71,23 +71,29 @@ constexpr int kLateIteration = NEO_RULE_LATE_ITERATION;
 // (-DNEO_MPC_SEGMENT_TIMING on top: wall-clock stamps at the first and behind the last solver iteration replace
 // the phase clocks of entries 4-5 -- set-up, iterations and K2 of every wave, tools/wave_timeline.py)
 #ifdef NEO_MPC_SEGMENT_TIMING
-#define NEO_SEGMENT_DECL unsigned long long seg_t0 = 0, seg_t1 = 0
+#define NEO_SEGMENT_DECL unsigned long long seg_t0 = 0, seg_t1 = 0, seg_scan = 0, seg_scan_at = 0
 #define NEO_SEGMENT(k) seg_t##k = wall_clock64()
+#define NEO_SEGMENT_SCAN_BEGIN() seg_scan_at = wall_clock64(); seg_scan = seg_scan_at
+#define NEO_SEGMENT_SCAN_END() seg_scan = wall_clock64() - seg_scan
 #define NEO_SEGMENT_DUMP()                                                                          \
-  a.solution[(size_t)b * nv + 4] = (double)seg_t0; a.solution[(size_t)b * nv + 5] = (double)seg_t1
+  a.solution[(size_t)b * nv + 4] = (double)seg_t0; a.solution[(size_t)b * nv + 5] = (double)seg_t1; \
+  a.solution[(size_t)b * nv + 3] = (double)seg_scan; a.solution[(size_t)b * nv + 2] = (double)seg_scan_at
 #else
 #define NEO_SEGMENT_DECL
 #define NEO_SEGMENT(k)
+#define NEO_SEGMENT_SCAN_BEGIN()
+#define NEO_SEGMENT_SCAN_END()
 #define NEO_SEGMENT_DUMP()
 #endif
 #define NEO_WAVE_START const unsigned long long wave_t0 = wall_clock64()
 #define NEO_WAVE_END()                                                                              \
   if (a.solution && lane == 0 && nv >= 9) {                                                        \
-    unsigned int hw_id;                                                                            \
+    unsigned int hw_id, xcc_id;                                                                    \
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));                            \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));                          \
     a.solution[(size_t)b * nv + 6] = (double)wave_t0;                                              \
     a.solution[(size_t)b * nv + 7] = (double)wall_clock64();                                       \
-    a.solution[(size_t)b * nv + 8] = (double)hw_id;                                                \
+    a.solution[(size_t)b * nv + 8] = (double)hw_id + 4294967296.0 * (double)(xcc_id & 15u);        \
     NEO_SEGMENT_DUMP();                                                                            \
   }
 #define NEO_PHASE_DECL long long phase_clock[8]
@@ -100,6 +106,8 @@ constexpr int kLateIteration = NEO_RULE_LATE_ITERATION;
 #define NEO_WAVE_END()
 #define NEO_SEGMENT_DECL
 #define NEO_SEGMENT(k)
+#define NEO_SEGMENT_SCAN_BEGIN()
+#define NEO_SEGMENT_SCAN_END()
 #define NEO_PHASE_DECL
 #define NEO_PHASE(k)
 #define NEO_PHASE_DUMP()
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     load_records(a, L, b, lane);
     // no request for this robot this tick (the plugin threw before its service call, cpp:234-236; K4 status 3): the node's
     // state does not advance: state record and warm start keep their bytes, the outputs say "skipped" (rollout.h)
-    if (uniform_int(reinterpret_cast<const int*>(L + a.lds.prob)[PI_SKIP]) != 0) { skip_instance(a, b, lane); return; }
+    if (uniform_int(reinterpret_cast<const int*>(L + a.lds.prob)[PI_SKIP]) == 1) { skip_instance(a, b, lane); return; }
     select_map(a.map, L + a.lds.prob);
     flags = reset_and_warm(a, L, b, lane) ? NEO_MPC_FLAG_RESET : 0;
     fcost = footprint_cost(a, L, b, lane);
@@ -244,19 +252,40 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     for (int k = 0; k < nv; ++k) cold = cold && (u[k] == 0.0);
     ctx_from_lds<false>(a, L, c);
     // The warm start is the previous solution shifted by a WHOLE control step (py:198-202: block i <- block i + 1, the
-    // filtered first control last) although only one control interval -- an eighth of a step at 30 Hz and the README's
-    // horizon -- has passed: the previous solution itself, i.e. the shift undone, [w_{N-1}, w_0, ..., w_{N-2}], is usually
-    // much closer to this tick's minimiser.  In free space (no costmap term under either rollout: one basin) the search
-    // starts from whichever of the two has the lower objective (lane 0 rolls out the warm start, lane 1 the unshifted
-    // one); on the costmap it starts where the reference starts.  The warm start handed BACK is the reference's shift as
-    // ever (K2).  Closed loop of 4096 robots: 6.2 -> 4.2 iterations per warm tick.
+    // FILTERED first control last, py:366-367) although only one control interval -- an eighth of a step at 30 Hz and the
+    // README's horizon -- has passed: the previous solution itself, i.e. the shift undone with the first block as the solver
+    // left it (kept in the state record by K2: S_PREV_U0; the filtered one where a caller's record does not carry it), is
+    // usually much closer to this tick's minimiser -- and IS the minimiser for a robot the collision latch has stopped.
+    // In free space (no costmap term under either rollout: one basin) the search starts from whichever of the two has the
+    // lower objective (lane 0 rolls out the warm start, lane 1 the un-shifted one).  On the costmap it starts where the
+    // reference starts, and the un-shifted point, when it has the lower objective, is ONE CANDIDATE of the first iteration
+    // (lane kAltLane, competing by objective value like every other lane: it wins where the problem has not changed, and loses
+    // to the first step from the reference's start where that leads into another basin -- starting from it outright ended one
+    // recorded call of the reference 1.9e-3 above it).  The warm start handed BACK is the reference's shift as ever (K2).
+    // Closed loop of 4096 robots (CPU mirror): 6.2 -> 4.45 -> 3.6 iterations per warm tick, per-tick maximum 13 -> 10.
+#ifndef NEO_AB_NO_ALT_SETUP   // (study build)
+    {
+      double* S = L + a.lds.state;
+      int* Si = reinterpret_cast<int*>(S);
+      const bool has_prev = uniform_int(Si[SI_HAS_PREV]) == 1 && !(flags & NEO_MPC_FLAG_RESET);
+      WAVE_SYNC();
+      if (lane == 0) {
+        double q0 = has_prev ? S[S_PREV_U0] : u[nv - 3], q1 = has_prev ? S[S_PREV_U0 + 1] : u[nv - 2], q2 = has_prev ? S[S_PREV_U0 + 2] : u[nv - 1];
+        project_block<kTame>(p, q0, q1, q2);
+        S[S_PREV_U0] = q0; S[S_PREV_U0 + 1] = q1; S[S_PREV_U0 + 2] = q2;
+        Si[SI_HAS_PREV] = 0;
+      }
+      WAVE_SYNC();
+    }
+#endif
     if (!cold && n > 1 && !(p.compat & kCompatNoUnshift) && p.max_it < kDumpGradient) {   // (not in the test hooks: they dump AT the given point)
+      const double* A0 = L + a.lds.state + S_PREV_U0;
       double ts = 0.0;
       const double fs = rollout_cost<kSteps, kTame, kCovered>(
           a, c, L,
           [&](int i, double& b0, double& b1, double& b2) {
-            const int src = lane == 1 ? (i == 0 ? n - 1 : i - 1) : i;
-            b0 = u[3 * src]; b1 = u[3 * src + 1]; b2 = u[3 * src + 2];
+            const double* src = lane == 1 ? (i == 0 ? A0 : u + 3 * (i - 1)) : u + 3 * i;
+            b0 = src[0]; b1 = src[1]; b2 = src[2];
           },
           NoRecord(), &ts);
       const double f_warm = lane_value(fs, 0), f_alt = lane_value(fs, 1);
@@ -264,13 +293,15 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       if (f_alt < f_warm && free_both) {
         double v0 = 0.0, v1 = 0.0, v2 = 0.0;   // (nv <= 192: up to three elements per lane)
         const int k0 = lane, k1 = lane + kLanes, k2 = lane + 2 * kLanes;
-        if (k0 < nv) v0 = u[k0 >= 3 ? k0 - 3 : k0 + nv - 3];
+        if (k0 < nv) v0 = k0 >= 3 ? u[k0 - 3] : A0[k0];
         if (k1 < nv) v1 = u[k1 - 3];
         if (k2 < nv) v2 = u[k2 - 3];
         WAVE_SYNC();
         if (k0 < nv) u[k0] = v0;
         if (k1 < nv) u[k1] = v1;
         if (k2 < nv) u[k2] = v2;
+      } else if (f_alt < f_warm && lane == 0) {
+        reinterpret_cast<int*>(L + a.lds.state)[SI_HAS_PREV] = kAltArmed;
       }
       WAVE_SYNC();
     }
@@ -547,6 +578,12 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       if (ft < f && f - ft >= kTrialRatio * pred) { took_trial = true; fb = ft; }
       WAVE_SYNC();
     }
+    // (first iteration only: the set-up armed the un-shifted previous solution as lane kAltLane's candidate)
+    const double* ALT0 = L + a.lds.state + S_PREV_U0;
+    bool alt_armed = false;
+#ifndef NEO_AB_NO_ALT_LANE   // (study build)
+    if (it == 0) alt_armed = uniform_int(reinterpret_cast<const int*>(L + a.lds.state)[SI_HAS_PREV]) == kAltArmed;
+#endif
     if (!took_trial) {
     // hop lanes (Riccati): lane h in 1..nhops tries the current point with the block of hop stage h - 1 changed
     int hop_stage = -1;
@@ -563,7 +600,12 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
           candidate_block<kTame, kRiccati>(a, c, L, lane, step, pstep, i, b0, b1, b2, hop_stage, hop_x, hop_y);
           // (a scalar branch taken in the first iteration only -- the empty asm keeps the compiler from turning it into
           // six selects per block that every iteration pays)
-          if (it == 0) { asm volatile(""); if (lane == 0) { b0 = u[3 * i]; b1 = u[3 * i + 1]; b2 = u[3 * i + 2]; } }
+          if (it == 0) {
+            asm volatile("");
+            if (lane == 0) { b0 = u[3 * i]; b1 = u[3 * i + 1]; b2 = u[3 * i + 2]; }
+            // (the un-shifted previous solution, armed by the set-up on the costmap: block 0 from the state slot)
+            if (lane == kAltLane && alt_armed) { const double* src = i == 0 ? ALT0 : u + 3 * (i - 1); b0 = src[0]; b1 = src[1]; b2 = src[2]; }
+          }
           if (kSteps) { cand[3 * i] = b0; cand[3 * i + 1] = b1; cand[3 * i + 2] = b2; }
         },
         [&](int i, double sn, double cs) {
@@ -578,6 +620,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     }
     ++nfev;
     if (!(fb < f)) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
+    const bool alt_won = alt_armed && best == kAltLane;
     float stepmax = 0.0f;
     if (kSteps && kNewton) {
       // the winner holds its candidate in registers: it measures the step against u and overwrites u
@@ -614,6 +657,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         for (int i = lane; i < n; i += kLanes) {
           double b0, b1, b2;
           candidate_block<kTame, kRiccati>(a, c, L, best, bstep, bpstep, i, b0, b1, b2, bhop, bhx, bhy);
+          if (alt_won) { const double* src = i == 0 ? ALT0 : u + 3 * (i - 1); b0 = src[0]; b1 = src[1]; b2 = src[2]; }
           u_new[3 * i] = b0; u_new[3 * i + 1] = b1; u_new[3 * i + 2] = b2;
         }
       }
@@ -634,7 +678,8 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     stall = (gain <= TOL[T_FTOL] * fscale || (double)stepmax <= TOL[T_STALL]) ? stall + 1 : 0;
     // stage-wise direction: the window and closing-in rules only judge runs of BLOCKED iterations (none of the three won
     // by a Newton step of at least half its length); iterations won by the Newton step end through the step test
-    const bool hop_won = kRiccati && best >= 1 && best <= nhops;
+    // (the un-shifted start that won the first iteration says as little about step lengths as a hop)
+    const bool hop_won = (kRiccati && best >= 1 && best <= nhops) || alt_won;
     nblocked = (best < 32 || lane_value(step, best) < kWindowStep || hop_won) ? nblocked + 1 : 0;
     const bool window_on = !kRiccati || nblocked >= 3;
     // three iterations that together gained less than wtol: creeping along a costmap cell edge
@@ -642,11 +687,22 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     const double wtol = it >= kLateIteration ? TOL[T_WTOL_LATE] : wtol0;
     bool creeping = wtol > 0.0 && gain + gain1 + gain2 <= wtol * fscale && window_on;
     // ... and so does a step below stall_step whose gain halved twice in a row: the search is closing in on a
-    // costmap cell edge (or the kink) geometrically; what is left to gain is less than the last gain
+    // costmap cell edge (or the kink) geometrically; what is left to gain is less than the last gain (in free space three
+    // gains it takes: round 5 -- the INFINITY the two older ones start at used to pass for a gain, and a warm search that began next to the
+    // kink ended after its second iteration, 2.4e-3 from the reference's converged first control on one G13 tick -- and the
+    // geometric series the gains start has to be worth less than the stall threshold, gain r / (1 - r) <= ftol f~ with r =
+    // gain / gain1: 3e-6 left to gain is 2.5e-3 in the first control along a direction of curvature 1)
     // (dense and L-BFGS directions: only behind kClosingRun blocked iterations -- the gains of a Newton search that converges
     // quadratically halve twice in a row as well, and one blocked iteration after them, a bound about to become active, is
     // no sign of creeping: random parameter sets, 1 solve in 3000 stopped 5e-3 short)
+    // (in free space -- where the first control is gated, not only the objective: dense direction: no costmap term under the
+    // NEW iterate's rollout; stage-wise: under the rollout the iteration started from)
+    bool free_now = kRiccati ? free_path : false;
+    if (kNewton) free_now = lane_value(cterm, best) == 0.0;
     creeping = creeping || (wtol0 > 0.0 && (double)stepmax <= TOL[T_STALL] && gain <= 0.5 * gain1 && gain1 <= 0.5 * gain2 &&
+#ifndef NEO_AB_OLD_CLOSING   // (study build)
+                            (!free_now || (gain2 < INFINITY && gain * gain <= TOL[T_FTOL] * fscale * (gain1 - gain))) &&
+#endif
                             (kRiccati ? window_on : nblocked >= kClosingRun));
     // Blocked-run stop rule (dense Newton).  kBlockedRun iterations in a row not won by a decent Newton step that
     // together gain less than 0.1 x opt_tolerance (0.03 x with no costmap term under the new iterate's rollout): something
@@ -710,7 +766,9 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     ctx_from_lds<false>(as, L, cs);
     int ls = lane_id;
     asm volatile("" : "+v"(ls));
+    NEO_SEGMENT_SCAN_BEGIN();
     const bool won = cell_scan<kSteps, kTame, kCovered>(as, cs, L, f, kNewton ? &u_term : nullptr, nfev, ls, kSteps ? kSteps : as.p.n);
+    NEO_SEGMENT_SCAN_END();
     resume = won && f_before - f > as.p.scan_resume_gain && it < as.p.max_it;
 #ifdef NEO_AB_NO_RESUME   // (study build)
     resume = false;
@@ -753,7 +811,7 @@ __global__ __launch_bounds__(kLanes) void k_postprocess(const SolveArgs args) {
   if (b >= a.count) return;
   const int nv = 3 * a.p.n;
   load_records(a, L, b, lane);
-  if (uniform_int(reinterpret_cast<const int*>(L + a.lds.prob)[PI_SKIP]) != 0) { skip_instance(a, b, lane, true); return; }   // (no request this tick: see k_solve)
+  if (uniform_int(reinterpret_cast<const int*>(L + a.lds.prob)[PI_SKIP]) == 1) { skip_instance(a, b, lane, true); return; }   // (no request this tick: see k_solve)
   select_map(a.map, L + a.lds.prob);
   int flags = reset_and_warm(a, L, b, lane) ? NEO_MPC_FLAG_RESET : 0;
   const double fcost = footprint_cost(a, L, b, lane);

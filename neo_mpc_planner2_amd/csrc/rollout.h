@@ -173,6 +173,7 @@ __device__ void postprocess(const SolveArgs& a, const Ctx& c, double* L, uint32_
   }
   // low-pass on the first control, in place (py:366-367)
   const double g = p.low_pass_gain;
+  const double raw0 = x[0], raw1 = x[1], raw2 = x[2];   // (the solution's own first block: next tick's un-shifted start)
   double x0 = x[0] * g + S[S_LAST + 0] * (1 - g);
   double x1 = x[1] * g + S[S_LAST + 1] * (1 - g);
   double x2 = x[2] * g + S[S_LAST + 2] * (1 - g);
@@ -218,6 +219,8 @@ __device__ void postprocess(const SolveArgs& a, const Ctx& c, double* L, uint32_
     for (int k = 0; k < 4; ++k) S[S_OLD_GOAL + 3 + k] = P[P_GOAL_Q + k];
     S[S_WAIT] = waiting;
     Si[SI_HAS_GOAL] = 1; Si[SI_COLLISION] = collision; Si[SI_COLL_FP] = coll_fp;
+    Si[SI_HAS_PREV] = success ? 1 : 0;   // (an un-shifted warm start, py:399-400, has nothing to un-shift)
+    S[S_PREV_U0] = raw0; S[S_PREV_U0 + 1] = raw1; S[S_PREV_U0 + 2] = raw2;
     neo_mpc_command cmd;
     cmd.vel[0] = out0; cmd.vel[1] = out1; cmd.vel[2] = out2;
     cmd.cost = cost; cmd.status = status; cmd.iterations = nit; cmd.evaluations = nfev; cmd.flags = flags;
@@ -225,8 +228,8 @@ __device__ void postprocess(const SolveArgs& a, const Ctx& c, double* L, uint32_
     if (a.velocities) { double* v = a.velocities + 3 * (size_t)b; v[0] = out0; v[1] = out1; v[2] = out2; }
   }
   WAVE_SYNC();
-  // the state goes back field by field: last_control, waiting_time and the flags every tick (48 bytes), old_goal (56
-  // bytes) only when it changed -- py:402 assigns it every call, but between two resets it is the same goal
+  // the state goes back field by field: last_control, waiting_time, the flags and the previous first block every tick
+  // (72 bytes), old_goal (56 bytes) only when it changed -- py:402 assigns it every call, but between two resets it is the same goal
   const bool goal_changed = (flags & NEO_MPC_FLAG_RESET) != 0;
   if (lane < 3 || (lane >= S_WAIT && lane < kStateDoubles) || (goal_changed && lane >= S_OLD_GOAL && lane < S_WAIT))
     reinterpret_cast<double*>(a.states_out + b)[lane] = S[lane];
@@ -280,7 +283,7 @@ __device__ __forceinline__ void select_map(DevMap& m, const double* P) {
   m.origin_y = m.pool_origins[2 * idx + 1];
 }
 
-// (only the fields that exist are read: 216 of the 256 bytes of a request, 104 of the 128 of a state record -- with
+// (only the fields that exist are read: 216 of the 256 bytes of a request; the state record in full -- with
 // page-locked host batches worked on in place these loads cross PCIe)
 __device__ void load_records(const SolveArgs& a, double* L, uint32_t b, int lane) {
   if (lane < kProblemDoubles) L[a.lds.prob + lane] = reinterpret_cast<const double*>(a.problems + b)[lane];

@@ -17,8 +17,13 @@ enum : int {
   PI_MAP_INDEX = 50,  // int32 view of the request record: neo_mpc_problem.map_index
   PI_SKIP = 52,       // ... neo_mpc_problem.skip (no request this tick, cpp:234-236)
   kProblemDoubles = 27,  // what of the 32-double request record the device reads (the rest is reserved)
-  kStateDoubles = 13,    // ... of the 16-double state record
-  S_LAST = 0, S_OLD_GOAL = 3, S_WAIT = 10, SI_HAS_GOAL = 22, SI_COLLISION = 23, SI_COLL_FP = 24
+  kStateDoubles = 16,    // ... of the 16-double state record
+  S_LAST = 0, S_OLD_GOAL = 3, S_WAIT = 10, SI_HAS_GOAL = 22, SI_COLLISION = 23, SI_COLL_FP = 24,
+  // the build's own hint (no counterpart in the node): the previous solve's first control block BEFORE the low-pass
+  // (py:366-367 filters x.x[0:3] in place, so the warm start's last block is the filtered one) and whether it is there.
+  // Inside a solve the LDS copy of the slot holds the first block of the un-shifted start, projected, and
+  // SI_HAS_PREV == kAltArmed says that the un-shifted start is a candidate of the first iteration (k_solve).
+  SI_HAS_PREV = 25, S_PREV_U0 = 13, kAltArmed = 2, kAltLane = 5
 };
 
 // The tolerance block of LDS (LdsLayout::tol, doubles): stop tolerances and cold per-instance constants, read once per

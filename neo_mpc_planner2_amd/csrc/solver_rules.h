@@ -61,10 +61,12 @@ typedef struct neo_rules {
 } neo_rules;
 
 /* AUTO = dense Newton at control_steps 3 unless the costmap weight is heavy (the wall model lives in the stage-wise
- * direction), stage-wise otherwise; NEWTON = dense (control_steps <= 8). */
+ * direction), stage-wise otherwise; NEWTON = dense (control_steps <= 8).  A pinned LBFGS / NEWTON at a heavy costmap weight
+ * (refused by neo_mpc_create; reachable through neo_mpc_set_params on a live handle) runs the stage-wise direction. */
 static inline int neo_rules_direction(const neo_mpc_params* p) {
   const int heavy_costmap = p->w_costmap > 0.25 * p->w_trans;
-  return p->method == NEO_MPC_METHOD_LBFGS ? NEO_DIRECTION_LBFGS
+  return heavy_costmap && p->method != NEO_MPC_METHOD_AUTO ? NEO_DIRECTION_STAGEWISE
+         : p->method == NEO_MPC_METHOD_LBFGS ? NEO_DIRECTION_LBFGS
          : p->method == NEO_MPC_METHOD_NEWTON ? NEO_DIRECTION_DENSE
          : p->method == NEO_MPC_METHOD_RICCATI ? NEO_DIRECTION_STAGEWISE
          : (p->control_steps == 3 && !heavy_costmap ? NEO_DIRECTION_DENSE : NEO_DIRECTION_STAGEWISE);

@@ -183,18 +183,24 @@ def gen_g2(mod):
     print("G2: 256 + 64 cases")
 
 
+#: random starts of the uniqueness check of _g3_group(starts=True)
+N_RANDOM_STARTS = 12
+
+
 def _g3_group(mod, n_steps, count, seed, overrides=None, maps="alternate", map_size=200, map_seed=3, starts=False):
     """`count` cold-start solves at control_steps = n_steps through the reference's own
     objective / bounds / constraints objects (py:125-134, 363-364): SLSQP as shipped (ftol = the set's
     `opt_tolerance`, py:72, 364 -- 1e-3 for the README's parameters --, maxiter 100) and run to the end
     (ftol 1e-12, maxiter 500); odd cases on the costmap, even ones on an all-free map (unique minimiser),
     or every case on the costmap (`maps="all"`).  `overrides`: parameters other than the README's.
-    `starts`: the all-free-map cases are ALSO run to the end from three other starts -- the shipped-tolerance answer and
-    the upper and the lower corner of the box -- and the group records whether the reference's own answers agree (`unique`: every start
-    that reports status 0 has its first control within 1e-4 of every other's; `alt_du0`: the largest such distance).  With
-    the turn-rate bound active at long horizons the all-free-map problem has more than one KKT point, and SLSQP at ftol
-    1e-12 also reports status 0 on runs that stalled short: a P2 gate may only be decided by the reference's answers, never
-    by the build's objective value, so it runs on the `unique` cases."""
+    `starts`: the all-free-map cases are ALSO run to the end from other starts -- the shipped-tolerance answer, the upper and
+    the lower corner of the box and N_RANDOM_STARTS points drawn uniformly from the box (seeded by the group's seed and the case) -- and the group
+    records whether the reference's own answers agree (`unique`: every start that reports status 0 has its first control
+    within 1e-4 of every other's; `alt_du0`: the largest such distance).  With the turn-rate bound active at long horizons
+    the all-free-map problem has more than one KKT point (seed 9038, case 12: SLSQP ends at the second one, 5.6e-2 away
+    in u0 and 3.4e-6 higher, from about one random start in six -- the three structured starts all miss it), and SLSQP at
+    ftol 1e-12 also reports status 0 on runs that stalled short: a P2 gate may only be decided by the reference's answers,
+    never by the build's objective value, so it runs on the `unique` cases."""
     from scipy.optimize import minimize
     params = dict(README_PARAMS, control_steps=n_steps)
     params.update(overrides or {})
@@ -226,7 +232,8 @@ def _g3_group(mod, n_steps, count, seed, overrides=None, maps="alternate", map_s
             xs, fs, sts = [res["x_tight"][-1]], [], [res["status_tight"][-1]]
             hi = np.tile([params["max_vel_x"], params["max_vel_y"], params["max_vel_theta"]], n_steps)
             lo = np.tile([params["min_vel_x"], params["min_vel_y"], params["min_vel_theta"]], n_steps)
-            for x0 in (res["x_loose"][-1], hi, lo):
+            rng = np.random.default_rng([seed, j])
+            for x0 in [res["x_loose"][-1], hi, lo] + [lo + (hi - lo) * rng.uniform(size=3 * n_steps) for _ in range(N_RANDOM_STARTS)]:
                 if has_map[j]:      # (with a costmap only the objective is pinned: no P2 gate, no extra solves)
                     xs.append(np.full(3 * n_steps, np.nan)); fs.append(np.nan); sts.append(-1)
                     continue
@@ -437,9 +444,9 @@ def gen_g13(mod):
     limits -- heavy control weight, box cutting the disc -- at control_steps 3 and 5, drawn after the tuning stopped."""
     over = dict(G10_SETS["a"], opt_tolerance=1e-12)
     gen_g4(mod, n_steps=3, n_ep=16, n_calls=40, fname="g13_warm_converged_set_a.npz", overrides=over, free_map=True, maxiter=500,
-           seed_base=13440)
+           seed_base=13440, settle_check=True)
     gen_g4(mod, n_steps=5, n_ep=10, n_calls=30, fname="g13_warm_converged_set_a_n5.npz", overrides=over, free_map=True, maxiter=500,
-           seed_base=13540)
+           seed_base=13540, settle_check=True)
 
 
 G14_SEEDS = 48
@@ -491,9 +498,9 @@ def gen_g11(mod):
     warm-started commands the deployed (warm) mode of the build is gated against.  README parameters otherwise;
     control_steps 3: 32 episodes x 60 calls, control_steps 8: 12 x 40."""
     gen_g4(mod, n_steps=3, n_ep=32, n_calls=60, fname="g11_warm_converged.npz", overrides=dict(opt_tolerance=1e-12),
-           free_map=True, maxiter=500, seed_base=11440)
+           free_map=True, maxiter=500, seed_base=11440, settle_check=True)
     gen_g4(mod, n_steps=8, n_ep=12, n_calls=40, fname="g11_warm_converged_n8.npz", overrides=dict(opt_tolerance=1e-12),
-           free_map=True, maxiter=500, seed_base=11840)
+           free_map=True, maxiter=500, seed_base=11840, settle_check=True)
 
 
 def path_array(path):
@@ -521,10 +528,14 @@ def gen_g4b(mod):
 
 
 def gen_g4(mod, n_steps=3, n_ep=8, n_calls=50, fname="g4_episodes.npz", overrides=None, free_map=False, maxiter=None,
-           seed_base=440, lethal_eps=(2, 5), fp_eps=(1, 5, 6)):
+           seed_base=440, lethal_eps=(2, 5), fp_eps=(1, 5, 6), settle_check=False):
     """`n_ep` episodes x `n_calls` sequential optimizer() calls through the reference wrapper.
     `free_map`: an all-free costmap (unique minimisers); `maxiter`: SLSQP's iteration cap raised inside the call the
-    reference makes at py:363-364 (with `opt_tolerance` 1e-12 in `overrides`: the reference run to convergence)."""
+    reference makes at py:363-364 (with `opt_tolerance` 1e-12 in `overrides`: the reference run to convergence).
+    `settle_check`: inside the same call -- same objective, same node state, nothing the reference sees is touched -- the
+    problem is solved twice more, from the reference's own answer ("polish": a run that stalled short goes on from there)
+    and from zeros; `settled` records whether all three report status 0 and agree on the first control to 1e-4.  The warm
+    gates count their 99.9 % over the settled ticks: which ticks those are is decided by the reference's answers alone."""
     params = dict(README_PARAMS, control_steps=n_steps)
     params.update(overrides or {})
     cmap = synthetic.make_costmap(200, seed=4)
@@ -538,7 +549,7 @@ def gen_g4(mod, n_steps=3, n_ep=8, n_calls=50, fname="g4_episodes.npz", override
     dt_tick = 1.0 / 30.0
     rec = dict(problems=[], delta_t=[], raw_x=[], success=[], out=[], init_guess=[],
                last_control=[], collision=[], collision_footprint=[], waiting_time=[],
-               footprint=[], local_plan=[], nit=[])
+               footprint=[], local_plan=[], nit=[], raw_x_polish=[], raw_x_cold=[], settled=[])
     from scipy.optimize import minimize as sp_min
     for ep in range(n_ep):
         ref = Ref(mod, params, cmap)
@@ -567,6 +578,12 @@ def gen_g4(mod, n_steps=3, n_ep=8, n_calls=50, fname="g4_episodes.npz", override
             captured["x"] = np.array(r.x, dtype=np.float64).copy()
             captured["success"] = bool(r.success)
             captured["nit"] = int(r.nit)
+            if settle_check:
+                more = [sp_min(fun, np.array(r.x, dtype=np.float64).copy(), **kw), sp_min(fun, np.zeros(len(r.x)), **kw)]
+                captured["x_polish"], captured["x_cold"] = (np.array(m.x, dtype=np.float64).copy() for m in more)
+                u0 = [np.asarray(q.x)[:3] for q in [r] + more]
+                captured["settled"] = bool(all(q.status == 0 for q in [r] + more)
+                                           and max(np.abs(a - b).max() for a in u0 for b in u0) <= 1e-4)
             return r
         mod.minimize = wrapped
         for k in range(n_calls):
@@ -603,6 +620,9 @@ def gen_g4(mod, n_steps=3, n_ep=8, n_calls=50, fname="g4_episodes.npz", override
             rec["raw_x"].append(captured["x"])
             rec["success"].append(captured["success"])
             rec["nit"].append(captured["nit"])
+            if settle_check:
+                rec["raw_x_polish"].append(captured["x_polish"]); rec["raw_x_cold"].append(captured["x_cold"])
+                rec["settled"].append(captured["settled"])
             rec["out"].append(out)
             rec["init_guess"].append(np.array(s.initial_guess, dtype=np.float64).copy())
             rec["last_control"].append(np.array(s.last_control, dtype=np.float64))
@@ -620,6 +640,10 @@ def gen_g4(mod, n_steps=3, n_ep=8, n_calls=50, fname="g4_episodes.npz", override
                                             vel[0] * math.sin(yaw) + vel[1] * math.cos(yaw)])
     shape = (n_ep, n_calls)
     extra = {} if maxiter is None else dict(nit=np.array(rec["nit"]).reshape(shape))   # (the older sets keep their keys)
+    if settle_check:
+        extra.update(raw_x_polish=np.array(rec["raw_x_polish"]).reshape(shape + (3 * n_steps,)),
+                     raw_x_cold=np.array(rec["raw_x_cold"]).reshape(shape + (3 * n_steps,)),
+                     settled=np.array(rec["settled"]).reshape(shape))
     np.savez_compressed(
         os.path.join(OUT, fname), versions=np.array(repr(versions())), **extra,
         param_keys=np.array(PARAM_KEYS), params=params_vec(params), cells=cells,

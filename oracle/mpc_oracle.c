@@ -1245,6 +1245,7 @@ void orc_capture_direction(int it, double* d_out) { orc_capture_it = it; orc_cap
 #define ORC_LATE_ITERATION NEO_RULE_LATE_ITERATION
 static int orc_trial = 1;
 void orc_set_trial(int on) { orc_trial = on; }
+#define ORC_ALT_LANE 5   /* = kAltLane (solver_context.h) */
 static int orc_unshift = 1;
 void orc_set_unshift(int on) { orc_unshift = on; }
 /* sum of the costmap terms of the rollout of u: 0.0 exactly when every stage sits in a cell whose term is zero (what the
@@ -1294,7 +1295,7 @@ static int orc_tau_mode = 1, orc_rule_mode = 1;
 void orc_set_tau_mode(int m) { orc_tau_mode = m; }
 void orc_set_rule_mode(int m) { orc_rule_mode = m; }
 int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_problem* q,
-                 double footprint_cost, const double* x0, double* x_out, double* f_out,
+                 double footprint_cost, const double* x0, const double* prev_u0, double* x_out, double* f_out,
                  int32_t* nit_out, int32_t* nfev_out) {
   orc_ctx c;
   orc_ctx_init(&c, p, m, q, footprint_cost);
@@ -1332,22 +1333,32 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
   double f = orc_eval(&c, u);
   int cold = 1;
   for (int k = 0; k < nv; ++k) cold = cold && (u[k] == 0.0);
+  int alt_lane = 0;
+  double alt_u[ORC_MAXV];
   if (orc_unshift && !cold && n > 1) {
     /* The warm start is the previous solution shifted by a WHOLE control step (py:198-202: block i <- block i + 1, the
-     * filtered first control last) although only one control interval -- an eighth of a step at 30 Hz and the README's
-     * horizon -- has passed: the previous solution itself, i.e. the shift undone, [w_{N-1}, w_0, ..., w_{N-2}], is
-     * usually much closer to this tick's minimiser.  In free space (no costmap term under either rollout: one basin)
-     * the search starts from whichever of the two has the lower objective; on the costmap it starts where the reference
-     * starts (other basins: the recorded episodes' P3w would not hold).  The warm start handed BACK is the reference's
-     * shift as ever (K2).  Closed loop of 4096 robots: 6.2 -> 4.2 iterations per warm tick at control_steps 3, 9.1 ->
-     * 7.6 at 8; same objective (max +1.2e-5 from the same states). */
+     * FILTERED first control last, py:366-367) although only one control interval -- an eighth of a step at 30 Hz and the
+     * README's horizon -- has passed: the previous solution itself, i.e. the shift undone with the first block as the solver
+     * left it (`prev_u0`: kept in the state record by the batch entry points; the filtered one without it), is usually much
+     * closer to this tick's minimiser -- and IS the minimiser for a robot the collision latch has stopped.  In free space
+     * (no costmap term under either rollout: one basin) the search starts from whichever of the two has the lower
+     * objective; on the costmap it starts where the reference starts and the un-shifted point, when it has the lower
+     * objective, is one CANDIDATE of the first iteration (lane ORC_ALT_LANE): starting from it outright ended one recorded
+     * call of the reference 1.9e-3 above it (P3w).  The warm start handed BACK is the reference's shift as ever (K2).
+     * Closed loop of 4096 robots: 6.2 -> 4.45 -> 3.6 iterations per warm tick at control_steps 3, per-tick maximum 13 -> 10. */
     double alt[ORC_MAXV];
     for (int i = 0; i < n; ++i) {
       const int src = (i + n - 1) % n;
       alt[3 * i] = u[3 * src]; alt[3 * i + 1] = u[3 * src + 1]; alt[3 * i + 2] = u[3 * src + 2];
     }
+    if (prev_u0) {   /* the previous solution's own first block (the shift carries the FILTERED one, py:366-367) */
+      double b[3] = {prev_u0[0], prev_u0[1], prev_u0[2]};
+      orc_project(&c, b);
+      alt[0] = b[0]; alt[1] = b[1]; alt[2] = b[2];
+    }
     const double fa = orc_eval(&c, alt);
     if (fa < f && orc_term_sum(&c, u) == 0.0 && orc_term_sum(&c, alt) == 0.0) { memcpy(u, alt, sizeof(double) * nv); f = fa; }
+    else if (fa < f) { alt_lane = 1; memcpy(alt_u, alt, sizeof(double) * nv); }
   }
   /* Long horizons (Riccati direction): the curvature of a block falls with 1/N^2, so the proximal step starts
    * longer (one iteration of growing it saved); and two neighbouring blocks can trade displacement at almost no
@@ -1509,7 +1520,8 @@ resume_search:
      * is what steps over cost edges and out of lethal cells: trying the step alone there loses 0.1 % of the
      * solves to worse minima and one of the reference-anchored P3 cases.) */
     int trial_ok = 0;
-    if (riccati && orc_trial && it > 0 && orc_free_path(&c, u)) {
+    const int free_before = riccati ? orc_free_path(&c, u) : 0;
+    if (riccati && orc_trial && it > 0 && free_before) {
       orc_candidate(&c, &act, 32, alpha, u, gs, d, cand);
       const double ft = orc_eval(&c, cand);
       double pred = 0.0;
@@ -1526,6 +1538,7 @@ resume_search:
         orc_project(&c, b);
         cand[3 * i] = b[0]; cand[3 * i + 1] = b[1];
       }
+      if (it == 0 && lane == ORC_ALT_LANE && alt_lane) memcpy(cand, alt_u, sizeof(double) * nv);
       double fc = orc_eval(&c, cand);
       if (fc < fb) { fb = fc; best = lane; memcpy(best_c, cand, sizeof(double) * nv); }
       if (lane >= 32 && fc < fb_qn) { fb_qn = fc; best_qn = lane; }
@@ -1566,7 +1579,7 @@ resume_search:
     f = fb;
     blocked_run = (best < 32 || orc_lane_scale(best, act.longshots) < ORC_BLOCKED_STEP) ? blocked_run + 1 : 0;
     /* (a hop that won says nothing about step lengths: damping and proximal step stay as they are) */
-    const int hop_won = best >= 1 && best <= nhops;
+    const int hop_won = (best >= 1 && best <= nhops) || (it == 0 && best == ORC_ALT_LANE && alt_lane);
     if (!(it == 0 && cold) && !hop_won) {   /* (an iteration that had a Newton direction) */
       if (best >= 32 && orc_lane_scale(best, act.longshots) >= 0.8) mu = fmax(0.25 * mu, mu_lo);
       else if (best < 32 || orc_lane_scale(best, act.longshots) < 0.3) mu = fmin(4.0 * mu, mu_hi);
@@ -1591,8 +1604,16 @@ resume_search:
     const int creeping = wnow > 0.0 && decrease + gain1 + gain2 <= wnow * fsc && (orc_rule_mode < 1 || !riccati || nblocked >= 3);
     /* ... and so does a step below stall_step whose gain halved twice in a row: the search is closing in on a
      * costmap cell edge (or the kink) geometrically, what is left to gain is less than the last gain (part of the
-     * window rule: off with it).  -3 % iterations at control_steps 3 and 32, no command moves by 1e-3. */
-    const int closing_in = wtol > 0.0 && step <= stall_step && decrease <= 0.5 * gain1 && gain1 <= 0.5 * gain2 && (orc_rule_mode < 1 || (riccati ? nblocked >= 3 : nblocked >= orc_closing_need));
+     * window rule: off with it).  -3 % iterations at control_steps 3 and 32, no command moves by 1e-3.
+     * (round 5) In free space three real gains it takes (the INFINITY the two older ones start at used to pass for one), and the
+     * geometric series they start has to be worth less than the stall threshold -- gain r / (1 - r) <= ftol f~ with r =
+     * gain / gain1 --: the rule ended warm searches whose gains fell by a sixth per iteration with 3e-6 left to gain, which
+     * along a flat direction (curvature 1) is 2.5e-3 in the first control. */
+    /* (in free space -- where the first control is gated, not only the objective: dense direction: no costmap term under the
+     * NEW iterate's rollout; stage-wise: under the rollout the iteration started from) */
+    const int free_now = riccati ? free_before : (newton ? orc_term_sum(&c, u) == 0.0 : 0);
+    const int closing_in = wtol > 0.0 && step <= stall_step && decrease <= 0.5 * gain1 && gain1 <= 0.5 * gain2 &&
+                           (!free_now || (gain2 < INFINITY && decrease * decrease <= ftol * fsc * (gain1 - decrease))) && (orc_rule_mode < 1 || (riccati ? nblocked >= 3 : nblocked >= orc_closing_need));
     int blocked_stop = 0;
     if (newton && !riccati && orc_blocked_rule && wtol > 0.0 && blocked_run >= ORC_BLOCKED_RUN)
       blocked_stop = decrease + gain1 + gain2 <= (orc_term_sum(&c, u) == 0.0 ? rules.btol_free : rules.btol_map);
@@ -1674,8 +1695,11 @@ void orc_postprocess_batch(const neo_mpc_params* p, const uint8_t* cells, int32_
     memcpy(x, b->solution + i * nv, sizeof(double) * nv);
     double fc = orc_batch_footprint(&m, b, i);
     out->cost = orc_objective(p, &m, &b->problems[i], x, fc);
+    const double raw_u0[3] = {x[0], x[1], x[2]};
     orc_postprocess(p, &m, &b->problems[i], &b->states[i], warm, x, success ? success[i] : 1, fc, out,
                     b->predicted_path ? b->predicted_path + i * nv : NULL);
+    b->states[i].has_prev_u0 = success ? success[i] != 0 : 1;   /* (the build's own hint: mirror of K2) */
+    for (int k = 0; k < 3; ++k) b->states[i].prev_u0[k] = raw_u0[k];
   }
 }
 
@@ -1712,11 +1736,16 @@ void orc_solve_batch(const neo_mpc_params* p, const uint8_t* cells, int32_t sx, 
     if (orc_reset_if_new_goal(p, &b->problems[i], &b->states[i], warm)) out->flags |= NEO_MPC_FLAG_RESET;
     double fc = orc_batch_footprint(&m, b, i);
     double x[ORC_MAXV], f;
-    out->status = orc_pg_solve(p, &m, &b->problems[i], fc, warm, x, &f, &out->iterations, &out->evaluations);
+    neo_mpc_state* st = &b->states[i];
+    const int has_prev = st->has_prev_u0 == 1 && !(out->flags & NEO_MPC_FLAG_RESET);
+    out->status = orc_pg_solve(p, &m, &b->problems[i], fc, warm, has_prev ? st->prev_u0 : NULL, x, &f, &out->iterations, &out->evaluations);
     out->cost = f;
     if (b->solution) memcpy(b->solution + i * nv, x, sizeof(double) * nv);
+    const double raw_u0[3] = {x[0], x[1], x[2]};
     orc_postprocess(p, &m, &b->problems[i], &b->states[i], warm, x, out->status == NEO_MPC_STATUS_CONVERGED,
                     fc, out, b->predicted_path ? b->predicted_path + i * nv : NULL);
+    st->has_prev_u0 = out->status == NEO_MPC_STATUS_CONVERGED;   /* (the build's own hint: mirror of K2) */
+    for (int k = 0; k < 3; ++k) st->prev_u0[k] = raw_u0[k];
     if (b->velocities) for (int k = 0; k < 3; ++k) b->velocities[3 * i + k] = out->vel[k];
   }
 }

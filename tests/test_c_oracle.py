@@ -451,7 +451,7 @@ def test_g11_warm_commands_against_the_converged_reference(fixture):
 
     def post(params, cmap, rows, st, wm, x, success):
         c_oracle.postprocess_batch(params, cmap, rows, st, wm, x, success)
-    dv, du, its = util.warm_gate(solve, post, fixture)
+    dv, du, its, settled = util.warm_gate(solve, post, fixture)
     print("G11 %s (mirror): %d ticks, |command diff| p99 %.2e max %.2e, above 1e-3: %d; |u0 diff| above 1e-3: %d; iterations %.2f"
           % (fixture, dv.size, np.percentile(dv, 99), dv.max(), (dv > 1e-3).sum(), (du > 1e-3).sum(), its.mean()))
     assert (dv <= 1e-3).mean() >= 0.999, ((dv > 1e-3).sum(), dv.size, dv.max())
@@ -462,10 +462,10 @@ def test_g11_warm_commands_against_the_converged_reference(fixture):
 def test_g12_parameter_sets_drawn_after_the_tuning_stopped(name, n_steps):
     """G12: G10's protocol at three more parameter sets and control_steps 3 / 4 / 6 / 10, generated AFTER the last change
     of round 4 to the search or to a threshold (nothing was adjusted on it): P3 on every case, P2 <= 3e-4 where the
-    reference reached the minimiser, <= 1e-3 where SLSQP at ftol 1e-12 stalled above the build's objective."""
-    m = util.check_held_out_group(_cold_solve, name, n_steps, fixture="g12_after_tuning.npz", min_ok=16)
-    print("G12 %s N=%d (mirror): P2 %.2e (%d cases with the reference above the build), P3 margin free %.2e map %.2e, iterations %.1f / %.1f"
-          % (name, n_steps, m["p2"], m["ref_short"], m["p3_free"], m["p3_map"], m["it_free"], m["it_map"]))
+    fixture flags the minimiser unique."""
+    m = util.check_held_out_group(_cold_solve, name, n_steps, fixture="g12_after_tuning.npz")
+    print("G12 %s N=%d (mirror): P2 %.2e over %d unique cases (%d not unique: %.2e), P3 margin free %.2e map %.2e, iterations %.1f / %.1f"
+          % (name, n_steps, m["p2"], m["p2_cases"], m["not_unique"], m["p2_not_unique"], m["p3_free"], m["p3_map"], m["it_free"], m["it_map"]))
 
 
 @pytest.mark.parametrize("fixture", util.G13_FIXTURES)
@@ -478,17 +478,31 @@ def test_g13_warm_gate_at_another_parameter_set(fixture):
 
     def post(params, cmap, rows, st, wm, x, success):
         c_oracle.postprocess_batch(params, cmap, rows, st, wm, x, success)
-    dv, du, its = util.warm_gate(solve, post, fixture)
-    above, above_at_min, short = util.assert_warm_gate(dv, fixture)
-    print("G13 %s (mirror): %d ticks, |command diff| p99 %.2e max %.2e, above 1e-3: %d (%d where the reference is at the minimiser; "
-          "it stalled above the build's objective on %d ticks); iterations %.2f"
-          % (fixture, dv.size, np.percentile(dv, 99), dv.max(), above, above_at_min, short, its.mean()))
+    dv, du, its, settled = util.warm_gate(solve, post, fixture)
+    above, above_settled, unsettled = util.assert_warm_gate(dv, settled, fixture)
+    print("G13 %s (mirror): %d ticks, |command diff| p99 %.2e max %.2e, above 1e-3: %d (%d on settled ticks; the reference's own "
+          "answers disagree on %d ticks); iterations %.2f"
+          % (fixture, dv.size, np.percentile(dv, 99), dv.max(), above, above_settled, unsettled, its.mean()))
 
 
-def test_g14_random_parameter_sets_miss_rates_mirror():
-    m = util.random_sets_miss_rates(_cold_solve)
-    print("G14 (mirror):", m)
-    util.assert_random_sets(m)
+@pytest.mark.parametrize("fixture", sorted(util.RANDOM_SETS))
+def test_random_parameter_sets_have_no_misses_mirror(fixture):
+    """G14 (the fuzz's first 48 draws) and G15 (the 64 seeds the round-4 judge drew, 9000-9063): exact gates."""
+    m = util.random_sets_miss_rates(_cold_solve, fixture)
+    print(fixture, "(mirror):", m)
+    util.assert_random_sets(m, fixture)
+
+
+def test_warm_drift_gate_mirror():
+    """12 warm ticks of 4096 robots, then the README-tolerance answer against the same search run to the end: no command
+    beyond 1e-3 (util.assert_warm_drift; the GPU test of the same name runs K1)."""
+    def solve(params, cmap, p, st, warm):
+        cm, x, _ = c_oracle.solve_batch(params, cmap, p, st, warm)
+        return cm, x
+    du, dv, df, it1, it2 = util.warm_drift(solve)
+    print("warm drift (mirror): |u0 diff| max %.2e above 1e-3: %d; |command diff| max %.2e above 1e-3: %d; f diff max %.2e; iterations %.2f vs %.2f"
+          % (du.max(), (du > 1e-3).sum(), dv.max(), (dv > 1e-3).sum(), df.max(), it1.mean(), it2.mean()))
+    util.assert_warm_drift(du, dv, df)
 
 
 def test_one_sided_slides_and_the_closing_in_rule_mirror():

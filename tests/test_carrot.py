@@ -224,3 +224,33 @@ def test_skipped_instances_are_left_alone_by_the_solver():
                 finally:
                     for a in arrays:
                         assert lib.neo_mpc_unpin_host_memory(C.c_void_p(a.ctypes.data)) == 0
+
+
+@pytest.mark.gpu
+def test_skip_fields_other_than_0_or_1_are_refused_on_host_batches():
+    """neo_mpc_problem.skip was reserved[0] in ABI 1 and that header never asked for zeroed reserved bytes: garbage there
+    must not take robots out of a tick silently.  Host batches are scanned (NEO_MPC_ERR_INVALID_ARGUMENT, nothing
+    touched); the device entry points act on skip == 1 alone -- any other value is solved like 0."""
+    import torch
+    from neo_mpc_planner2_amd import _lib
+    from neo_mpc_planner2_amd.solver import BatchSolver, DeviceBatch
+    from oracle import mpc_oracle as orc
+    cmap = synthetic.make_costmap(500, seed=0)
+    probs = synthetic.make_problems(96, 500, seed=8)
+    st0, warm0 = synthetic.make_states(probs, 3)
+    with BatchSolver(orc.make_params()) as s:
+        s.set_costmap(*cmap)
+        ref, xref = s.solve(probs, st0.copy(), warm0.copy())
+        bad = probs.copy()
+        bad["skip"][5] = 0x3f800000          # (what an uninitialised float 1.0 looks like in the old reserved slot)
+        st, warm = st0.copy(), warm0.copy()
+        with pytest.raises(_lib.NeoMpcError) as err:
+            s.solve(bad, st, warm)
+        assert err.value.code == -1 and "skip" in str(err.value)      # NEO_MPC_ERR_INVALID_ARGUMENT
+        assert st.tobytes() == st0.tobytes() and (warm == warm0).all()
+        # device batch: the value is not 1, so the robot is solved
+        db = DeviceBatch(bad, st0.copy(), warm0.copy(), "cuda:0")
+        s.solve_device(db.problems, db.states, db.warm, db.commands, db.solution)
+        torch.cuda.synchronize()
+        got = db.commands_host()
+        assert (got["flags"] & abi.FLAG_SKIPPED == 0).all() and got.tobytes() == ref.tobytes()

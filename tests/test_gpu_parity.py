@@ -348,11 +348,14 @@ def test_p3_on_the_reference_warm_starts(solver_mod, fixture):
 def test_forced_directions_without_a_wall_model_are_refused_at_heavy_costmap_weights(solver_mod):
     """No selectable configuration is knowingly worse than the reference: NEO_MPC_METHOD_LBFGS / _NEWTON have no wall
     model for costmap steps and, forced onto w_costmap > w_trans / 4, used to end above SLSQP on a few percent of the
-    costmap cases (G8 "turn", G9) -- neo_mpc_create and neo_mpc_set_params now answer NEO_MPC_ERR_UNSUPPORTED there; AUTO and
-    RICCATI are offered everywhere; unknown compat bits are refused; the behaviour version can be asked for."""
+    costmap cases (G8 "turn", G9) -- neo_mpc_create answers NEO_MPC_ERR_UNSUPPORTED there; AUTO and RICCATI are offered
+    everywhere.  A LIVE handle reconfigured across the threshold (cb_params, py:405-439, cannot fail in the reference) keeps
+    working: it runs the stage-wise direction while the weights stay there -- bit for bit what a RICCATI handle answers --
+    and goes back to its pinned direction with them.  Unknown compat bits are refused; the behaviour version can be asked."""
+    import ctypes as C
     from neo_mpc_planner2_amd import _lib
     lib = _lib.load()
-    assert lib.neo_mpc_abi_version() == abi.ABI_VERSION == 2 and lib.neo_mpc_behaviour_version() == 4
+    assert lib.neo_mpc_abi_version() == abi.ABI_VERSION == 2 and lib.neo_mpc_behaviour_version() == 5
     heavy = util.orc.make_params(w_costmap=0.3)          # 0.3 > 0.82 / 4
     for method in (1, 2):
         with pytest.raises(_lib.NeoMpcError) as e:
@@ -360,10 +363,21 @@ def test_forced_directions_without_a_wall_model_are_refused_at_heavy_costmap_wei
         assert e.value.code == -5 and "wall model" in str(e.value)
     for method in (0, 3):
         solver_mod.BatchSolver(dict(heavy, method=method)).close()
-    with solver_mod.BatchSolver(util.orc.make_params(method=2)) as s:       # README weights: offered ...
-        with pytest.raises(_lib.NeoMpcError) as e:
-            s.set_params(**dict(heavy, method=2))                           # ... but not reconfigured into the refused corner
-        assert e.value.code == -5
+    cfg, cmap, probs, st0, warm0 = synthetic.make_workload("C2", seed=12, batch=512)
+    with _solver(solver_mod, dict(heavy, method=3), cmap) as s:
+        want = s.solve(probs, st0.copy(), warm0.copy())[0]
+    for method in (1, 2):
+        with _solver(solver_mod, util.orc.make_params(method=method), cmap) as s:   # README weights: offered ...
+            assert lib.neo_mpc_effective_method(s._handle) == method
+            first = s.solve(probs, st0.copy(), warm0.copy())[0]
+            s.set_params(**dict(heavy, method=method))                              # ... reconfigured across the threshold
+            assert lib.neo_mpc_effective_method(s._handle) == 3 and s.params["method"] == method
+            got = s.solve(probs, st0.copy(), warm0.copy())[0]
+            assert got.tobytes() == want.tobytes()
+            s.set_params(**util.orc.make_params(method=method))                     # ... and back
+            assert lib.neo_mpc_effective_method(s._handle) == method
+            assert s.solve(probs, st0.copy(), warm0.copy())[0].tobytes() == first.tobytes()
+    assert lib.neo_mpc_effective_method(None) < 0
     with pytest.raises(_lib.NeoMpcError) as e:
         solver_mod.BatchSolver(util.orc.make_params(compat_flags=1 | 0x40))
     assert e.value.code == -1 and "compat_flags" in str(e.value) and lib.neo_mpc_last_error_code() == -1
@@ -424,7 +438,7 @@ def test_g11_warm_commands_against_the_converged_reference(solver_mod, fixture):
     def post(params, cmap, rows, st, wm, x, success):
         get(params, cmap).postprocess(rows, st, wm, x, success)
     try:
-        dv, du, its = util.warm_gate(solve, post, fixture)
+        dv, du, its, settled = util.warm_gate(solve, post, fixture)
     finally:
         if "s" in solvers:
             solvers["s"].close()
@@ -923,6 +937,27 @@ def test_closed_loop_warm_ticks_have_no_creeping_tail(solver_mod):
     print(summary)
 
 
+def test_warm_drift_gate(solver_mod):
+    """The deployed mode's accuracy as a GATE (round 4 measured it: 4 commands of 4096 beyond 1e-3): 12 warm ticks of 4096
+    robots on an all-free map, then K1 at the README tolerance against K1 run to the end from the same state -- no command
+    beyond 1e-3 (util.assert_warm_drift)."""
+    solvers = {}
+
+    def solve(params, cmap, p, st, warm):
+        key = params["max_iterations"] if "max_iterations" in params else 0
+        if key not in solvers:
+            solvers[key] = _solver(solver_mod, params, cmap)
+        return solvers[key].solve(p, st, warm)
+    try:
+        du, dv, df, it1, it2 = util.warm_drift(solve)
+    finally:
+        for s in solvers.values():
+            s.close()
+    print("warm drift: |u0 diff| max %.2e above 1e-3: %d; |command diff| max %.2e above 1e-3: %d; f diff max %.2e; iterations %.2f vs %.2f"
+          % (du.max(), (du > 1e-3).sum(), dv.max(), (dv > 1e-3).sum(), df.max(), it1.mean(), it2.mean()))
+    util.assert_warm_drift(du, dv, df)
+
+
 def test_bench_emits_the_contract_line():
     """`python bench.py --gpus 1 --steps K --warmup W` prints ONE JSON line, last on stdout, with the
     driver's keys, BASELINE.json's metric, the roofline object of the dominant kernel and (without
@@ -1071,9 +1106,9 @@ def test_g12_parameter_sets_drawn_after_the_tuning_stopped(solver_mod, name, n_s
         st, warm = synthetic.make_states(pr, params["control_steps"])
         with _solver(solver_mod, params, cmap) as s:
             return s.solve(pr, st, warm)
-    m = util.check_held_out_group(solve, name, n_steps, fixture="g12_after_tuning.npz", min_ok=16)
-    print("G12 %s N=%d: P2 %.2e (%d cases with the reference above the build), P3 margin free %.2e map %.2e, iterations %.1f / %.1f"
-          % (name, n_steps, m["p2"], m["ref_short"], m["p3_free"], m["p3_map"], m["it_free"], m["it_map"]))
+    m = util.check_held_out_group(solve, name, n_steps, fixture="g12_after_tuning.npz")
+    print("G12 %s N=%d: P2 %.2e over %d unique cases (%d not unique: %.2e), P3 margin free %.2e map %.2e, iterations %.1f / %.1f"
+          % (name, n_steps, m["p2"], m["p2_cases"], m["not_unique"], m["p2_not_unique"], m["p3_free"], m["p3_map"], m["it_free"], m["it_map"]))
 
 
 @pytest.mark.parametrize("fixture", util.G13_FIXTURES)
@@ -1092,14 +1127,14 @@ def test_g13_warm_gate_at_another_parameter_set(solver_mod, fixture):
     def post(params, cmap, rows, st, wm, x, success):
         get(params, cmap).postprocess(rows, st, wm, x, success)
     try:
-        dv, du, its = util.warm_gate(solve, post, fixture)
+        dv, du, its, settled = util.warm_gate(solve, post, fixture)
     finally:
         if "s" in solvers:
             solvers["s"].close()
-    above, above_at_min, short = util.assert_warm_gate(dv, fixture)
-    print("G13 %s: %d ticks, |command diff| p99 %.2e max %.2e, above 1e-3: %d (%d where the reference is at the minimiser; it "
-          "stalled above the build's objective on %d ticks); iterations %.2f"
-          % (fixture, dv.size, np.percentile(dv, 99), dv.max(), above, above_at_min, short, its.mean()))
+    above, above_settled, unsettled = util.assert_warm_gate(dv, settled, fixture)
+    print("G13 %s: %d ticks, |command diff| p99 %.2e max %.2e, above 1e-3: %d (%d on settled ticks; the reference's own answers "
+          "disagree on %d ticks); iterations %.2f"
+          % (fixture, dv.size, np.percentile(dv, 99), dv.max(), above, above_settled, unsettled, its.mean()))
 
 
 def test_one_sided_slides_and_the_closing_in_rule(solver_mod):
@@ -1113,13 +1148,43 @@ def test_one_sided_slides_and_the_closing_in_rule(solver_mod):
     print("stop-rule regressions: (|du0| of the instance, max over 256, iterations)", util.check_stop_rule_regressions(solve))
 
 
-def test_g14_random_parameter_sets_miss_rates(solver_mod):
-    """G14 through the C-ABI on the GPU: 48 random parameter sets x 24 cold problems against the reference, miss COUNTS
-    (util.random_sets_miss_rates)."""
+@pytest.mark.parametrize("fixture", sorted(util.RANDOM_SETS))
+def test_random_parameter_sets_have_no_misses(solver_mod, fixture):
+    """G14 / G15 through the C-ABI on the GPU: 48 + 64 random parameter sets x 24 cold problems against the reference
+    (util.random_sets_miss_rates); exact gates since round 5 -- no P3 miss, no P2 miss on the unique cases."""
     def solve(params, cmap, pr):
         st, warm = synthetic.make_states(pr, params["control_steps"])
         with _solver(solver_mod, params, cmap) as s:
             return s.solve(pr, st, warm)
-    m = util.random_sets_miss_rates(solve)
-    print("G14:", m)
-    util.assert_random_sets(m)
+    m = util.random_sets_miss_rates(solve, fixture)
+    print(fixture, m)
+    util.assert_random_sets(m, fixture)
+
+
+def test_non_finite_warm_starts_do_not_disturb_their_neighbours(solver_mod):
+    """Robustness of the static-tile kernels (their costmap lookups carry no bounds test: the reach tile covers every cell a
+    FEASIBLE rollout reaches): a NaN / Inf warm start -- projection lets NaN through, the cell index of a NaN position
+    saturates -- reads LDS outside the tile (an out-of-range LDS read returns 0 on this hardware; it cannot fault), scores
+    NaN, which no comparison accepts, and the search of that instance ends at once.  Nothing hangs, every other instance of
+    the batch answers bit for bit what it answers without the bad rows, and the bad rows' commands are finite (py:385-391's
+    fmin / fmax ignore NaN: the clamp around last_control decides)."""
+    cfg, cmap, probs, st0, warm0 = synthetic.make_workload("C2", seed=21, batch=512)
+    params = util.orc.make_params()
+    with _solver(solver_mod, params, cmap) as s:
+        assert s.kernel_info()["tile_in_lds"]
+        st, warm = st0.copy(), warm0.copy()
+        st["has_old_goal"] = 1                       # (so that the warm start is used: same goal as the request's)
+        st["old_goal"][:, :3] = probs["goal_xyz"]
+        st["old_goal"][:, 3:] = probs["goal_q"]
+        warm[:] = 0.05
+        good = s.solve(probs, st.copy(), warm.copy())[0]
+        bad_rows = np.arange(0, 512, 37)
+        w2 = warm.copy()
+        w2[bad_rows[0::3]] = np.nan
+        w2[bad_rows[1::3], 4] = np.inf
+        w2[bad_rows[2::3], 0] = -np.inf
+        got = s.solve(probs, st.copy(), w2)[0]
+    keep = np.ones(512, dtype=bool)
+    keep[bad_rows] = False
+    assert got[keep].tobytes() == good[keep].tobytes()
+    assert np.isfinite(got["vel"]).all() and (got["iterations"][bad_rows] <= params.get("max_iterations", 100)).all()

@@ -126,12 +126,15 @@ def closed_loop_on_the_mirror(params, cmap, probs, ticks, hz=30.0):
 orc = orc  # re-export: tests use util.orc.make_params
 
 
-def check_held_out_group(solve, name, n_steps, p2_bar=3e-4, fixture="g10_heldout.npz", min_ok=20):
+def check_held_out_group(solve, name, n_steps, p2_bar=3e-4, fixture="g10_heldout.npz", min_ok=8):
     """G10 gates for one (set, control_steps) group.  `solve(params, cmap, problems) -> (commands, x)` is the build's cold
     solve (GPU through the C-ABI, or the CPU mirror).  P3 on every case: f <= f(SLSQP as shipped, ftol = the set's
-    opt_tolerance) + 1e-3, feasible, converged.  P2 on the all-free-map cases where SLSQP at ftol 1e-12 reports status 0:
-    |u0 - u0(SLSQP 1e-12)|_inf <= p2_bar (the north star's bar is 1e-3; the round-3 judge asked for 3e-4 of margin on
-    sets that were never tuned on).  Returns the margins for the report line."""
+    opt_tolerance) + 1e-3, feasible, converged.  P2 on the all-free-map cases the FIXTURE flags `unique` -- the reference's
+    SLSQP at ftol 1e-12 reports status 0 and ends within 1e-4 of the same first control from fifteen other starts
+    (gen_golden._g3_group): |u0 - u0(SLSQP 1e-12)|_inf <= p2_bar (the north star's bar is 1e-3; the round-3 judge asked
+    for 3e-4 of margin on sets that were never tuned on).  Which cases count is decided by the reference's answers alone,
+    never by the build's objective value; the cases that are not unique (more than one KKT point, or a run of the
+    reference that stalled short) are reported, not gated.  Returns the margins for the report line."""
     grp, params, probs, hm = solve_group(fixture, "%s_n%d_" % (name, n_steps))
     assert params["control_steps"] == n_steps and len(probs) >= 48
     out = {}
@@ -147,31 +150,28 @@ def check_held_out_group(solve, name, n_steps, p2_bar=3e-4, fixture="g10_heldout
             assert (xs[:, :, q] <= params["max_vel_" + axis] + 1e-12).all() and (xs[:, :, q] >= params["min_vel_" + axis] - 1e-12).all()
         out["p3_" + tag] = worse.max()
         if tag == "free":
-            ok = grp["status_tight"][mask] == 0
-            assert ok.sum() >= min_ok
+            unique = grp["unique"][mask].astype(bool)
+            others = (grp["status_tight"][mask] == 0) & ~unique
+            assert unique.sum() >= min_ok, (name, n_steps, int(unique.sum()))
             du0 = np.abs(x[:, :3] - grp["x_tight"][mask][:, :3]).max(axis=1)
-            # SLSQP at ftol 1e-12 reports status 0 on runs that stalled short of the minimiser: where its objective is
-            # ABOVE the build's the distance between the two is the reference's error, not the build's -- such cases are
-            # held to the north star's own bar (1e-3), the others to p2_bar
-            ref_short = ok & (cmds["cost"] < grp["f_tight"][mask] - 1e-9)
-            at_min = ok & ~ref_short
-            assert du0[at_min].max() <= p2_bar, (name, n_steps, du0[at_min].max())                          # P2
-            assert not ref_short.any() or du0[ref_short].max() <= 1e-3, (name, n_steps, du0[ref_short].max())
+            assert du0[unique].max() <= p2_bar, (name, n_steps, du0[unique].max())                          # P2
             assert (cmds["cost"] <= grp["f_tight"][mask] + 1e-4).all()
-            out["p2"] = du0[ok].max()
-            out["ref_short"] = int(ref_short.sum())
+            out["p2"] = du0[unique].max()
+            out["p2_cases"] = int(unique.sum())
+            out["not_unique"] = int(others.sum())
+            out["p2_not_unique"] = float(du0[others].max()) if others.any() else 0.0
         out["it_" + tag] = cmds["iterations"].mean()
     return out
 
 
 def warm_gate(solve, postprocess, fixture):
-    """G11: every call of the reference's CONVERGED episodes (SLSQP at ftol 1e-12, maxiter 500, all-free map) solved by the
-    build at the README tolerance from the reference's own state -- its warm start, last_control, goal bookkeeping; the
+    """G11 / G13: every call of the reference's CONVERGED episodes (SLSQP at ftol 1e-12, maxiter 500, all-free map) solved by
+    the build at the README tolerance from the reference's own state -- its warm start, last_control, goal bookkeeping; the
     states are advanced with the reference's raw x.x injected (P5), so call k starts exactly where the reference did.
     `solve(params, cmap, rows, states, warm) -> (commands, x)`, `postprocess(params, cmap, rows, states, warm, x, success)`.
     Returns |command - reference command|_inf and |u0 - reference u0|_inf over the calls the reference converged on
-    (status 0), and the iteration counts; warm_gate.ref_short marks the ticks on which the reference's answer has a higher
-    objective than the build's."""
+    (status 0), the iteration counts, and the fixture's `settled` flag of those calls (the reference's own answer, the same
+    solve taken up again from that answer and one from zeros agree on the first control to 1e-4: gen_golden.gen_g4)."""
     from neo_mpc_planner2_amd import abi
     g = load(fixture)
     params = params_from(g["param_keys"], g["params"])
@@ -183,15 +183,10 @@ def warm_gate(solve, postprocess, fixture):
     n_ep, n_calls = probs.shape
     states, warm = abi.new_states(n_ep, n)
     dv, du, its = [], [], []
-    ref_short = []
-    from oracle import c_oracle
     for k in range(n_calls):
         rows = probs[:, k].copy()
         rows["footprint_cost"] = 0.0
         cmds, x = solve(params, cmap, rows, states.copy(), warm.copy())
-        # (ticks where the reference's "converged" x.x has a HIGHER objective than the build's answer, by far more than the
-        # 1e-9 .. 1e-8 SLSQP at ftol 1e-12 usually leaves: it stalled)
-        ref_short.append(cmds["cost"] < c_oracle.objective_batch(params, cmap, rows, g["raw_x"][:, k]) - 1e-6)
         dv.append(np.abs(cmds["vel"] - g["out"][:, k]).max(axis=1))
         du.append(np.abs(x[:, :3] - g["raw_x"][:, k][:, :3]).max(axis=1))
         its.append(cmds["iterations"].copy())
@@ -200,20 +195,48 @@ def warm_gate(solve, postprocess, fixture):
         assert np.allclose(states["last_control"], g["last_control"][:, k], rtol=0, atol=1e-13)
     ok = g["success"].astype(bool)
     dv, du, its = np.array(dv).T, np.array(du).T, np.array(its).T
-    warm_gate.ref_short = np.array(ref_short).T[ok]      # (kept off the return value: three callers unpack three)
-    return dv[ok], du[ok], its
+    return dv[ok], du[ok], its, g["settled"].astype(bool)[ok]
 
 
-def assert_warm_gate(dv, fixture):
-    """The gate on warm_gate()'s command differences: >= 99.9 % of the ticks within 1e-3 of the reference's converged
-    command -- counted over the ticks where the reference's answer is at least as good as the build's (where its objective
-    is above the build's, the reference stalled short of the minimiser it was supposed to supply) -- and >= 99 % over all."""
-    short = warm_gate.ref_short
-    assert short.mean() <= 0.02
-    at_min = dv[~short]
-    assert (at_min <= 1e-3).mean() >= 0.999, (fixture, (at_min > 1e-3).sum(), at_min.size, at_min.max())
+def assert_warm_gate(dv, settled, fixture):
+    """The gate on warm_gate()'s command differences: >= 99.9 % of the SETTLED ticks within 1e-3 of the reference's
+    converged command (which ticks are settled is the fixture's statement about the reference's own answers -- the build's
+    objective value decides nothing), >= 99 % of all ticks, none beyond 5e-3."""
+    assert settled.mean() >= 0.9, (fixture, settled.mean())
+    at = dv[settled]
+    assert (at <= 1e-3).mean() >= 0.999, (fixture, (at > 1e-3).sum(), at.size, at.max())
     assert (dv <= 1e-3).mean() >= 0.99 and dv.max() <= 5e-3, (fixture, (dv > 1e-3).sum(), dv.size, dv.max())
-    return int((dv > 1e-3).sum()), int((at_min > 1e-3).sum()), int(short.sum())
+    return int((dv > 1e-3).sum()), int((at > 1e-3).sum()), int((~settled).sum())
+
+
+def warm_drift(solve, count=4096, ticks=12):
+    """Closed-loop drift: `count` robots on an all-free map, pose fixed, velocity = the previous command, `ticks` warm ticks
+    at the README tolerance; then the same state solved once more at the README tolerance and once run to the end (400
+    iterations, tolerances 1e-9 / 1e-12, no window rules).  `solve(params, cmap, problems, states, warm) -> (commands, x)`
+    updates states / warm in place.  Returns |first control difference|, |command difference|, objective difference,
+    iteration counts."""
+    from neo_mpc_planner2_amd import synthetic
+    cmap = synthetic.make_costmap(500, seed=0)
+    zero = (np.zeros_like(cmap[0]),) + tuple(cmap[1:])
+    p = synthetic.make_problems(count, 500, seed=77)
+    st, warm = synthetic.make_states(p, 3)
+    params = orc.make_params()
+    for _ in range(ticks):
+        cm, _ = solve(params, zero, p, st, warm)
+        p["cur_vel"] = cm["vel"]
+    c1, x1 = solve(params, zero, p, st.copy(), warm.copy())
+    tight = dict(params, window_tolerance=-1.0, step_tolerance=1e-9, cost_tolerance=1e-12, max_iterations=400)
+    c2, x2 = solve(tight, zero, p, st.copy(), warm.copy())
+    return (np.abs(x1[:, :3] - x2[:, :3]).max(axis=1), np.abs(c1["vel"] - c2["vel"]).max(axis=1), c1["cost"] - c2["cost"],
+            c1["iterations"], c2["iterations"])
+
+
+def assert_warm_drift(du, dv, df):
+    """The gate (round 5): after 12 warm ticks no COMMAND is more than 1e-3 from the run-to-the-end kernel's (round 4: 4 of
+    4096, max 3.7e-3), no first control more than 2e-3 and at most two beyond 1e-3 (round 4: 8, max 7.4e-3)."""
+    assert (dv > 1e-3).sum() == 0, ((dv > 1e-3).sum(), dv.max())
+    assert (du > 1e-3).sum() <= 2 and du.max() <= 2e-3, ((du > 1e-3).sum(), du.max())
+    assert df.max() <= 1e-4
 
 
 #: (round 4) two searches the random-parameter fuzz found stopping short; the values are the fuzz's draws
@@ -259,14 +282,14 @@ def check_stop_rule_regressions(solve):
 
 
 def random_sets_miss_rates(solve, fixture="g14_random_sets.npz"):
-    """G14: 48 RANDOM parameter sets (oracle/fuzz_reference.py's first draws) x 24 cold problems under G10's protocol.
-    Counts instead of all-or-nothing gates -- away from hand-picked sets a descent method on a piecewise-constant costmap
-    term does end in other basins than SLSQP now and then, and this fixture says how often: P3 misses (objective more than
-    1e-3 above SLSQP as shipped) on all-free maps and on costmaps, cases where SLSQP as shipped is more than 1e-3 above the
-    build, P2 misses (first control more than 1e-3 from SLSQP run to the end, where that converged and is not above the
-    build's objective).  `solve(params, cmap, problems) -> (commands, x)`, cold."""
+    """G14 / G15: RANDOM parameter sets (oracle/fuzz_reference.py's draws) x 24 cold problems under G10's protocol.  Counts:
+    P3 misses (objective more than 1e-3 above SLSQP as shipped) on all-free maps and on costmaps, cases where SLSQP as
+    shipped is more than 1e-3 above the build, P2 misses (first control more than 1e-3 from SLSQP run to the end) over the
+    cases the fixture flags `unique` (check_held_out_group), and -- reported only -- the largest distance over the status-0
+    cases that are not.  `solve(params, cmap, problems) -> (commands, x)`, cold."""
     g = load(fixture)
-    out = dict(cases_free=0, cases_map=0, p3_miss_free=0, p3_miss_map=0, ref_worse=0, p2_cases=0, p2_miss=0, p2_worst=0.0, ref_short=0)
+    out = dict(cases_free=0, cases_map=0, p3_miss_free=0, p3_miss_map=0, p3_worst=-1.0, ref_worse=0, p2_cases=0, p2_miss=0, p2_worst=0.0,
+               not_unique=0, p2_not_unique_worst=0.0, misses=[])
     for seed, n in zip(g["seeds"], g["steps"]):
         pre = "s%d_" % seed
         grp = {k[len(pre):]: g[k] for k in g.files if k.startswith(pre)}
@@ -280,22 +303,30 @@ def random_sets_miss_rates(solve, fixture="g14_random_sets.npz"):
             worse = cmds["cost"] - grp["f_loose"][mask]
             out["cases_" + tag] += int(mask.sum())
             out["p3_miss_" + tag] += int((worse > 1e-3).sum())
+            out["p3_worst"] = max(out["p3_worst"], float(worse.max()))
             out["ref_worse"] += int((worse < -1e-3).sum())
+            out["misses"] += [("P3", int(seed), int(np.nonzero(mask)[0][i]), float(worse[i])) for i in np.nonzero(worse > 1e-3)[0]]
             if tag == "free":
-                ok = grp["status_tight"][mask] == 0
+                unique = grp["unique"][mask].astype(bool)
+                others = (grp["status_tight"][mask] == 0) & ~unique
                 du0 = np.abs(x[:, :3] - grp["x_tight"][mask][:, :3]).max(axis=1)
-                short = ok & (cmds["cost"] < grp["f_tight"][mask] - 1e-9)
-                at = ok & ~short
-                out["p2_cases"] += int(at.sum())
-                out["p2_miss"] += int((du0[at] > 1e-3).sum())
-                out["p2_worst"] = max(out["p2_worst"], float(du0[at].max()) if at.any() else 0.0)
-                out["ref_short"] += int(short.sum())
+                out["p2_cases"] += int(unique.sum())
+                out["p2_miss"] += int((du0[unique] > 1e-3).sum())
+                out["p2_worst"] = max(out["p2_worst"], float(du0[unique].max()) if unique.any() else 0.0)
+                out["not_unique"] += int(others.sum())
+                out["p2_not_unique_worst"] = max(out["p2_not_unique_worst"], float(du0[others].max()) if others.any() else 0.0)
+                out["misses"] += [("P2", int(seed), int(np.nonzero(mask)[0][i]), float(du0[i])) for i in np.nonzero(unique & (du0 > 1e-3))[0]]
     return out
 
 
-def assert_random_sets(m):
-    assert m["cases_free"] == m["cases_map"] == 576
-    assert m["p3_miss_free"] == 0, m
-    assert m["p3_miss_map"] <= 3, m          # (0.5 % of the costmap cases; measured: 1, +1.2e-3)
-    assert m["p2_miss"] <= 1 and m["p2_worst"] <= 3e-3, m
-    assert m["ref_worse"] >= 500, m           # (the reference at its shipped tolerance is the looser of the two by far)
+#: fixture -> (random parameter sets, all-free-map cases the reference's own answers flag unique at least)
+RANDOM_SETS = {"g14_random_sets.npz": 48, "g15_judge_sets.npz": 64}
+
+
+def assert_random_sets(m, fixture="g14_random_sets.npz"):
+    """Exact gates (round 5): no P3 miss on any of the random sets' cases, all-free map or costmap; no P2 miss on the cases
+    the reference's own answers flag unique."""
+    assert m["cases_free"] == m["cases_map"] == 12 * RANDOM_SETS[fixture]
+    assert m["p3_miss_free"] == 0 and m["p3_miss_map"] == 0, m
+    assert m["p2_miss"] == 0 and m["p2_worst"] <= 1e-3 and m["p2_cases"] >= 0.8 * m["cases_free"], m
+    assert m["ref_worse"] >= 10 * RANDOM_SETS[fixture], m     # (the reference at its shipped tolerance is the looser of the two by far)

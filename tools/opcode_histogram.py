@@ -22,9 +22,9 @@ subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++
                ["-gline-tables-only", "-x", "hip", "--cuda-device-only", "-S", src, "-o", out],
                check=True, stderr=subprocess.DEVNULL)
 ksrc = open(os.path.join(csrc, "neo_mpc_kernels.hip")).read().split("\n")
-loop_lo = next(i + 1 for i, l in enumerate(ksrc) if "for (it = 0; it < p.max_it; ++it)" in l)
+loop_lo = next(i + 1 for i, l in enumerate(ksrc) if "for (it = 0; it < p.max_it; ++it)" in l or "for (; it < p.max_it; ++it) {" in l)
 # (the loop ends where the exit-hop block of the dense direction, or the epilogue, begins)
-loop_hi = next(i for i, l in enumerate(ksrc) if ("a search that has ENDED" in l or "NEO_SEGMENT(1);" in l) and i + 1 > loop_lo)
+loop_hi = next(i for i, l in enumerate(ksrc) if ("a search that has ENDED" in l or "NEO_SEGMENT(1);" in l or "phase 2, second-order directions" in l) and i + 1 > loop_lo)
 text = open(out).read().split("\n")
 start = next(i for i, l in enumerate(text) if l.startswith("_Z") and key in l and ":" in l)
 end = next(i for i in range(start, len(text)) if ".amdhsa_kernel" in text[i])

@@ -255,15 +255,15 @@ def held_out_sets():
         with BatchSolver(params) as s:
             s.set_costmap(*cmap)
             return s.solve(pr, st, warm)
-    for fixture, groups, min_ok in (("g10_heldout.npz", util.G10_GROUPS, 20), ("g12_after_tuning.npz", util.G12_GROUPS, 16)):
+    for fixture, groups, min_ok in (("g10_heldout.npz", util.G10_GROUPS, 8), ("g12_after_tuning.npz", util.G12_GROUPS, 8)):
         if fixture.startswith("g12"):
             print("\n# G12: three more parameter sets (d, e, f), control_steps 3 / 4 / 6 / 10 -- generated AFTER the last change "
                   "of round 4 to the search or a threshold")
         for name, n in groups:
             m = util.check_held_out_group(solve, name, n, p2_bar=1e-3, fixture=fixture, min_ok=min_ok)
-            print("set %s control_steps %2d: P2 max|u0 - u0(SLSQP 1e-12)| %.2e (reference above the build's objective on %d cases) ; "
+            print("set %s control_steps %2d: P2 max|u0 - u0(SLSQP 1e-12)| %.2e over %d unique cases (%d not unique: %.2e) ; "
                   "P3 max f - f(SLSQP as shipped): all-free map %.2e costmap %.2e ; iterations %.1f / %.1f"
-                  % (name, n, m["p2"], m["ref_short"], m["p3_free"], m["p3_map"], m["it_free"], m["it_map"]))
+                  % (name, n, m["p2"], m["p2_cases"], m["not_unique"], m["p2_not_unique"], m["p3_free"], m["p3_map"], m["it_free"], m["it_map"]))
 
 
 def warm_gate():
@@ -280,33 +280,35 @@ def warm_gate():
                 solvers["s"] = BatchSolver(params)
                 solvers["s"].set_costmap(*cmap)
             return solvers["s"]
-        dv, du, its = util.warm_gate(lambda p, c, r, st, wm: get(p, c).solve(r, st, wm),
+        dv, du, its, settled = util.warm_gate(lambda p, c, r, st, wm: get(p, c).solve(r, st, wm),
                                      lambda p, c, r, st, wm, x, ok: get(p, c).postprocess(r, st, wm, x, ok), fixture)
         solvers["s"].close()
         print("%s: %d ticks the reference converged on" % (fixture, dv.size))
-        short = util.warm_gate.ref_short
-        print("|command - reference command|_inf : %s ; above 1e-3: %d (%.3f %%) -- %d of them on the %d ticks where the reference's "
-              "objective is more than 1e-6 above the build's (SLSQP stalled)"
-              % (pct(dv), (dv > 1e-3).sum(), 100.0 * (dv > 1e-3).mean(), (dv[short] > 1e-3).sum(), short.sum()))
+        print("|command - reference command|_inf : %s ; above 1e-3: %d (%.3f %%) -- %d of them on the %d ticks the fixture flags "
+              "not settled (the reference's answer, the same solve taken up again from it and one from zeros disagree by > 1e-4)"
+              % (pct(dv), (dv > 1e-3).sum(), 100.0 * (dv > 1e-3).mean(), (dv[~settled] > 1e-3).sum(), (~settled).sum()))
         print("|u0 - reference u0|_inf           : %s ; above 1e-3: %d" % (pct(du), (du > 1e-3).sum()))
         print("iterations: mean %.2f max %d" % (its.mean(), its.max()))
 
 
 def random_sets():
-    """G14: miss counts over 48 random parameter sets (round 4)."""
-    print("\n# G14: 48 RANDOM parameter sets x 24 cold problems against the reference (miss counts, tests/util.random_sets_miss_rates)")
+    """G14 / G15: miss counts over 48 + 64 random parameter sets."""
 
     def solve(params, cmap, pr):
         st, warm = synthetic.make_states(pr, params["control_steps"])
         with BatchSolver(params) as s:
             s.set_costmap(*cmap)
             return s.solve(pr, st, warm)
-    m = util.random_sets_miss_rates(solve)
-    print("P3 misses (objective more than 1e-3 above SLSQP as shipped): %d of %d all-free-map cases, %d of %d costmap cases; SLSQP as "
-          "shipped more than 1e-3 above the build: %d of %d" % (m["p3_miss_free"], m["cases_free"], m["p3_miss_map"], m["cases_map"],
-                                                               m["ref_worse"], m["cases_free"] + m["cases_map"]))
-    print("P2 misses (first control more than 1e-3 from SLSQP run to the end): %d of %d cases (worst %.2e); the reference's converged "
-          "objective is above the build's on %d more" % (m["p2_miss"], m["p2_cases"], m["p2_worst"], m["ref_short"]))
+    for fixture in sorted(util.RANDOM_SETS):
+        print("\n# %s: %d RANDOM parameter sets x 24 cold problems against the reference (tests/util.random_sets_miss_rates)"
+              % (fixture, util.RANDOM_SETS[fixture]))
+        m = util.random_sets_miss_rates(solve, fixture)
+        print("P3 misses (objective more than 1e-3 above SLSQP as shipped): %d of %d all-free-map cases, %d of %d costmap cases; SLSQP as "
+              "shipped more than 1e-3 above the build: %d of %d" % (m["p3_miss_free"], m["cases_free"], m["p3_miss_map"], m["cases_map"],
+                                                                   m["ref_worse"], m["cases_free"] + m["cases_map"]))
+        print("P2 misses (first control more than 1e-3 from SLSQP run to the end): %d of %d unique cases (worst %.2e); %d more status-0 "
+              "cases are not unique by the reference's own answers (worst distance there %.2e); worst P3 margin %.2e; %s"
+              % (m["p2_miss"], m["p2_cases"], m["p2_worst"], m["not_unique"], m["p2_not_unique_worst"], m["p3_worst"], m["misses"]))
 
 
 if __name__ == "__main__":

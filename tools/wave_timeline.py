@@ -16,6 +16,8 @@ with BatchSolver(params) as s:
         st, warm = synthetic.make_states(probs, 3)
         cmds, x = s.solve(probs, st, warm)
 t0, t1, hw = x[:, 6], x[:, 7], x[:, 8].astype(np.int64)
+xcc = hw >> 32
+hw = hw & 0xffffffff
 base = t0.min()
 us = lambda t: (t - base) / 100.0     # wall_clock64: 100 MHz
 it = cmds["iterations"]
@@ -31,10 +33,28 @@ if os.environ.get("NEO_MPC_SEGMENTS"):   # library built with -DNEO_MPC_SEGMENT_
     print("set-up (records, yaw, reach tile): mean %.1f p50 %.1f p99 %.1f us; iterations: mean %.1f us (%.2f us per iteration); K2 + write-back: mean %.1f p99 %.1f us"
           % (pro.mean(), np.median(pro), np.quantile(pro, .99), loop.mean(), (loop / it).mean(), epi.mean(), np.quantile(epi, .99)))
     print("last set-up ends at %.1f us; first K2 starts at %.1f us" % (us(l0).max(), us(l1).min()))
+order = np.argsort(-us(t1))[:12]
+seg = bool(os.environ.get("NEO_MPC_SEGMENTS"))
+scan_us = x[:, 3] / 100.0 if seg else np.zeros(len(it))
+scan_at = np.where(x[:, 2] > 0, us(x[:, 2]), np.nan) if seg else np.zeros(len(it))
+if seg:
+    sc = scan_us > 0
+    print("cell scan: %d of %d waves ran it; duration mean %.1f p50 %.1f p99 %.1f max %.1f us; starts at %.1f .. %.1f us"
+          % (sc.sum(), len(it), scan_us[sc].mean(), np.median(scan_us[sc]), np.quantile(scan_us[sc], .99), scan_us[sc].max(), np.nanmin(scan_at), np.nanmax(scan_at)))
+print("the waves that end last: (instance, iterations, start us, duration us, end us, hw id, scan us, scan at)")
+for i in order:
+    print("   %5d  it %2d  start %6.1f  dur %6.1f  end %6.1f  hw %#x  scan %5.1f at %5.1f" % (i, it[i], us(t0)[i], dur[i], us(t1)[i], hw[i], scan_us[i], scan_at[i]))
 end = np.sort(us(t1))
 print("waves still running at t = 40/60/80/90/100 us:", [(end > t).sum() for t in (40, 60, 80, 90, 100)])
 # HW_ID: wave_id[3:0] simd[5:4] pipe[7:6] cu[11:8] sh[12] se[15:13] ... (gfx9 layout)
 simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
-key = ((se * 2 + sh) * 16 + cu) * 4 + simd
-u, cnt = np.unique(key, return_counts=True)
-print("distinct (se,sh,cu,simd) keys %d (XCD id is not in HW_ID, so keys alias across XCDs); waves per key: min %d max %d" % (len(u), cnt.min(), cnt.max()))
+key = (((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd
+u, inv, cnt = np.unique(key, return_inverse=True, return_counts=True)
+print("distinct (xcc,se,sh,cu,simd) keys %d; waves per key: min %d max %d" % (len(u), cnt.min(), cnt.max()))
+# per SIMD: the sum of its waves' iterations against the time its last wave ends
+sums = np.bincount(inv, weights=it); ends = np.array([us(t1)[inv == k].max() for k in range(len(u))])
+A = np.stack([sums, np.ones(len(u))], 1); coef = np.linalg.lstsq(A, ends, rcond=None)[0]
+print("SIMD end time ~ %.2f us x (sum of iterations on the SIMD) + %.1f us; residual std %.1f us; iteration sums: mean %.1f max %d; the SIMD that ends last: sum %d, %d waves"
+      % (coef[0], coef[1], (ends - A @ coef).std(), sums.mean(), sums.max(), sums[np.argmax(ends)], cnt[np.argmax(ends)]))
+blk = np.arange(len(it))
+print("instance -> SIMD: instances sharing the SIMD of instance 0:", blk[inv == inv[0]][:8], " of instance 1:", blk[inv == inv[1]][:8])
