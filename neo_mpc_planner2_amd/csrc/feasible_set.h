@@ -36,18 +36,10 @@ __device__ __forceinline__ void project_block(const DevParams& p, double& b0, do
   const double qx = zx * (r / nz), qy = zy * (r / nz);
   if (qx >= p.lo[0] && qx <= p.hi[0] && qy >= p.lo[1] && qy <= p.hi[1]) { b0 = qx; b1 = qy; return; }
   double best = INFINITY, bx = px, by = py;  // both bind: closest circle / box-edge intersection
-  // (the radius re-read opaquely: the eight corner points depend on the parameters alone, and left to itself the compiler
-  // computes them ahead of the solver loop -- four square roots, their negatives and a dozen validity masks parked in
-  // vector and scalar registers all through the loop, spilled to scratch and reloaded by every candidate of every
-  // iteration (general dense kernel: 18 scratch loads in the loop) for a branch that only blocks in a corner of the
-  // feasible set take)
-  double rr = r;
-  asm volatile("" : "+v"(rr));
   for (int e = 0; e < 4; ++e) {
-    double fixed = (e == 0) ? p.lo[0] : (e == 1) ? p.hi[0] : (e == 2) ? p.lo[1] : p.hi[1];
-    asm volatile("" : "+v"(fixed));   // (... and so are the squares of the bounds)
-    if (fabs(fixed) > rr) continue;
-    const double o = sqrt(rr * rr - fixed * fixed);
+    const double fixed = (e == 0) ? p.lo[0] : (e == 1) ? p.hi[0] : (e == 2) ? p.lo[1] : p.hi[1];
+    if (fabs(fixed) > r) continue;
+    const double o = sqrt(r * r - fixed * fixed);
     for (int s = -1; s <= 1; s += 2) {
       const double ex = (e < 2) ? fixed : s * o, ey = (e < 2) ? s * o : fixed;
       if (ex < p.lo[0] || ex > p.hi[0] || ey < p.lo[1] || ey > p.hi[1]) continue;

@@ -998,7 +998,15 @@ def test_bench_emits_the_contract_line():
     names = [o["workload"] for o in rec["other_workloads"]]
     assert names[:3] == ["C3", "C5", "C4 per-GPU shard"] and all("error" not in o for o in rec["other_workloads"])
     assert all(o["solver"]["status_max_iter"] == 0 and o["value"] > 1e6 for o in rec["other_workloads"])
-    assert rec["warm_tick"]["ticks"] >= 50 and rec["warm_tick"]["max_iterations_max"] < 100
+    # rate floors, 12-15 % under what round 5 measured (box-to-box variance is 5 %): round 4 lost 14 % and 18 % on the two
+    # general-kernel parameter sets and nothing said so -- the headline at 5 steps without settle reads low, hence 36 M
+    floors = {"C3": 25.5e6, "C5": 5.9e6, "C4 per-GPU shard": 66e6, "C2/cut": 24e6, "C2/turn": 9.6e6}
+    got = {o["workload"]: o["value"] for o in rec["other_workloads"]}
+    assert set(floors) <= set(got) and all(got[k] >= v for k, v in floors.items()), got
+    assert rec["value"] >= 36e6, rec["value"]
+    wt = rec["warm_tick"]
+    assert wt["ticks"] >= 50 and wt["max_iterations_max"] <= 16 and wt["ms_per_tick_median"] <= 0.105, wt
+    assert wt["mean_iterations"] <= 3.8, wt      # (round 4: 4.30; the un-shifted start with the solver's own first block)
     # HBM traffic from the PMC passes is reported only for the build it was measured on
     assert r["traffic"] is not None or any(w in r["traffic_note"] for w in ("stale", "no PMC", "batch"))
 

@@ -1,6 +1,6 @@
 #!/bin/bash
-# copy the summaries of `bash tools/r4_profile.sh <tag>` (gpurun_out/) into profiles/ as <prefix>_*
-# usage: bash tools/r3_install.sh <tag, e.g. r04a> <prefix, e.g. r04_a> [old prefix to remove]
+# copy the summaries of `bash tools/r5_profile.sh <tag>` (gpurun_out/) into profiles/ as <prefix>_*
+# usage: bash tools/r5_install.sh <tag, e.g. r04a> <prefix, e.g. r04_a> [old prefix to remove]
 set -e
 TAG=$1; T=$2; OLD=${3:-}
 F=gpurun_out/final_$TAG; P=gpurun_out/prof_$TAG
@@ -20,6 +20,7 @@ cp $F/fleet_loop_pool.json profiles/${T}_fleet_loop_pool.json
 cp $F/tick_latency.json profiles/${T}_tick_latency.json
 cp $F/gpu_tests.log profiles/${T}_gpu_tests.txt
 cp $F/host_path.json profiles/${T}_host_path.json
+cp $F/split_call.json profiles/${T}_split_call.json
 cp $F/opcodes_c2.txt profiles/${T}_opcodes_c2.txt
 cp $F/opcodes_riccati.txt profiles/${T}_opcodes_riccati.txt
 cp gpurun_out/prof_${TAG}_k1cal/calibration.json profiles/${T}_k1_traffic_calibration.json

@@ -1,8 +1,8 @@
 #!/bin/bash
 # one gpurun call: GPU tests, rocprofv3 evidence for C2 / C3 / C5 (kernel stats + PMC in separate passes) and K3, the default
 # bench line (other_workloads, warm_tick, pcie variants ride in it), parity report, closed loop, tick latency
-# usage: bash tools/r4_profile.sh <tag>      then: bash tools/r4_install.sh <tag> <prefix>
-TAG=${1:-r04a}
+# usage: bash tools/r5_profile.sh <tag>      then: bash tools/r5_install.sh <tag> <prefix>
+TAG=${1:-r05a}
 O=gpurun_out/final_$TAG
 mkdir -p $O
 timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -15 > $O/gpu_tests.log
@@ -26,6 +26,7 @@ timeout 300 python tools/bench_fleet_loop.py 2>/dev/null | tail -1 > $O/fleet_lo
 timeout 300 python tools/bench_fleet_loop.py --pool 2>/dev/null | tail -1 > $O/fleet_loop_pool.json
 timeout 120 python tools/bench_tick_latency.py 2>/dev/null | tail -1 > $O/tick_latency.json
 timeout 600 python tools/bench_host_path.py 2>/dev/null | tail -1 > $O/host_path.json
+timeout 300 python tools/bench_split_call.py 2>/dev/null | tail -1 > $O/split_call.json
 python tools/opcode_histogram.py k_solveILi4ELi3ELi1ELb1ELi1024E > $O/opcodes_c2.txt 2>&1
 python tools/opcode_histogram.py k_solveILi4ELi0ELi2ELb1ELi0E > $O/opcodes_riccati.txt 2>&1
 cat $O/gpu_tests.log; cut -c1-1500 $O/bench_c2.json; grep -v amdgpu $O/parity_report.txt | tail -30; cat $O/fleet_loop.json | cut -c1-400; cat $O/tick_latency.json

@@ -10,11 +10,36 @@ from neo_mpc_planner2_amd.solver import BatchSolver
 from neo_mpc_planner2_amd.mpc_optimization_server import README_PARAMS
 cfg, cmap, probs, st, warm = synthetic.make_workload("C2", seed=0)
 params = dict(README_PARAMS); params.update(control_steps=3)
+warm_ticks = int(sys.argv[sys.argv.index("--warm") + 1]) if "--warm" in sys.argv else 0   # the timeline of the T-th warm tick of the closed loop
 with BatchSolver(params) as s:
     s.set_costmap(*cmap)
-    for rep in range(3):
+    if not warm_ticks:
+        for rep in range(3):
+            st, warm = synthetic.make_states(probs, 3)
+            cmds, x = s.solve(probs, st, warm)
+    else:   # (the fleet loop of neo_mpc_planner2_amd/fleet.py on host arrays: robots moved by their own commands)
+        def yaw_of(q):
+            return np.arctan2(2 * (q[:, 3] * q[:, 2] + q[:, 0] * q[:, 1]), 1 - 2 * (q[:, 1] ** 2 + q[:, 2] ** 2))
+        probs = probs.copy()
         st, warm = synthetic.make_states(probs, 3)
-        cmds, x = s.solve(probs, st, warm)
+        yaw, pos = yaw_of(probs["cur_q"]).copy(), probs["cur_xy"].copy()
+        c_, s_ = np.cos(yaw), np.sin(yaw)
+        off = np.stack([c_ * probs["carrot_xy"][:, 0] - s_ * probs["carrot_xy"][:, 1], s_ * probs["carrot_xy"][:, 0] + c_ * probs["carrot_xy"][:, 1]], 1)
+        cyw = yaw + yaw_of(probs["carrot_q"])
+        probs["control_interval"] = 1 / 30.0
+        probs["delta_t"] = 1 / 30.0
+        for t in range(warm_ticks + 1):
+            cmds, x = s.solve(probs, st, warm)
+            v = cmds["vel"]
+            yaw = yaw + v[:, 2] / 30.0
+            c_, s_ = np.cos(yaw), np.sin(yaw)
+            pos = pos + np.stack([c_ * v[:, 0] - s_ * v[:, 1], s_ * v[:, 0] + c_ * v[:, 1]], 1) / 30.0
+            probs["cur_xy"], probs["cur_q"] = pos, synthetic.yaw_quat(yaw)
+            probs["carrot_xy"][:, 0] = c_ * off[:, 0] + s_ * off[:, 1]
+            probs["carrot_xy"][:, 1] = -s_ * off[:, 0] + c_ * off[:, 1]
+            probs["carrot_q"] = synthetic.yaw_quat(cyw - yaw)
+            probs["cur_vel"] = v
+        print("warm tick %d of the closed loop: %d robots stopped by the latch" % (warm_ticks, int((cmds["flags"] & 2 != 0).sum())))
 t0, t1, hw = x[:, 6], x[:, 7], x[:, 8].astype(np.int64)
 xcc = hw >> 32
 hw = hw & 0xffffffff
