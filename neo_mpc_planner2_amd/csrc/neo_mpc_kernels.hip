@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   constexpr int kRegSteps = kSteps ? kSteps : 1;
   constexpr int kPairs = kSteps ? 4 : NEO_MPC_MAX_LBFGS_MEMORY;  // specialisations: lbfgs_memory <= 4
   int flags;
-  double fcost, f = INFINITY;   // f(x0) comes out of the first candidate pass: lane 0 evaluates x0 itself there
+  double f = INFINITY;   // f(x0) comes out of the first candidate pass: lane 0 evaluates x0 itself there
   bool cold = true;             // x0 == 0 (wave-uniform: every lane scans the same LDS values)
   // ---- phase 0: set-up.  Records, reset, footprint, reach tile; the per-instance constants and the stop tolerances go to
   //      the tolerance block of LDS (layout: solver_context.h), where every later phase reads them; x0.
@@ -225,7 +225,11 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     if (uniform_int(reinterpret_cast<const int*>(L + a.lds.prob)[PI_SKIP]) == 1) { skip_instance(a, b, lane); return; }
     select_map(a.map, L + a.lds.prob);
     flags = reset_and_warm(a, L, b, lane) ? NEO_MPC_FLAG_RESET : 0;
-    fcost = footprint_cost(a, L, b, lane);
+    // (the footprint cost -- the request's own, or the raster's -- waits for K2 in the request record's slot in LDS: as a
+    // register it was live across the whole kernel and, at four waves per SIMD, spilled to scratch: the only scratch of the
+    // headline kernel, 1.5 KB of memory traffic per solve against 885 B of algorithmic bytes)
+    const double fcost = footprint_cost(a, L, b, lane);
+    if (lane == 0) L[a.lds.prob + P_FOOTPRINT] = fcost;
     Ctx c;
     make_ctx_wave(p, a.map, L + a.lds.prob, fcost, c, lane);
     load_tile(a, c, L, lane);
@@ -315,7 +319,14 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   bool final_step = false;
   double alpha = 1.0;
   bool scanned = false;   // the cell scan has had its turn (cell_scan.h)
-  const int lane_id = lane;
+  // (the lane index is not kept in a register across the loop -- the stage-wise kernels at four waves per SIMD parked it in
+  // scratch and reloaded it at the top of every iteration: it is re-derived from the hardware's lane mask count, seeded
+  // with an opaque zero so that the compiler cannot hoist it either)
+  auto lane_again = []() {
+    int zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+    return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero));
+  };
   NEO_SEGMENT_DECL;
   NEO_SEGMENT(0);
   for (;;) {   // (the search; taken up again behind a cell scan that paid)
@@ -368,16 +379,14 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   // iteration's critical path)
   double my_scale;
   {
-    int l0 = lane_id;
-    asm volatile("" : "+v"(l0));
+    int l0 = lane_again();
     my_scale = kRiccati ? 0.0 : lane_scale<kSecond>(l0);
   }
   for (; it < p.max_it; ++it) {
     // The lane index is re-read opaquely every iteration: otherwise the compiler hoists two dozen
     // lane-derived constants (step multipliers, compare masks, LDS addresses) out of the loop and,
     // at 4 waves/SIMD, parks them in scratch -- recomputing them costs a few integer operations.
-    int lane = lane_id;
-    asm volatile("" : "+v"(lane));
+    int lane = lane_again();
     // stage-wise direction: this iteration's sweep carries the second-order terms of the rollout step
 #ifdef NEO_AB_NO_TAU
     const bool exact_step = false;
@@ -764,8 +773,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     select_map(as.map, L + as.lds.prob);
     Ctx cs;
     ctx_from_lds<false>(as, L, cs);
-    int ls = lane_id;
-    asm volatile("" : "+v"(ls));
+    int ls = lane_again();
     NEO_SEGMENT_SCAN_BEGIN();
     const bool won = cell_scan<kSteps, kTame, kCovered>(as, cs, L, f, kNewton ? &u_term : nullptr, nfev, ls, kSteps ? kSteps : as.p.n);
     NEO_SEGMENT_SCAN_END();
@@ -797,7 +805,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   WAVE_SYNC();
   f += L[a.lds.tol + T_KONST];
   c.true_yaw = L[a.lds.tol + T_TRUE_YAW];
-  postprocess(a, c, L, b, lane, u, status == NEO_MPC_STATUS_CONVERGED, fcost, flags, f, status, it, nfev);
+  postprocess(a, c, L, b, lane, u, status == NEO_MPC_STATUS_CONVERGED, L[a.lds.prob + P_FOOTPRINT], flags, f, status, it, nfev);
   NEO_WAVE_END();
 }
 
