@@ -48,12 +48,15 @@ extern "C" {
  *      field by field (old_goal only when it changed).  Blocks in a corner of the feasible set that a Newton step sends
  *      outward are pinned and the direction is computed once more; the closing-in stop rule of the dense / L-BFGS
  *      directions waits for two blocked iterations; a step below opt_tolerance ends the search only if it won its iteration.
- *   5  (round 5) cell scan in place of the dense direction's exit hop, in every direction: a search that has ended looks
- *      at the costmap cells around every stage (up to 3 cells away, inside the reach of a feasible rollout), evaluates the
- *      cheapest ones as candidates and is taken up again once when that gained more than opt_tolerance.  A pinned LBFGS /
- *      NEWTON direction that a neo_mpc_set_params call takes across w_costmap = w_trans / 4 runs the stage-wise
- *      direction from there on (neo_mpc_effective_method) instead of failing the reconfigure; neo_mpc_create still
- *      refuses the combination.  neo_mpc_problem.skip: host batches with values other than 0 / 1 are refused.
+ *   5  (round 5) cell scan in place of the dense direction's exit hop, in both second-order directions: a search that has
+ *      ended looks at the costmap cells around every stage (up to 3 cells away, inside the reach of a feasible rollout),
+ *      evaluates the cheapest ones as candidates and is taken up again once when that gained more than opt_tolerance.
+ *      The warm start is un-shifted with the previous solve's own first block (neo_mpc_state.prev_u0, was reserved); on a
+ *      costmap the un-shifted point is a candidate of the first iteration instead of a starting point.  Closing-in stop
+ *      rule, in free space: three real gains and a geometric estimate of what is left below the stall threshold.  A
+ *      pinned LBFGS / NEWTON direction that a neo_mpc_set_params call takes across w_costmap = w_trans / 4 runs the
+ *      stage-wise direction from there on (neo_mpc_effective_method) instead of failing the reconfigure; neo_mpc_create
+ *      still refuses the combination.  neo_mpc_problem.skip: host batches with values other than 0 / 1 are refused.
  * method = NEO_MPC_METHOD_NEWTON / _LBFGS / _RICCATI pins a direction. */
 #define NEO_MPC_BEHAVIOUR_VERSION 5
 

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""The deployed (warm-started) mode against the REFERENCE ITSELF at random parameter sets (development container only:
+imports /root/reference under the ROS stand-ins, like gen_golden.py).  For every seed a parameter set is drawn
+(fuzz_reference.draw), the reference runs G11's protocol on it -- optimizer() episodes RUN TO CONVERGENCE (`opt_tolerance`
+1e-12, SLSQP's cap raised to 500 inside the call of py:363-364) on an all-free map, robots moved by the reference's own
+commands, carrot re-drawn every 10 calls, new goal mid-episode, every tick solved three times for the `settled` flag -- and
+the CPU mirror of the build's search, at the set's own shipped tolerance, solves every call from the reference's own state
+(tests/util.warm_gate).  Reported per set and in total: settled ticks, how many of them have the build's command more than
+1e-3 from the reference's converged command, the largest difference.
+Test infrastructure: nothing here is shipped.   usage: fuzz_reference_warm.py <first seed> <last seed + 1> [episodes] [calls]"""
+import contextlib
+import io
+import multiprocessing as mp
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def work(args):
+    seed, n_ep, n_calls = args
+    tmp = tempfile.mkdtemp(prefix="neo_warm_fuzz_")
+    os.environ["NEO_MPC_GOLDEN_OUT"] = tmp
+    from oracle import fuzz_reference, gen_golden, ros_stubs, c_oracle
+    import util
+    gen_golden.OUT = tmp
+    n, over = fuzz_reference.draw(seed)
+    tol = over["opt_tolerance"]
+    mod = ros_stubs.load_reference()
+    name = "warm_seed%d.npz" % seed
+    with contextlib.redirect_stdout(io.StringIO()):
+        gen_golden.gen_g4(mod, n_steps=n, n_ep=n_ep, n_calls=n_calls, fname=name, overrides=dict(over, opt_tolerance=1e-12),
+                          free_map=True, maxiter=500, seed_base=50000 + 10 * seed, settle_check=True)
+    util.GOLDEN = tmp
+
+    def solve(params, cmap, rows, st, wm):
+        cm, x, _ = c_oracle.solve_batch(dict(params, opt_tolerance=tol), cmap, rows, st, wm)
+        return cm, x
+
+    def post(params, cmap, rows, st, wm, x, ok):
+        c_oracle.postprocess_batch(params, cmap, rows, st, wm, x, ok)
+    c_oracle.set_threads(1)
+    dv, du, its, settled = util.warm_gate(solve, post, name)
+    os.remove(os.path.join(tmp, name))
+    return seed, n, tol, int(dv.size), int(settled.sum()), int((dv[settled] > 1e-3).sum()), int((dv > 1e-3).sum()), \
+        float(dv[settled].max()) if settled.any() else 0.0, float(dv.max()), float(its.mean())
+
+
+if __name__ == "__main__":
+    seeds = list(range(int(sys.argv[1]), int(sys.argv[2])))
+    n_ep = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    n_calls = int(sys.argv[4]) if len(sys.argv) > 4 else 30
+    with mp.Pool(max(1, (os.cpu_count() or 2) - 1)) as pool:
+        rows = pool.map(work, [(s, n_ep, n_calls) for s in seeds], chunksize=1)
+    tot = np.zeros(4, dtype=int)
+    for seed, n, tol, ticks, ns, bad_s, bad, mx_s, mx, it in rows:
+        tot += (ticks, ns, bad_s, bad)
+        print("seed %d control_steps %2d opt_tolerance %.0e: %4d converged ticks, %4d settled; command more than 1e-3 from the "
+              "reference's: %d settled (%d of all); max %.2e settled (%.2e all); iterations %.2f"
+              % (seed, n, tol, ticks, ns, bad_s, bad, mx_s, mx, it))
+    print("%d parameter sets: %d converged ticks, %d settled; command more than 1e-3 from the reference's converged command on %d "
+          "settled ticks (%.3f %%), on %d of all" % (len(rows), tot[0], tot[1], tot[2], 100.0 * tot[2] / max(1, tot[1]), tot[3]))
