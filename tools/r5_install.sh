@@ -7,7 +7,7 @@ F=gpurun_out/final_$TAG; P=gpurun_out/prof_$TAG
 [ -n "$OLD" ] && git rm -q --ignore-unmatch profiles/${OLD}_* || true
 cp $P/kernels.txt profiles/${T}_kernels_c2.txt
 cp $P/pmc.txt profiles/${T}_pmc_c2.txt
-for w in C3 C5; do
+for w in C3 C5 C4; do
   lw=$(echo $w | tr A-Z a-z)
   cp ${P}_$w/kernels.txt profiles/${T}_kernels_$lw.txt
   cp ${P}_$w/pmc.txt profiles/${T}_pmc_$lw.txt
@@ -27,7 +27,7 @@ cp gpurun_out/prof_${TAG}_k1cal/calibration.json profiles/${T}_k1_traffic_calibr
 python - <<PY
 import json
 out = {}
-for d in ("$P", "${P}_C3", "${P}_C5"):
+for d in ("$P", "${P}_C3", "${P}_C5", "${P}_C4"):
     out.update(json.load(open(d + "/traffic_entry.json")))
 json.dump(out, open("profiles/hbm_traffic.json", "w"), indent=1)
 open("profiles/hbm_traffic.json", "a").write("\n")

@@ -11,10 +11,11 @@ timeout 600 bash tools/profile_k1_traffic.sh $TAG > $O/profile_k1cal.txt 2>&1
 timeout 900 bash tools/profile_all.sh $TAG C2 50 > $O/profile_c2.txt 2>&1
 timeout 900 bash tools/profile_all.sh $TAG C3 4 > $O/profile_c3.txt 2>&1
 timeout 900 bash tools/profile_all.sh $TAG C5 4 > $O/profile_c5.txt 2>&1
+timeout 900 bash tools/profile_all.sh $TAG C4 4 > $O/profile_c4.txt 2>&1
 python - <<PY
 import json
 out = {}
-for d in ("gpurun_out/prof_$TAG", "gpurun_out/prof_${TAG}_C3", "gpurun_out/prof_${TAG}_C5"):
+for d in ("gpurun_out/prof_$TAG", "gpurun_out/prof_${TAG}_C3", "gpurun_out/prof_${TAG}_C5", "gpurun_out/prof_${TAG}_C4"):
     try: out.update(json.load(open(d + "/traffic_entry.json")))
     except Exception as e: print("no traffic entry in", d, e)
 json.dump(out, open("profiles/hbm_traffic.json", "w"), indent=1)
