@@ -51,7 +51,7 @@ int main(void) {
   P(neo_mpc_problem, control_interval); P(neo_mpc_problem, footprint_cost); P(neo_mpc_problem, map_index);
   P(neo_mpc_problem, switch_opt); P(neo_mpc_problem, skip);
   P(neo_mpc_state, old_goal); P(neo_mpc_state, waiting_time); P(neo_mpc_state, has_old_goal);
-  P(neo_mpc_state, collision_footprint);
+  P(neo_mpc_state, collision_footprint); P(neo_mpc_state, has_prev_u0); P(neo_mpc_state, prev_u0);
   P(neo_mpc_command, cost); P(neo_mpc_command, status); P(neo_mpc_command, flags);
   P(neo_mpc_batch, footprints); P(neo_mpc_batch, footprint_points); P(neo_mpc_batch, velocities);
   return 0;
@@ -69,8 +69,10 @@ int main(void) {
         assert got["neo_mpc_params." + f] == getattr(abi.NeoMpcParams, f).offset
     for f in ("carrot_xy", "goal_xyz", "cur_vel", "control_interval", "footprint_cost", "map_index", "switch_opt", "skip"):
         assert got["neo_mpc_problem." + f] == abi.PROBLEM_DTYPE.fields[f][1]
-    for f in ("old_goal", "waiting_time", "has_old_goal", "collision_footprint"):
+    for f in ("old_goal", "waiting_time", "has_old_goal", "collision_footprint", "has_prev_u0", "prev_u0"):
         assert got["neo_mpc_state." + f] == abi.STATE_DTYPE.fields[f][1]
+    # (round 5: the build's one hint lives where ABI 1 had reserved bytes -- the last 28 of the record, same size)
+    assert got["neo_mpc_state.has_prev_u0"] == 100 and got["neo_mpc_state.prev_u0"] == 104
     for f in ("cost", "status", "flags"):
         assert got["neo_mpc_command." + f] == abi.COMMAND_DTYPE.fields[f][1]
     for f in ("footprints", "footprint_points", "velocities"):
