@@ -37,18 +37,28 @@ def work(args):
         gen_golden.gen_g4(mod, n_steps=n, n_ep=n_ep, n_calls=n_calls, fname=name, overrides=dict(over, opt_tolerance=1e-12),
                           free_map=True, maxiter=500, seed_base=50000 + 10 * seed, settle_check=True)
     util.GOLDEN = tmp
+    g = util.load(name)
+    call = [0]
+    df = []
 
     def solve(params, cmap, rows, st, wm):
-        cm, x, _ = c_oracle.solve_batch(dict(params, opt_tolerance=tol), cmap, rows, st, wm)
+        p = dict(params, opt_tolerance=tol)
+        cm, x, _ = c_oracle.solve_batch(p, cmap, rows, st, wm)
+        # (the build's objective against the objective of the reference's converged x.x of the same call)
+        df.append(cm["cost"] - c_oracle.objective_batch(p, cmap, rows, g["raw_x"][:, call[0]]))
+        call[0] += 1
         return cm, x
 
     def post(params, cmap, rows, st, wm, x, ok):
         c_oracle.postprocess_batch(params, cmap, rows, st, wm, x, ok)
     c_oracle.set_threads(1)
     dv, du, its, settled = util.warm_gate(solve, post, name)
+    df = np.array(df).T[g["success"].astype(bool)]
     os.remove(os.path.join(tmp, name))
-    return seed, n, tol, int(dv.size), int(settled.sum()), int((dv[settled] > 1e-3).sum()), int((dv > 1e-3).sum()), \
-        float(dv[settled].max()) if settled.any() else 0.0, float(dv.max()), float(its.mean())
+    bad = settled & (dv > 1e-3)
+    return seed, n, tol, int(dv.size), int(settled.sum()), int(bad.sum()), int((dv > 1e-3).sum()), \
+        float(dv[settled].max()) if settled.any() else 0.0, float(dv.max()), float(its.mean()), \
+        int((bad & (df > 1e-3)).sum()), int((bad & (df < -1e-3)).sum()), float(df[bad].max()) if bad.any() else 0.0
 
 
 if __name__ == "__main__":
@@ -57,11 +67,14 @@ if __name__ == "__main__":
     n_calls = int(sys.argv[4]) if len(sys.argv) > 4 else 30
     with mp.Pool(max(1, (os.cpu_count() or 2) - 1)) as pool:
         rows = pool.map(work, [(s, n_ep, n_calls) for s in seeds], chunksize=1)
-    tot = np.zeros(4, dtype=int)
-    for seed, n, tol, ticks, ns, bad_s, bad, mx_s, mx, it in rows:
-        tot += (ticks, ns, bad_s, bad)
+    tot = np.zeros(6, dtype=int)
+    for seed, n, tol, ticks, ns, bad_s, bad, mx_s, mx, it, worse, better, dfmax in rows:
+        tot += (ticks, ns, bad_s, bad, worse, better)
         print("seed %d control_steps %2d opt_tolerance %.0e: %4d converged ticks, %4d settled; command more than 1e-3 from the "
-              "reference's: %d settled (%d of all); max %.2e settled (%.2e all); iterations %.2f"
-              % (seed, n, tol, ticks, ns, bad_s, bad, mx_s, mx, it))
+              "reference's: %d settled (%d of all); max %.2e settled (%.2e all); of those the build's objective is more than 1e-3 "
+              "above / below the reference's on %d / %d (largest f - f_ref %.2e); iterations %.2f"
+              % (seed, n, tol, ticks, ns, bad_s, bad, mx_s, mx, worse, better, dfmax, it))
     print("%d parameter sets: %d converged ticks, %d settled; command more than 1e-3 from the reference's converged command on %d "
-          "settled ticks (%.3f %%), on %d of all" % (len(rows), tot[0], tot[1], tot[2], 100.0 * tot[2] / max(1, tot[1]), tot[3]))
+          "settled ticks (%.3f %%), on %d of all; on %d of those settled ticks the build's objective is more than 1e-3 above the "
+          "reference's, on %d more than 1e-3 below (the others: another KKT point of the same value)"
+          % (len(rows), tot[0], tot[1], tot[2], 100.0 * tot[2] / max(1, tot[1]), tot[3], tot[4], tot[5]))
