@@ -356,6 +356,19 @@ int neo_mpc_unpin_host_memory(void* ptr);
 int neo_mpc_set_host_path(neo_mpc_handle* handle, int mode);
 /* Same with every pointer in device memory; enqueued on `stream`, returns without waiting. */
 int neo_mpc_solve_batch_device(neo_mpc_handle* handle, const neo_mpc_batch* batch, void* stream);
+
+/* Balanced dispatch for a fleet's NEXT tick (round 5; optional, changes no result).  A launch of up to 4096 instances is one
+ * residency round on an MI355X -- workgroups w, w + 1024, w + 2048, w + 3072 share a SIMD -- and ends with the SIMD whose
+ * four searches need the most iterations.  Robots keep their habits from tick to tick, so the iteration counts of the
+ * previous tick (`d_previous_commands[i].iterations`, device memory, `count` records) predict the next tick's load: the
+ * library sorts the instances by them, deals them over the SIMDs longest first, and the following
+ * neo_mpc_solve_batch_device[_timed] calls OF THE SAME COUNT on this handle solve instance order[w] in workgroup w (every
+ * array of the batch stays in the caller's order; every instance's result is bit for bit what it is without).  The order
+ * is built by a small kernel on `stream` -- enqueue the next solve behind it, i.e. on the same stream or behind an event.
+ * Refresh it every few ticks; counts that are not a multiple of 1024, or beyond 4096, get launch order.
+ * d_previous_commands == NULL: back to launch order. */
+int neo_mpc_balance_dispatch_device(neo_mpc_handle* handle, const neo_mpc_command* d_previous_commands, size_t count,
+                                    void* stream);
 /* Same; `start_event` / `stop_event` (hipEvent_t, either may be NULL) are stamped with the start and the
  * end of the solve kernel by the dispatch itself (hipExtLaunchKernel): a measurement harness gets K1's
  * duration without putting event-record packets between consecutive launches. */

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("NEO_MPC_LIB") or os.path.join(HERE, "libneo_mpc.so")
 
 #: every symbol include/neo_mpc.h declares
 EXPORTS = (
-    "neo_mpc_abi_version", "neo_mpc_behaviour_version", "neo_mpc_effective_method", "neo_mpc_last_error", "neo_mpc_last_error_code", "neo_mpc_default_params", "neo_mpc_create",
+    "neo_mpc_abi_version", "neo_mpc_behaviour_version", "neo_mpc_effective_method", "neo_mpc_balance_dispatch_device", "neo_mpc_last_error", "neo_mpc_last_error_code", "neo_mpc_default_params", "neo_mpc_create",
     "neo_mpc_destroy", "neo_mpc_set_params", "neo_mpc_get_params", "neo_mpc_set_costmap",
     "neo_mpc_set_costmap_device", "neo_mpc_set_costmap_pool", "neo_mpc_set_costmap_pool_device", "neo_mpc_solve_batch", "neo_mpc_solve_batch_device",
     "neo_mpc_solve_batch_device_timed", "neo_mpc_solve_batch_begin", "neo_mpc_solve_batch_wait",
@@ -100,6 +100,7 @@ def load():
         lib.neo_mpc_behaviour_version.restype = C.c_int
         lib.neo_mpc_effective_method.restype = C.c_int
         lib.neo_mpc_effective_method.argtypes = [C.c_void_p]
+        lib.neo_mpc_balance_dispatch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     _lib = lib
     return lib
 

@@ -93,6 +93,8 @@ struct neo_mpc_handle {
   // staging block and one device arena, so a tick is one H2D, K1, one D2H and one synchronisation
   void* pin = nullptr;
   DeviceBuffer arena;
+  DeviceBuffer order_buf;     // dispatch order of device batches (neo_mpc_balance_dispatch_device)
+  size_t order_count = 0;     // ... armed for batches of this many instances; 0: launch order
   // Stream ordering around the device map: every ingest records map_ready on the stream it ran on and
   // every solve / postprocess / objective launch waits for it on its own stream; every such launch
   // records the in-use event OF ITS STREAM (one per distinct stream the caller has used), and the next
@@ -502,7 +504,7 @@ void neo_mpc_destroy(neo_mpc_handle* h) {
   DeviceBuffer* all[] = {&h->map_buf, &h->raw_buf, &h->term_buf, &h->problems, &h->states, &h->warm, &h->commands,
                          &h->solution, &h->path, &h->footprints, &h->success, &h->u, &h->cost, &h->plan_poses,
                          &h->plan_offsets, &h->robot_poses, &h->fp_costs, &h->slow_down, &h->carrots, &h->vel,
-                         &h->arena, &h->origins_buf};
+                         &h->arena, &h->origins_buf, &h->order_buf};
   for (DeviceBuffer* b : all) b->release();
   if (h->pin) (void)hipHostFree(h->pin);
   if (h->map_ready) (void)hipEventDestroy(h->map_ready);
@@ -588,9 +590,24 @@ int neo_mpc_solve_batch_device_timed(neo_mpc_handle* h, const neo_mpc_batch* bat
   if (rc) return rc;
   HIP_TRY(hipSetDevice(h->device));  // the stream and the buffers must belong to the handle's device
   if ((rc = map_acquire(h, stream))) return rc;
+  if (h->order_count != 0 && h->order_count == batch->count) a.order = (const uint32_t*)h->order_buf.ptr;
   launch_solve(a, h->tuning, stream, start_event, stop_event);
   HIP_TRY(hipGetLastError());
   return map_release(h, stream);
+}
+
+// Balanced dispatch for a fleet's next tick (K5): see k_dispatch_order.  Results do not depend on it.
+int neo_mpc_balance_dispatch_device(neo_mpc_handle* h, const neo_mpc_command* d_previous_commands, size_t count, void* stream) {
+  if (!h) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "null handle");
+  if (!d_previous_commands || count == 0) { h->order_count = 0; return NEO_MPC_OK; }
+  if (count > 0xffffffffull) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "count too large");
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = h->order_buf.reserve(count * sizeof(uint32_t));
+  if (rc) return rc;
+  launch_dispatch_order(d_previous_commands, (uint32_t*)h->order_buf.ptr, (uint32_t)count, stream);
+  HIP_TRY(hipGetLastError());
+  h->order_count = count;
+  return NEO_MPC_OK;
 }
 
 int neo_mpc_solve_batch_device(neo_mpc_handle* h, const neo_mpc_batch* batch, void* stream) {

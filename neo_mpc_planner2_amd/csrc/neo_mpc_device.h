@@ -157,6 +157,7 @@ struct SolveArgs {
   neo_mpc_state* states_out; // where K2 writes the state / the warm start back: the arrays they were read from
   double* warm_out;          // (device batches), or the caller's page-locked host arrays (neo_mpc_solve_batch)
   const double* term_table;  // [256] per-step costmap term by raw cell value
+  const uint32_t* order;     // optional: workgroup w solves instance order[w] (neo_mpc_balance_dispatch_device); null: w
   uint32_t footprint_points;
   uint32_t count;
   DevParams p;
@@ -205,5 +206,8 @@ void launch_carrots(const CarrotArgs& a, void* stream);
 void launch_postprocess(const SolveArgs& a, void* stream);
 void launch_objective(const ObjectiveArgs& a, void* stream);
 void launch_ingest(const IngestArgs& a, const LaunchTuning& t, void* stream);
+// K5: dispatch order of the next launch from the iteration counts of the previous one (neo_mpc_balance_dispatch_device)
+void launch_dispatch_order(const neo_mpc_command* commands, uint32_t* order, uint32_t count, void* stream);
+constexpr uint32_t kDispatchSimds = 1024;   // a 4096-instance launch is one residency round: workgroups w, w + 1024, w + 2048, w + 3072 share a SIMD
 
 }  // namespace neo_mpc

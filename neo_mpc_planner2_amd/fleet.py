@@ -13,11 +13,14 @@ import numpy as np
 from . import abi
 
 
-def closed_loop(solver, batch, ticks, hz=30.0, before_tick=None, after_tick=None):
+def closed_loop(solver, batch, ticks, hz=30.0, before_tick=None, after_tick=None, balance_every=0):
     """Run `ticks` control ticks of `batch` (a solver.DeviceBatch) through `solver` (a BatchSolver with its costmap
     set).  Returns per-tick lists: kernel_ms (HIP events around the K1 launch), mean_iterations, max_iterations,
     stopped_fraction.  `before_tick(t, pos)` runs before tick t's launch (e.g. re-centre a costmap pool),
-    `after_tick(t, commands)` after its commands are on the host."""
+    `after_tick(t, commands)` after its commands are on the host.  `balance_every` = R > 0: every R-th tick the
+    dispatch order of the following ticks is rebuilt from that tick's iteration counts (neo_mpc_balance_dispatch_device:
+    one small kernel behind K1 on the same stream; `balance_ms` in the result is its own duration) -- results do not
+    depend on it, only which robots share a SIMD."""
     import torch
     b = batch
     P = b.problems.view(torch.float64).reshape(b.count, -1)          # the 32 doubles of each request
@@ -40,10 +43,17 @@ def closed_loop(solver, batch, ticks, hz=30.0, before_tick=None, after_tick=None
         e1.record(stream)
     torch.cuda.synchronize()
     out = {"kernel_ms": [], "mean_iterations": [], "max_iterations": [], "stopped_fraction": []}
+    bal_evs = []
     for t in range(ticks):
         if before_tick is not None:
             before_tick(t, pos)
         solver.solve_device(b.problems, b.states, b.warm, b.commands, velocities=b.vel, events=evs[t])
+        if balance_every and t % balance_every == 0:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            solver.balance_dispatch(b.commands)
+            e1.record(stream)
+            bal_evs.append((e0, e1))
         cmd = b.vel
         yaw = yaw + cmd[:, 2] / hz
         c, sn = torch.cos(yaw), torch.sin(yaw)
@@ -70,6 +80,10 @@ def closed_loop(solver, batch, ticks, hz=30.0, before_tick=None, after_tick=None
         if after_tick is not None:
             after_tick(t, cm)
     out["kernel_ms"] = [a.elapsed_time(e) for a, e in evs]
+    if bal_evs:
+        out["balance_ms"] = [a.elapsed_time(e) for a, e in bal_evs]
+        out["balance_every"] = balance_every
+        solver.balance_dispatch(None)
     return out
 
 
@@ -80,4 +94,9 @@ def summary(loop, skip=5):
             "ms_per_tick_max": float(np.max(ms[skip:])), "mean_iterations": float(np.mean(it[skip:])),
             "max_iterations_median": float(np.median(mx[skip:])), "max_iterations_max": int(np.max(mx[skip:])),
             "cold_tick_ms": float(ms[0]), "cold_tick_mean_iterations": float(it[0]),
-            "stopped_fraction_last_tick": float(loop["stopped_fraction"][-1])}
+            "stopped_fraction_last_tick": float(loop["stopped_fraction"][-1]),
+            # balanced dispatch (closed_loop(balance_every=R)): the order kernel's own duration (events around it, launch
+            # gaps included) and its share of a tick when it runs every R-th tick
+            **({"balance_every": loop["balance_every"], "order_kernel_ms_median": float(np.median(loop["balance_ms"])),
+                "ms_per_tick_median_incl_order": float(np.median(ms[skip:]) + np.median(loop["balance_ms"]) / loop["balance_every"])}
+               if "balance_ms" in loop else {})}

@@ -275,6 +275,19 @@ class BatchSolver:
         _lib.check(self._lib.neo_mpc_select_carrots_device(self._handle, C.byref(lp), C.byref(b), C.c_void_p(stream)))
 
     # -- device-resident batches (torch tensors as plain device memory) ----------------
+    def balance_dispatch(self, commands, stream=None):
+        """Dispatch order of the following device solves of the same count from the iteration counts in `commands` (a CUDA
+        uint8 tensor of command records, e.g. the previous tick's; None: back to launch order) --
+        neo_mpc_balance_dispatch_device.  Enqueued on `stream` (default: torch's current).  Changes no result."""
+        if commands is None:
+            _lib.check(self._lib.neo_mpc_balance_dispatch_device(self._handle, None, 0, None))
+            return
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream(commands.device).cuda_stream
+        _lib.check(self._lib.neo_mpc_balance_dispatch_device(self._handle, C.c_void_p(commands.data_ptr()), commands.shape[0],
+                                                             C.c_void_p(stream)))
+
     def solve_device(self, problems, states, warm, commands, solution=None, path=None, footprints=None,
                      stream=None, velocities=None, events=None):
         """All arguments are CUDA uint8/float64 torch tensors holding the C records

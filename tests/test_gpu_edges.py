@@ -471,3 +471,44 @@ def test_host_entry_point_on_page_locked_buffers():
         assert cmds_b is out[0] and x_b is out[1]
         assert np.array_equal(x_a, x_b) and cmds_a.tobytes() == cmds_b.tobytes()
         assert st_a.tobytes() == p_st.tobytes() and np.array_equal(warm_a, p_warm)
+
+
+@pytest.mark.parametrize("count", [4096, 2048, 1500, 5000])
+def test_balanced_dispatch_changes_no_result(count):
+    """neo_mpc_balance_dispatch_device: the dispatch order of the next device solves is rebuilt from the previous tick's
+    iteration counts (K5) so that the searches sharing a SIMD need about the same number of iterations in total.  Instances
+    are independent: commands, states, warm starts and solutions of every instance are bit for bit what they are in launch
+    order -- which also says that the order is a permutation (an instance left out would keep its zeros, one solved twice
+    would have advanced its state twice) -- for a one-round launch, a smaller multiple of 1024, and counts that get launch
+    order (not a multiple of 1024; more than one round).  A batch of another size ignores the order; NULL disarms it."""
+    import torch
+    from neo_mpc_planner2_amd.solver import BatchSolver, DeviceBatch
+    params = util.orc.make_params()
+    cfg, cmap, probs, st, warm = synthetic.make_workload("C2", seed=5, batch=count)
+    with BatchSolver(params) as s:
+        s.set_costmap(*cmap)
+        runs = []
+        for balanced in (False, True):
+            db = DeviceBatch(probs, st, warm, "cuda:0")
+            P = db.problems.view(torch.float64).reshape(count, -1)
+            per_tick = []
+            for t in range(4):
+                s.solve_device(db.problems, db.states, db.warm, db.commands, solution=db.solution)
+                if balanced:
+                    s.balance_dispatch(db.commands)
+                P[:, 19:22] = db.commands.view(torch.float64).reshape(count, -1)[:, 0:3]     # cur_vel <- the command
+                torch.cuda.synchronize()
+                per_tick.append((db.commands_host().copy(), db.states_host().copy(), db.warm.cpu().numpy().copy(),
+                                 db.solution.cpu().numpy().copy()))
+            if balanced:   # a batch of another size on the same handle: launch order, same results as ever
+                half = DeviceBatch(probs[: count // 2], st[: count // 2], warm[: count // 2], "cuda:0")
+                s.solve_device(half.problems, half.states, half.warm, half.commands)
+                torch.cuda.synchronize()
+                assert half.commands_host().tobytes() == runs[0][0][0][: count // 2].tobytes()
+                s.balance_dispatch(None)
+            runs.append(per_tick)
+    for t in range(4):
+        for a, b in zip(runs[0][t], runs[1][t]):
+            assert a.tobytes() == b.tobytes(), t
+    it = runs[0][3][0]["iterations"]
+    assert (it > 0).all() and it.max() > it.min()      # (a spread of loads: there was something to balance)
