@@ -31,6 +31,8 @@ extern "C" {
 /* ABI 2 (round 4): neo_mpc_behaviour_version(); NEO_MPC_COMPAT_REFERENCE_START; unknown compat bits and the forced
  * directions without a wall model at a heavy costmap weight are refused; neo_mpc_problem.skip (was reserved[0]) and
  * NEO_MPC_FLAG_SKIPPED; neo_mpc_carrot.status 3.  No record changed its size or the offset of a field that existed.
+ * Round 5 added entry points only (neo_mpc_effective_method, neo_mpc_balance_dispatch_device) and gave the last 28 bytes
+ * of neo_mpc_state, reserved until then, a meaning (has_prev_u0, prev_u0): still ABI 2.
  *
  * Behaviour history (iterates and iteration counts differ between versions, results stay inside the parity protocol of
  * DESIGN.md section 1; neo_mpc_behaviour_version() returns the number of the build that answers):
