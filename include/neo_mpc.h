@@ -363,7 +363,8 @@ int neo_mpc_solve_batch_device(neo_mpc_handle* handle, const neo_mpc_batch* batc
  * residency round on an MI355X -- workgroups w, w + 1024, w + 2048, w + 3072 share a SIMD -- and ends with the SIMD whose
  * four searches need the most iterations.  Robots keep their habits from tick to tick, so the iteration counts of the
  * previous tick (`d_previous_commands[i].iterations`, device memory, `count` records) predict the next tick's load: the
- * library sorts the instances by them, deals them over the SIMDs longest first, and the following
+ * library sorts the instances by them (by their exponential average over successive calls of the same count, decay 1/2),
+ * deals them over the SIMDs longest first, and the following
  * neo_mpc_solve_batch_device[_timed] calls OF THE SAME COUNT on this handle solve instance order[w] in workgroup w (every
  * array of the batch stays in the caller's order; every instance's result is bit for bit what it is without).  The order
  * is built by a small kernel on `stream` -- enqueue the next solve behind it, i.e. on the same stream or behind an event.

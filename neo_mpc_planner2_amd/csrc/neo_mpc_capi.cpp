@@ -94,6 +94,7 @@ struct neo_mpc_handle {
   void* pin = nullptr;
   DeviceBuffer arena;
   DeviceBuffer order_buf;     // dispatch order of device batches (neo_mpc_balance_dispatch_device)
+  DeviceBuffer load_buf;      // ... and the exponential average of the iteration counts it is sorted by
   size_t order_count = 0;     // ... armed for batches of this many instances; 0: launch order
   // Stream ordering around the device map: every ingest records map_ready on the stream it ran on and
   // every solve / postprocess / objective launch waits for it on its own stream; every such launch
@@ -504,7 +505,7 @@ void neo_mpc_destroy(neo_mpc_handle* h) {
   DeviceBuffer* all[] = {&h->map_buf, &h->raw_buf, &h->term_buf, &h->problems, &h->states, &h->warm, &h->commands,
                          &h->solution, &h->path, &h->footprints, &h->success, &h->u, &h->cost, &h->plan_poses,
                          &h->plan_offsets, &h->robot_poses, &h->fp_costs, &h->slow_down, &h->carrots, &h->vel,
-                         &h->arena, &h->origins_buf, &h->order_buf};
+                         &h->arena, &h->origins_buf, &h->order_buf, &h->load_buf};
   for (DeviceBuffer* b : all) b->release();
   if (h->pin) (void)hipHostFree(h->pin);
   if (h->map_ready) (void)hipEventDestroy(h->map_ready);
@@ -604,7 +605,10 @@ int neo_mpc_balance_dispatch_device(neo_mpc_handle* h, const neo_mpc_command* d_
   HIP_TRY(hipSetDevice(h->device));
   int rc = h->order_buf.reserve(count * sizeof(uint32_t));
   if (rc) return rc;
-  launch_dispatch_order(d_previous_commands, (uint32_t*)h->order_buf.ptr, (uint32_t)count, stream);
+  if ((rc = h->load_buf.reserve(count * sizeof(float)))) return rc;
+  // (the average is kept while calls of the same count follow one another; disarming or another count starts it afresh)
+  const bool fresh = h->order_count != count;
+  launch_dispatch_order(d_previous_commands, (float*)h->load_buf.ptr, (uint32_t*)h->order_buf.ptr, (uint32_t)count, fresh, stream);
   HIP_TRY(hipGetLastError());
   h->order_count = count;
   return NEO_MPC_OK;

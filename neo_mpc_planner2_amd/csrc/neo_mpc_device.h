@@ -207,7 +207,7 @@ void launch_postprocess(const SolveArgs& a, void* stream);
 void launch_objective(const ObjectiveArgs& a, void* stream);
 void launch_ingest(const IngestArgs& a, const LaunchTuning& t, void* stream);
 // K5: dispatch order of the next launch from the iteration counts of the previous one (neo_mpc_balance_dispatch_device)
-void launch_dispatch_order(const neo_mpc_command* commands, uint32_t* order, uint32_t count, void* stream);
+void launch_dispatch_order(const neo_mpc_command* commands, float* load, uint32_t* order, uint32_t count, bool fresh, void* stream);
 constexpr uint32_t kDispatchSimds = 1024;   // a 4096-instance launch is one residency round: workgroups w, w + 1024, w + 2048, w + 3072 share a SIMD
 
 }  // namespace neo_mpc

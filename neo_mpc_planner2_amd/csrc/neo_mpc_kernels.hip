@@ -1158,19 +1158,23 @@ void launch_objective(const ObjectiveArgs& a, void* stream) {
 // (measured with the XCC id in the hardware key) and the SIMD with the largest sum of iterations ends the
 // launch -- 23.5 iteration-slots against a mean of 13.9 in the closed loop of 4096 robots.  Robots keep their habits from one
 // tick to the next (correlation of the iteration counts of consecutive ticks 0.79: stopped robots 2, cruising robots 3,
-// robots along a wall 8 and more), so the previous tick's counts predict this tick's load: instances sorted by them,
-// longest first, and dealt over the 1024 SIMDs in snake order (slot 0 left to right, slot 1 right to left, ...) bring the
-// maximum down to 21.  One workgroup, a counting sort by min(iterations, 127); ranks among equal counts come from atomics
-// (any order of equals is as good as another).  Counts that are not a multiple of 1024 or beyond 4096 (more than one
-// round: the hardware deals waves as slots free up) get the identity.
-__global__ __launch_bounds__(1024) void k_dispatch_order(const neo_mpc_command* commands, uint32_t* order, uint32_t count) {
-  __shared__ uint32_t hist[128];
+// robots along a wall 8 and more), so past counts predict this tick's load: instances sorted by them, longest first, and
+// dealt over the 1024 SIMDs in snake order (slot 0 left to right, slot 1 right to left, ...) bring the maximum down to 21
+// with the last tick's counts alone, to 20.3 with `load` = an exponential average over the calls (decay 1/2: the handle
+// keeps it between calls; on the mirror's closed loop, the order rebuilt every 5th tick).  One workgroup, a counting sort
+// over 512 bins of a quarter of an iteration; ranks among equals come from atomics (any order of equals is as good as
+// another).  Counts that are not a multiple of 1024 or beyond 4096 (more than one round: the hardware deals waves as slots
+// free up) get the identity.
+__global__ __launch_bounds__(1024) void k_dispatch_order(const neo_mpc_command* commands, float* load, uint32_t* order,
+                                                         uint32_t count, int fresh) {
+  constexpr uint32_t kBins = 512;
+  __shared__ uint32_t hist[kBins], scan[kBins];
   const uint32_t t = threadIdx.x;
   if (count % kDispatchSimds != 0 || count > 4 * kDispatchSimds) {
     for (uint32_t i = t; i < count; i += 1024) order[i] = i;
     return;
   }
-  if (t < 128) hist[t] = 0;
+  if (t < kBins) hist[t] = 0;
   __syncthreads();
   uint32_t key[4], rank[4];
 #pragma unroll
@@ -1178,30 +1182,38 @@ __global__ __launch_bounds__(1024) void k_dispatch_order(const neo_mpc_command* 
     const uint32_t i = t + 1024u * k;
     if (i < count) {
       const int it = commands[i].iterations;
-      key[k] = 127u - (uint32_t)(it < 0 ? 0 : it > 127 ? 127 : it);   // ascending key = descending iteration count
+      const float now = (float)(it < 0 ? 0 : it > 127 ? 127 : it);
+      const float e = fresh ? 2.0f * now : 0.5f * load[i] + now;     // (a fresh average starts at its steady state)
+      load[i] = e;
+      const uint32_t q = (uint32_t)fminf(2.0f * e + 0.5f, (float)(kBins - 1));   // (e is twice the count in the steady state)
+      key[k] = kBins - 1u - q;                                        // ascending key = descending load
       rank[k] = atomicAdd(&hist[key[k]], 1u);
     }
   }
   __syncthreads();
-  if (t == 0) {
-    uint32_t run = 0;
-    for (int k = 0; k < 128; ++k) { const uint32_t h = hist[k]; hist[k] = run; run += h; }
+  // exclusive prefix sum over the bins (Hillis-Steele, 9 steps, two buffers)
+  uint32_t* src = hist;
+  uint32_t* dst = scan;
+  for (uint32_t d = 1; d < kBins; d <<= 1) {
+    if (t < kBins) dst[t] = src[t] + (t >= d ? src[t - d] : 0u);
+    __syncthreads();
+    uint32_t* tmp = src; src = dst; dst = tmp;
   }
-  __syncthreads();
+  // (src holds the inclusive sums)
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const uint32_t i = t + 1024u * k;
     if (i < count) {
-      const uint32_t pos = hist[key[k]] + rank[k], slot = pos / kDispatchSimds;
+      const uint32_t pos = (key[k] ? src[key[k] - 1u] : 0u) + rank[k], slot = pos / kDispatchSimds;
       uint32_t lane = pos % kDispatchSimds;
       if (slot & 1u) lane = kDispatchSimds - 1u - lane;
       order[slot * kDispatchSimds + lane] = i;
     }
   }
 }
-void launch_dispatch_order(const neo_mpc_command* commands, uint32_t* order, uint32_t count, void* stream) {
+void launch_dispatch_order(const neo_mpc_command* commands, float* load, uint32_t* order, uint32_t count, bool fresh, void* stream) {
   if (count == 0) return;
-  hipLaunchKernelGGL(k_dispatch_order, dim3(1), dim3(1024), 0, (hipStream_t)stream, commands, order, count);
+  hipLaunchKernelGGL(k_dispatch_order, dim3(1), dim3(1024), 0, (hipStream_t)stream, commands, load, order, count, fresh ? 1 : 0);
 }
 void launch_ingest(const IngestArgs& a, const LaunchTuning& tuning, void* stream) {
   const long total = (long)a.rows * (a.pitch >> 4);
