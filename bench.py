@@ -412,13 +412,13 @@ def warm_tick(dev, local_rank, ticks=60):
         solver.set_costmap(torch.from_numpy(cmap[0]).to(dev), *cmap[1:])
         b = DeviceBatch(probs, st, warm, dev, want_solution=False)
         plain = fleet.summary(fleet.closed_loop(solver, b, ticks))
-        # ... and as a fleet server runs it: every 10th tick the dispatch order of the following ticks is rebuilt from that
+        # ... and as a fleet server runs it: every 5th tick the dispatch order of the following ticks is rebuilt from that
         # tick's iteration counts (neo_mpc_balance_dispatch_device; results bit for bit the same -- tests/test_gpu_edges.py)
         b = DeviceBatch(probs, st, warm, dev, want_solution=False)
-        res = fleet.summary(fleet.closed_loop(solver, b, ticks, balance_every=10))
+        res = fleet.summary(fleet.closed_loop(solver, b, ticks, balance_every=5))
     res["what"] = ("C2 fleet in closed loop: 4096 robots, 30 Hz, robots moved by their own commands, warm start = the "
                    "previous solution shifted by one control step; kernel ms between events around each tick's launch; "
-                   "dispatch order rebuilt every 10th tick from the iteration counts (their exponential average over the rebuilds; balanced dispatch), "
+                   "dispatch order rebuilt every 5th tick from the iteration counts (their exponential average over the rebuilds; balanced dispatch), "
                    "`launch_order`: the same loop without")
     res["solves_per_s"] = 4096 / (1e-3 * res["ms_per_tick_median_incl_order"])
     res["launch_order"] = {k: plain[k] for k in ("ms_per_tick_median", "ms_per_tick_max", "mean_iterations", "max_iterations_median",
