@@ -113,6 +113,9 @@ int main(int argc, char** argv) {
       b.count = count; b.problems = r.problems; b.states = r.states; b.warm_start = r.warm; b.commands = r.commands;
       b.velocities = r.vel;
       CHECK_MPC(neo_mpc_solve_batch_device(r.h, &b, r.stream));
+      // balanced dispatch: every 5th tick the robots are re-dealt over the SIMDs by their iteration counts (same stream,
+      // behind the solve; no result depends on it)
+      if (tick % 5 == 0) CHECK_MPC(neo_mpc_balance_dispatch_device(r.h, r.commands, count, r.stream));
     }
     auto g0 = std::chrono::steady_clock::now();
     CHECK_MPC(neo_mpc_group_start());   // the single exchange step
