@@ -21,6 +21,8 @@ cp $F/tick_latency.json profiles/${T}_tick_latency.json
 cp $F/gpu_tests.log profiles/${T}_gpu_tests.txt
 cp $F/host_path.json profiles/${T}_host_path.json
 cp $F/split_call.json profiles/${T}_split_call.json
+cp $F/balanced_dispatch.json profiles/${T}_balanced_dispatch.json
+cp $F/soak_fleet.json profiles/${T}_soak_fleet.json
 cp $F/opcodes_c2.txt profiles/${T}_opcodes_c2.txt
 cp $F/opcodes_riccati.txt profiles/${T}_opcodes_riccati.txt
 cp gpurun_out/prof_${TAG}_k1cal/calibration.json profiles/${T}_k1_traffic_calibration.json

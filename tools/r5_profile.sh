@@ -28,6 +28,8 @@ timeout 300 python tools/bench_fleet_loop.py --pool 2>/dev/null | tail -1 > $O/f
 timeout 120 python tools/bench_tick_latency.py 2>/dev/null | tail -1 > $O/tick_latency.json
 timeout 600 python tools/bench_host_path.py 2>/dev/null | tail -1 > $O/host_path.json
 timeout 300 python tools/bench_split_call.py 2>/dev/null | tail -1 > $O/split_call.json
+timeout 300 python tools/bench_balance.py 2>/dev/null | tail -1 > $O/balanced_dispatch.json
+timeout 600 python tools/soak_fleet.py 2>/dev/null | tail -1 > $O/soak_fleet.json
 python tools/opcode_histogram.py k_solveILi4ELi3ELi1ELb1ELi1024E > $O/opcodes_c2.txt 2>&1
 python tools/opcode_histogram.py k_solveILi4ELi0ELi2ELb1ELi0E > $O/opcodes_riccati.txt 2>&1
 cat $O/gpu_tests.log; cut -c1-1500 $O/bench_c2.json; grep -v amdgpu $O/parity_report.txt | tail -30; cat $O/fleet_loop.json | cut -c1-400; cat $O/tick_latency.json
