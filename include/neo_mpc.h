@@ -59,8 +59,15 @@ extern "C" {
  *      pinned LBFGS / NEWTON direction that a neo_mpc_set_params call takes across w_costmap = w_trans / 4 runs the
  *      stage-wise direction from there on (neo_mpc_effective_method) instead of failing the reconfigure; neo_mpc_create
  *      still refuses the combination.  neo_mpc_problem.skip: host batches with values other than 0 / 1 are refused.
+ *   6  (round 6) AUTO at control_steps 3 (below w_costmap = w_trans / 4): DIRECTION BY NEIGHBOURHOOD.  An instance with a
+ *      lethal cell (raw 254, or the outside of the map) among the cells of its reach tile -- NEO_MPC_FLAG_WALL_IN_REACH says
+ *      so in its command -- is solved by the stage-wise direction (wall model, hop candidates; with the control_steps-3
+ *      stop rules), every other instance by the dense direction as before; one launch, one kernel (k_solve_routed).  The
+ *      dense direction has no wall model: every objective miss of random-parameter runs against the reference at
+ *      control_steps 3 was a dense search hemmed in by lethal cells.  method = NEO_MPC_METHOD_NEWTON is the dense direction
+ *      for every instance (version 5's AUTO at control_steps 3).
  * method = NEO_MPC_METHOD_NEWTON / _LBFGS / _RICCATI pins a direction. */
-#define NEO_MPC_BEHAVIOUR_VERSION 5
+#define NEO_MPC_BEHAVIOUR_VERSION 6
 
 /* return codes */
 #define NEO_MPC_OK 0
@@ -80,6 +87,10 @@ extern "C" {
 #define NEO_MPC_FLAG_SKIPPED 4 /* neo_mpc_problem.skip was set: no request was made for this robot this tick (cpp:234-236).
                                   Its state record and warm start have not been touched; the command is zero twist with this
                                   flag alone, its rows of solution / predicted_path / velocities are zero */
+#define NEO_MPC_FLAG_WALL_IN_REACH 8 /* a lethal cell (raw 254) -- or the outside of the map -- lies within the cells a feasible
+                                  rollout of this robot can reach (the solver's reach tile; always set when the reach is too
+                                  long for a tile).  Under NEO_MPC_METHOD_AUTO at control_steps 3 such an instance was solved
+                                  by the stage-wise direction, every other one by the dense direction */
 
 /* neo_mpc_params.compat_flags */
 #define NEO_MPC_COMPAT_ODOM_YAW_GOAL_W 1 /* py:213: odom_yaw takes quaternion w from the goal pose */
@@ -91,8 +102,10 @@ extern "C" {
 #define NEO_MPC_COMPAT_ALL (NEO_MPC_COMPAT_ODOM_YAW_GOAL_W | NEO_MPC_COMPAT_REFERENCE_START) /* any other bit: INVALID_ARGUMENT */
 
 /* neo_mpc_params.method */
-#define NEO_MPC_METHOD_AUTO 0   /* dense Newton at control_steps == 3 (the register-resident 9 x 9 kernel),
-                                   stage-wise (Riccati) Newton at every other control_steps -- and at 3 when
+#define NEO_MPC_METHOD_AUTO 0   /* control_steps == 3: by neighbourhood -- dense Newton (the register-resident 9 x 9
+                                   system) for an instance with no lethal cell in reach, stage-wise (Riccati) Newton
+                                   for one next to a wall (NEO_MPC_FLAG_WALL_IN_REACH), in one launch; stage-wise
+                                   Newton at every other control_steps -- and for every instance at 3 when
                                    w_costmap > w_trans / 4 (cost steps become walls: the wall model is part
                                    of the stage-wise direction) */
 #define NEO_MPC_METHOD_LBFGS 1  /* projected L-BFGS, any control_steps */
@@ -292,7 +305,9 @@ int neo_mpc_set_params(neo_mpc_handle* handle, const neo_mpc_params* params);
 int neo_mpc_get_params(const neo_mpc_handle* handle, neo_mpc_params* params);
 /* The direction the handle's solves run: NEO_MPC_METHOD_LBFGS / _NEWTON / _RICCATI (never AUTO) -- what AUTO resolved to,
  * or the stage-wise direction in place of a pinned LBFGS / NEWTON above w_costmap = w_trans / 4 (see NEO_MPC_METHOD_*);
- * < 0 on a null handle. */
+ * < 0 on a null handle.  AUTO at control_steps 3 below that threshold decides per instance (behaviour 6): NEWTON is the
+ * answer -- the direction of the instances with no wall in reach; those with NEO_MPC_FLAG_WALL_IN_REACH in their command ran
+ * the stage-wise one. */
 int neo_mpc_effective_method(const neo_mpc_handle* handle);
 
 /* Replaces the node's `Costmap2d(self)` subscription (py:118): raw nav2 costs, row-major

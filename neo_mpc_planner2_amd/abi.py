@@ -23,7 +23,8 @@ PROBLEM_DTYPE = np.dtype([
                                     # no polygon is supplied (py:262, 343)
     ("map_index", "<i4"),           # which costmap of a pool (BatchSolver.set_costmap_pool); else ignored
     ("switch_opt", "<i4"),          # request.switch_opt (cpp:245; stored py:354, never read)
-    ("skip", "<i4"),                # != 0: no request is made for this robot this tick (cpp:234-236); state untouched
+    ("skip", "<i4"),                # 1: no request is made for this robot this tick (cpp:234-236); state untouched.  0: solve.
+                                    # Anything else: host batches are refused, device batches solve the robot (include/neo_mpc.h)
     ("reserved_i", "<i4"),
     ("reserved", "<f8", (5,)),
 ], align=False)
@@ -69,6 +70,7 @@ STATUS_MAX_ITER = 1
 FLAG_RESET = 1
 FLAG_STOPPED = 2
 FLAG_SKIPPED = 4
+FLAG_WALL_IN_REACH = 8   # a lethal cell within the robot's reach tile (AUTO at control_steps 3: solved by the stage-wise direction)
 
 ABI_VERSION = 2          # NEO_MPC_ABI_VERSION of include/neo_mpc.h
 COMPAT_ODOM_YAW_GOAL_W = 1

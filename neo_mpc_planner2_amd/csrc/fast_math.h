@@ -25,15 +25,11 @@ __device__ __forceinline__ double rcp_fast(double x) {
 // live across the solver loop, so every step pays a 64-bit move -- ten per sincos, sixty per solver iteration of the
 // control_steps-3 kernel (tools/opcode_histogram.py: v_mov_b64 was the third most frequent vector opcode of the loop).
 __device__ __forceinline__ double fma3(double a, double b, double c) {
-#ifdef NEO_NO_FMA3
-  return fma(a, b, c);
-#else
   // (the addend -- a literal coefficient -- in a SCALAR register pair: two s_mov_b32 on the scalar unit instead of sixteen
   // loop-resident vector registers of coefficients)
   double r;
   asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
   return r;
-#endif
 }
 
 // 1/sqrt(x), x > 0, to ~1e-13 relative: v_rsq_f64 (2^-26.x, tools/rsq_check.hip) and ONE Newton step -- for quantities that

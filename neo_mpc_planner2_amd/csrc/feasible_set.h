@@ -52,10 +52,25 @@ __device__ __forceinline__ void project_block(const DevParams& p, double& b0, do
 
 // candidate step multipliers: lanes 0..31 scale the proximal-gradient step by 2^(-12 + l/2),
 // lanes 32..63 are step lengths along the L-BFGS direction
-__constant__ double kQnSteps[32] = {
-    1.0, 0.84, 1.19, 0.71, 1.41, 0.59, 1.68, 0.5, 2.0, 0.42, 2.38, 0.35, 2.83, 0.25, 4.0, 0.177,
-    0.125, 0.088, 0.0625, 0.044, 0.03125, 0.0156, 0.0078, 0.0039, 0.00195, 0.00098, 4.9e-4, 2.4e-4,
-    1.2e-4, 6e-5, 3e-5, 1.5e-5};
+#define NEO_QN_STEPS                                                                                  \
+  1.0, 0.84, 1.19, 0.71, 1.41, 0.59, 1.68, 0.5, 2.0, 0.42, 2.38, 0.35, 2.83, 0.25, 4.0, 0.177,         \
+  0.125, 0.088, 0.0625, 0.044, 0.03125, 0.0156, 0.0078, 0.0039, 0.00195, 0.00098, 4.9e-4, 2.4e-4,    \
+  1.2e-4, 6e-5, 3e-5, 1.5e-5
+__constant__ double kQnSteps[32] = {NEO_QN_STEPS};
+// Which Newton lanes (32-63, long shots included) step at least / less than a given length: bit `lane` of a 64-bit mask -- a
+// rule that asks "was the iteration won by a step of at least 0.8" tests one bit with scalar instructions instead of
+// comparing a float64 against a constant the compiler keeps in (and, at four waves per SIMD, spills from) a vector register
+// pair all through the solver loop.
+constexpr unsigned long long newton_lanes_at_least(double t) {
+  constexpr double steps[32] = {NEO_QN_STEPS};
+  unsigned long long m = 0;
+  for (int l = 32; l < 64; ++l) {
+    const double s = l >= 61 ? (double)(1 << (l - 58)) : steps[l - 32];
+    if (s >= t) m |= 1ull << l;
+  }
+  return m;
+}
+constexpr unsigned long long kNewtonLanes = 0xffffffff00000000ull;
 
 // kLongShots (Newton directions): lanes 61-63 trade the three shortest step lengths (L-BFGS's last resort)
 // for 8, 16 and 32 -- long shots that find the way out of a lethal cell
@@ -95,9 +110,7 @@ __device__ __forceinline__ void candidate_block(const SolveArgs& a, const Ctx& c
   // step is made with the gradient at u, the other blocks' Newton step was computed with them held: when both correct
   // the same residual the candidate overshoots, the search cuts the step length for everybody (the "hovering" searches
   // of warm-started ticks: 2.2 % of the converged reference's commands missed by more than 1e-3, none with this)
-#ifndef NEO_AB_NO_NEARPUT
   if (near && lane >= 32 && (lane & 1)) { b0 = u[0]; b1 = u[1]; b2 = u[2]; return; }
-#endif
   if (lane < 32 || near) {  // proximal gradient: forward step on the smooth part (for a block next to the kink: reduced
                             // on its face by the tangent-cone pass), prox of the control norm
     if (lane >= 32) step = pstep;

@@ -192,6 +192,11 @@ void derive(neo_mpc_handle* h) {
   neo_rules_derive(&p, &r);
   d.xtol = r.xtol;
   d.kink_radius = r.kink_radius;
+  {
+    neo_rules rs;   // (the rules of the instances the routed kernel sends to the stage-wise direction)
+    neo_rules_derive_as(&p, NEO_DIRECTION_STAGEWISE, &rs);
+    d.kink_radius_stagewise = rs.kink_radius;
+  }
   d.stall_step = r.stall_step;
   d.hop_min_drop = r.hop_min_drop;
   d.hop_range = h->has_map ? neo_rules_hop_range(d.dt, h->map.resolution) : NEO_RULE_HOP_DIST;
@@ -211,6 +216,10 @@ void derive(neo_mpc_handle* h) {
   // the reference's SLSQP solves at w_costmap = 0.3 (G8 "turn") the dense direction ends 3e-3 and 9e-3 above
   // SLSQP's value in 2 of 24 cases, the stage-wise one in none.
   d.newton = r.direction;
+  // (round 6) AUTO at control_steps 3: direction by neighbourhood -- dense where the reach tile is all free, stage-wise
+  // elsewhere (solver_rules.h neo_rules_routes_by_neighbourhood; method = NEO_MPC_METHOD_NEWTON is the dense direction for
+  // every instance: round 5's AUTO, the A/B partner)
+  d.routed = (neo_rules_routes_by_neighbourhood(&p) && r.direction == NEO_DIRECTION_DENSE) ? 1 : 0;
   d.early_tol = h->no_early ? 0.0 : r.xtol;
   d.final_tol = h->no_early ? 0.0 : r.final_tol;
   d.ftol = r.ftol;
@@ -229,11 +238,8 @@ void derive(neo_mpc_handle* h) {
   l.tile_w = 0; l.tile_h = 0; l.reach = 0;
   if (h->has_map) {
     const int R = neo_rules_reach_cells(&p, h->map.resolution);   // (solver_rules.h: the cell scan's radius too)
-    if (R <= 60) {
-      int w = 4;
-      while (w < 2 * R + 4) w <<= 1;
-      if (w <= kMaxTileWidth) { l.reach = R; l.tile_w = w; l.tile_h = 2 * R + 1; }
-    }
+    const int w = neo_rules_tile_width(R);   // (0: no tile -- a reach beyond 60 cells)
+    if (w) { l.reach = R; l.tile_w = w; l.tile_h = 2 * R + 1; }
   }
   l.total_bytes = off * 8 + l.tile_w * l.tile_h;
   l.total_bytes = (l.total_bytes + 15) & ~15;

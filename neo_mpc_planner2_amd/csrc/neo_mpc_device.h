@@ -4,13 +4,14 @@
 #include <stdint.h>
 
 #include "../../include/neo_mpc.h"
+#include "solver_rules.h"
 
 namespace neo_mpc {
 
 constexpr int kLanes = 64;          // one CDNA4 wavefront per MPC instance
 constexpr int kMapBorder = 64;      // lethal border (cells) K3 adds around a single costmap
 constexpr int kPoolBorder = 16;     // ... around each map of a pool (every lookup is bounds-checked anyway)
-constexpr int kMaxTileWidth = 128;  // widest reach tile staged in LDS (bytes per row)
+constexpr int kMaxTileWidth = NEO_RULE_MAX_TILE_WIDTH;  // widest reach tile staged in LDS (bytes per row; solver_rules.h)
 constexpr int kCompatNoUnshift = 0x10000;   // DevParams.compat (internal bit): searches always start at the warm start (NEO_MPC_COMPAT_REFERENCE_START)
 constexpr int kDumpGradient = 0x40000000;  // DevParams.max_it value of the gradient test hook (neo_mpc_gradient_batch)
 
@@ -34,6 +35,7 @@ struct DevParams {
   double wtol;               // three iterations in a row gaining less than this (relative) end the search; 0: off
   double wtol_late;          // ... the same from iteration kLateIteration on (the control_steps-3 window)
   double kink_radius;        // |u_i - v_cur| below which a block is handled by the prox step only
+  double kink_radius_stagewise;  // ... for the instances the routed kernel sends to the stage-wise direction
   double btol_map, btol_free;  // dense Newton direction: kBlockedRun consecutive iterations not won by a decent Newton step that
                              // together gain less than this end the search (with / without a costmap term under the rollout); 0: off
   double hop_min_drop;       // stage-wise direction: a cheaper neighbour cell is worth a hop candidate when its costmap
@@ -49,6 +51,8 @@ struct DevParams {
   int32_t scan_reach;        // cell scan: no cell further than this from the robot's own cell (= the reach tile's radius)
   int32_t newton;            // search direction of lanes 32-63: 0 projected L-BFGS, 1 projected Newton with
                              // the dense system (control_steps <= 8), 2 projected Newton by the Riccati sweep
+  int32_t routed;            // direction by neighbourhood (AUTO at control_steps 3, solver_rules.h): `newton` is the direction of
+                             // the instances whose reach tile is all free, the others take the stage-wise one (k_solve_routed)
 };
 
 // Device costmap written by the ingest kernel (K3): raw nav2 costs with a lethal border of

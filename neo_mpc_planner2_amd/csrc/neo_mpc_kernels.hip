@@ -75,9 +75,16 @@ constexpr int kLateIteration = NEO_RULE_LATE_ITERATION;
 #define NEO_SEGMENT(k) seg_t##k = wall_clock64()
 #define NEO_SEGMENT_SCAN_BEGIN() seg_scan_at = wall_clock64(); seg_scan = seg_scan_at
 #define NEO_SEGMENT_SCAN_END() seg_scan = wall_clock64() - seg_scan
-#define NEO_SEGMENT_DUMP()                                                                          \
-  a.solution[(size_t)b * nv + 4] = (double)seg_t0; a.solution[(size_t)b * nv + 5] = (double)seg_t1; \
-  a.solution[(size_t)b * nv + 3] = (double)seg_scan; a.solution[(size_t)b * nv + 2] = (double)seg_scan_at
+#define NEO_SEGMENT_DUMP()                                                                                   \
+  {                                                                                                          \
+    SolveArgs ad;                                                                                            \
+    fresh_args<kSteps, kStaticTile, kLayoutSteps, kRouted>(ad);                                              \
+    const int nvd = 3 * ad.p.n;                                                                              \
+    if (ad.solution && lane_again() == 0 && nvd >= 9) {                                                      \
+      ad.solution[(size_t)b * nvd + 4] = (double)seg_t0; ad.solution[(size_t)b * nvd + 5] = (double)seg_t1;  \
+      ad.solution[(size_t)b * nvd + 3] = (double)seg_scan; ad.solution[(size_t)b * nvd + 2] = (double)seg_scan_at; \
+    }                                                                                                        \
+  }
 #else
 #define NEO_SEGMENT_DECL
 #define NEO_SEGMENT(k)
@@ -86,15 +93,15 @@ constexpr int kLateIteration = NEO_RULE_LATE_ITERATION;
 #define NEO_SEGMENT_DUMP()
 #endif
 #define NEO_WAVE_START const unsigned long long wave_t0 = wall_clock64()
-#define NEO_WAVE_END()                                                                              \
-  if (a.solution && lane == 0 && nv >= 9) {                                                        \
+#define NEO_WAVE_END_ARGS(args)                                                                     \
+  if ((args).solution && lane == 0 && (args).p.n >= 3) {                                            \
+    const int nvw = 3 * (args).p.n;                                                                \
     unsigned int hw_id, xcc_id;                                                                    \
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));                            \
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));                          \
-    a.solution[(size_t)b * nv + 6] = (double)wave_t0;                                              \
-    a.solution[(size_t)b * nv + 7] = (double)wall_clock64();                                       \
-    a.solution[(size_t)b * nv + 8] = (double)hw_id + 4294967296.0 * (double)(xcc_id & 15u);        \
-    NEO_SEGMENT_DUMP();                                                                            \
+    (args).solution[(size_t)b * nvw + 6] = (double)wave_t0;                                        \
+    (args).solution[(size_t)b * nvw + 7] = (double)wall_clock64();                                 \
+    (args).solution[(size_t)b * nvw + 8] = (double)hw_id + 4294967296.0 * (double)(xcc_id & 15u);  \
   }
 #define NEO_PHASE_DECL long long phase_clock[8]
 #define NEO_PHASE(k) phase_clock[k] = clock64()
@@ -103,11 +110,12 @@ constexpr int kLateIteration = NEO_RULE_LATE_ITERATION;
     for (int k = 0; k < 6; ++k) a.solution[(size_t)b * nv + k] = (double)(phase_clock[k + 1] - phase_clock[k])
 #else
 #define NEO_WAVE_START
-#define NEO_WAVE_END()
+#define NEO_WAVE_END_ARGS(args)
 #define NEO_SEGMENT_DECL
 #define NEO_SEGMENT(k)
 #define NEO_SEGMENT_SCAN_BEGIN()
 #define NEO_SEGMENT_SCAN_END()
+#define NEO_SEGMENT_DUMP()
 #define NEO_PHASE_DECL
 #define NEO_PHASE(k)
 #define NEO_PHASE_DUMP()
@@ -121,12 +129,34 @@ constexpr int kNewtonMaxSteps = 8;
 // see through) and of the per-instance constants (re-read from the tolerance block of LDS, where the set-up leaves them): the
 // vector-register residents of the solver loop are then dead outside it.  Allocated as ONE live range across the scan they
 // came out spilled -- and reloaded from scratch inside the loop, +20 % on a C2 launch for code that runs once per solve.
-template <int kSteps, int kStaticTile, int kLayoutSteps>
+// kRouted: the stage-wise branch of the routed control_steps-3 kernel (k_solve_routed).  Its LDS carve-up is the stage-wise
+// one for three stages laid INSIDE the dense kernel's (records, tolerance block, term table, iterate and gradients sit at the
+// same offsets in both; the reach tile stays where the set-up staged it), control_steps is the constant 3 -- the run-time-sized
+// code below folds to three stages -- and the prox-only zone around the kink is the stage-wise direction's.
+constexpr int kRoutedSteps = 3;
+constexpr LdsLayout make_routed_stagewise_layout() {
+  LdsLayout l = make_lds_layout(kRoutedSteps, 0, true, true);
+  constexpr LdsLayout dense = make_lds_layout(kRoutedSteps, 4, false);
+  l.tile = dense.tile;
+  l.total_bytes = dense.total_bytes;
+  return l;
+}
+static_assert(make_lds_layout(kRoutedSteps, 0, true, true).tile <= make_lds_layout(kRoutedSteps, 4, false).tile,
+              "the stage-wise arrays of three stages fit in front of the dense kernel's reach tile");
+static_assert(make_lds_layout(kRoutedSteps, 0, true, true).gr == make_lds_layout(kRoutedSteps, 4, false).gr,
+              "records, iterate and gradients share their offsets");
+template <int kSteps, int kStaticTile, int kLayoutSteps, bool kRouted = false>
 __device__ __forceinline__ void fresh_args(SolveArgs& a) {
   auto kp = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();   // (k_solve's only argument: offset 0)
   asm volatile("" : "+s"(kp));
   a = *(const SolveArgs*)kp;
-  if (kSteps || kStaticTile) {  // compile-time LDS offsets (lbfgs_memory is 4 in the specialisations' layout)
+  if (kRouted) {
+    constexpr LdsLayout kLayout = make_routed_stagewise_layout();
+    const int tile_w = a.lds.tile_w, tile_h = a.lds.tile_h, reach = a.lds.reach;
+    a.lds = kLayout;
+    a.lds.tile_w = tile_w; a.lds.tile_h = tile_h; a.lds.reach = reach;
+    a.p.n = kRoutedSteps;
+  } else if (kSteps || kStaticTile) {  // compile-time LDS offsets (lbfgs_memory is 4 in the specialisations' layout)
     constexpr LdsLayout kStaticLayout = make_lds_layout(kLayoutSteps, kSteps ? 4 : 0, false);
     const int tile_w = a.lds.tile_w, tile_h = a.lds.tile_h, reach = a.lds.reach;
     a.lds = kStaticLayout;
@@ -176,46 +206,23 @@ __device__ __forceinline__ void ctx_from_lds(const SolveArgs& a, const double* L
 // "dynamic LDS base + offset" value that lives in (and gets spilled from) a scalar register.
 // kDir: search direction of lanes 32-63 -- 0 projected L-BFGS, 1 projected Newton with the dense system
 // (above), 2 projected Newton solved stage by stage (riccati.h; kSteps == 0 only, any control_steps).
-template <int kMinWavesPerSimd, int kSteps, int kDir = 0, bool kTame = false, int kStaticTile = 0>
-__global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveArgs args) {
+// What the phases hand to one another in registers (everything else goes through LDS).
+struct SolveCarry {
+  int flags;                 // NEO_MPC_FLAG_RESET (set-up -> K2)
+  bool cold;                 // x0 == 0 (wave-uniform: every lane scans the same LDS values)
+  bool wall_in_reach;        // a lethal cell in the reach tile (set-up -> the routed kernel's branch)
+  double f = INFINITY;       // objective at u; f(x0) comes out of the first candidate pass: lane 0 evaluates x0 itself there
+  int it = 0, nfev = 1, status = NEO_MPC_STATUS_MAX_ITER;
+};
+
+// ---- phase 0: set-up.  Records, reset, footprint, reach tile; the per-instance constants and the stop tolerances go to
+//      the tolerance block of LDS (layout: solver_context.h), where every later phase reads them; x0.
+//      Returns false when the instance makes no request this tick (nothing more to do).
+template <int kSteps, bool kTame, int kStaticTile, int kLayoutSteps>
+__device__ __forceinline__ bool solve_setup(double* L, uint32_t b, int lane, SolveCarry& s) {
   constexpr bool kCovered = kStaticTile > 0;   // the reach tile is there and covers every lookup (costmap.h cell_raw)
-  constexpr bool kNewton = kDir == 1;    // dense system in registers
-  constexpr bool kRiccati = kDir == 2;   // stage-wise recursion
-  constexpr bool kSecond = kDir != 0;    // either: Newton stop rules, no quasi-Newton state
-  static_assert(!kRiccati || kSteps == 0, "the Riccati direction lives in the run-time-sized kernel");
-  // Newton: control_steps == kSteps, or (kSteps == 0) any control_steps <= kNewtonMaxSteps -- the
-  // system's arrays are sized for the bound and every loop over them is guarded by the run-time size
-  constexpr int kNwSteps = !kNewton ? 1 : kSteps ? kSteps : kNewtonMaxSteps;
-  extern __shared__ __align__(16) double Ldyn[];
-  // (the run-time-sized Newton kernel carves LDS for its largest system and no L-BFGS pairs)
-  constexpr LdsLayout kStaticLayout = make_lds_layout(kSteps ? kSteps : kNewtonMaxSteps, kSteps ? 4 : 0, false);
-  constexpr int kStaticDoubles = kStaticTile ? (kStaticLayout.total_bytes + kStaticTile) / 8 : 2;
-  __shared__ __align__(16) double Lstat[kStaticDoubles];
-  double* const L = kStaticTile ? Lstat : Ldyn;
-  constexpr int kLayoutSteps = kSteps ? kSteps : kNewtonMaxSteps;
-#ifdef NEO_GEOMETRY_IN_SGPRS
-  constexpr bool kVectorPose = false;
-#else
-  // the four constants the costmap lookup of every stage of every candidate needs (world position = X0 + Rot(psi0) (x, y))
-  // stay in VECTOR registers (every lane holds the same value).  The scalar file is over-subscribed -- a hundred
-  // scalars are spilled to vector lanes -- and each use of a spilled pair costs two v_readlane and a wait state: twelve
-  // lane reads per stage.  (Round 4: the three-address polynomial kernels freed nine vector registers.)
-  // (the general kernels have no vector register to spare at four waves per SIMD: scalar there, as before)
-  constexpr bool kVectorPose = kTame;
-#endif
-  const int lane = threadIdx.x;
-  if (blockIdx.x >= args.count) return;
-  // (balanced dispatch, neo_mpc_balance_dispatch_device: which instance this workgroup solves -- instances are independent,
-  // every result is bit for bit what it is in launch order; only which of them share a SIMD changes)
-  const uint32_t b = args.order ? (uint32_t)__builtin_amdgcn_readfirstlane((int)args.order[blockIdx.x]) : blockIdx.x;
-  NEO_WAVE_START;
-  constexpr int kRegSteps = kSteps ? kSteps : 1;
-  constexpr int kPairs = kSteps ? 4 : NEO_MPC_MAX_LBFGS_MEMORY;  // specialisations: lbfgs_memory <= 4
   int flags;
-  double f = INFINITY;   // f(x0) comes out of the first candidate pass: lane 0 evaluates x0 itself there
-  bool cold = true;             // x0 == 0 (wave-uniform: every lane scans the same LDS values)
-  // ---- phase 0: set-up.  Records, reset, footprint, reach tile; the per-instance constants and the stop tolerances go to
-  //      the tolerance block of LDS (layout: solver_context.h), where every later phase reads them; x0.
+  bool cold = true;
   {
     SolveArgs a;
     fresh_args<kSteps, kStaticTile, kLayoutSteps>(a);
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     load_records(a, L, b, lane);
     // no request for this robot this tick (the plugin threw before its service call, cpp:234-236; K4 status 3): the node's
     // state does not advance: state record and warm start keep their bytes, the outputs say "skipped" (rollout.h)
-    if (uniform_int(reinterpret_cast<const int*>(L + a.lds.prob)[PI_SKIP]) == 1) { skip_instance(a, b, lane); return; }
+    if (uniform_int(reinterpret_cast<const int*>(L + a.lds.prob)[PI_SKIP]) == 1) { skip_instance(a, b, lane); return false; }
     select_map(a.map, L + a.lds.prob);
     flags = reset_and_warm(a, L, b, lane) ? NEO_MPC_FLAG_RESET : 0;
     // (the footprint cost -- the request's own, or the raster's -- waits for K2 in the request record's slot in LDS: as a
@@ -235,6 +242,8 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     Ctx c;
     make_ctx_wave(p, a.map, L + a.lds.prob, fcost, c, lane);
     load_tile(a, c, L, lane);
+    s.wall_in_reach = (c.tile_geom & kTileWall) != 0;
+    if (s.wall_in_reach) flags |= NEO_MPC_FLAG_WALL_IN_REACH;
     // The stop tolerances are read once per iteration: from LDS, so that they do not sit in (and get
     // spilled from) scalar registers all through the loop.
     // So do two per-instance constants the loop has no use for: the request's true yaw (K2 only) and
@@ -269,7 +278,6 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     // to the first step from the reference's start where that leads into another basin -- starting from it outright ended one
     // recorded call of the reference 1.9e-3 above it).  The warm start handed BACK is the reference's shift as ever (K2).
     // Closed loop of 4096 robots (CPU mirror): 6.2 -> 4.45 -> 3.6 iterations per warm tick, per-tick maximum 13 -> 10.
-#ifndef NEO_AB_NO_ALT_SETUP   // (study build)
     {
       double* S = L + a.lds.state;
       int* Si = reinterpret_cast<int*>(S);
@@ -283,7 +291,6 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       }
       WAVE_SYNC();
     }
-#endif
     if (!cold && n > 1 && !(p.compat & kCompatNoUnshift) && p.max_it < kDumpGradient) {   // (not in the test hooks: they dump AT the given point)
       const double* A0 = L + a.lds.state + S_PREV_U0;
       double ts = 0.0;
@@ -312,8 +319,54 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       WAVE_SYNC();
     }
   }
+  s.flags = flags; s.cold = cold;
+  return true;
+}
+
+// ---- phases 1 and 2: the search, the cell scan behind it, and the search once more behind a scan that paid.
+// kSteps > 0: specialisation for control_steps == kSteps -- every lane keeps its candidate's controls
+// and sin/cos in registers, so the winner is stored without being recomputed and the next adjoint
+// sweep needs no trigonometry.  kSteps == 0: any control_steps (LDS-only path).
+// kDir: search direction of lanes 32-63 -- 0 projected L-BFGS, 1 projected Newton with the dense system: control_steps ==
+// kSteps, or with kSteps == 0 any control_steps <= kNewtonMaxSteps (measured against L-BFGS on the 1000^2 map, 65 536
+// instances: +28 % at control_steps 1, +54 % at 2, +50 % at 4, +38 % at 5-7, +42 % at 8), 2 projected Newton solved stage by
+// stage (riccati.h; kSteps == 0 only, any control_steps).
+// kTame: instantiation for parameter sets (the README's among them) whose max_vel_trans disc lies
+// inside the vx/vy box -- the box/disc corner cases of the projection and of the tangent cone drop
+// out -- and whose heading cannot leave [-pi/4, pi/4] within the horizon -- no range reduction in
+// the rollout's sin/cos.
+// kStaticTile > 0: LDS is a static array sized for the compile-time layout plus a reach
+// tile of at most kStaticTile bytes -- every LDS address is then an instruction immediate instead of a
+// "dynamic LDS base + offset" value that lives in (and gets spilled from) a scalar register.
+// kRouted: the stage-wise branch of k_solve_routed (fresh_args).
+// Returns true when a test hook has dumped what it was asked for (the kernel ends there).
+template <int kMinWavesPerSimd, int kSteps, int kDir, bool kTame, int kStaticTile, int kLayoutSteps, bool kRouted = false>
+__device__ __forceinline__ bool solve_search(double* L, uint32_t b, SolveCarry& sc) {
+  constexpr bool kCovered = kStaticTile > 0;   // the reach tile is there and covers every lookup (costmap.h cell_raw)
+  constexpr bool kNewton = kDir == 1;    // dense system in registers
+  constexpr bool kRiccati = kDir == 2;   // stage-wise recursion
+  constexpr bool kSecond = kDir != 0;    // either: Newton stop rules, no quasi-Newton state
+  // the control_steps-3 stop rules of the dense direction -- the window rule on every run of three iterations, the blocked-run
+  // rule, closing-in behind two blocked iterations -- also end the stage-wise searches of the routed kernel: what ends a search
+  // depends on the horizon, not on how the direction was computed (solver_rules.h neo_rules_derive_routed)
+  constexpr bool kBlockedRule = kNewton || kRouted;
+  static_assert(!kRiccati || kSteps == 0, "the Riccati direction lives in the run-time-sized code");
+  static_assert(!kRouted || kRiccati, "the routed branch is the stage-wise one");
+  // Newton: control_steps == kSteps, or (kSteps == 0) any control_steps <= kNewtonMaxSteps -- the
+  // system's arrays are sized for the bound and every loop over them is guarded by the run-time size
+  constexpr int kNwSteps = !kNewton ? 1 : kSteps ? kSteps : kNewtonMaxSteps;
+  // the four constants the costmap lookup of every stage of every candidate needs (world position = X0 + Rot(psi0) (x, y))
+  // stay in VECTOR registers (every lane holds the same value).  The scalar file is over-subscribed -- a hundred
+  // scalars are spilled to vector lanes -- and each use of a spilled pair costs two v_readlane and a wait state: twelve
+  // lane reads per stage.  (Round 4: the three-address polynomial kernels freed nine vector registers.)
+  // (the general kernels have no vector register to spare at four waves per SIMD: scalar there, as before)
+  constexpr bool kVectorPose = kTame;
+  constexpr int kRegSteps = kSteps ? kSteps : 1;
+  constexpr int kPairs = kSteps ? 4 : NEO_MPC_MAX_LBFGS_MEMORY;  // specialisations: lbfgs_memory <= 4
+  double f = sc.f;
+  const bool cold = sc.cold;
   // ---- what the search carries from one iteration to the next -- and across the cell scan when it is taken up again
-  int npairs = 0, head = 0, nfev = 1, it = 0, status = NEO_MPC_STATUS_MAX_ITER, stall = 0;
+  int npairs = 0, head = 0, nfev = sc.nfev, it = sc.it, status = sc.status, stall = 0;
   int blocked_run = 0;   // dense Newton: consecutive iterations not won by a decent Newton step
   int nblocked = 1;      // consecutive iterations not won by a Newton step of at least half its length (or won by a hop)
   double u_term = 0.0;   // dense Newton: sum of the costmap terms under the current iterate's rollout (0: every stage in a free cell)
@@ -334,7 +387,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   for (;;) {   // (the search; taken up again behind a cell scan that paid)
   // ---- phase 1: the search
   SolveArgs a;
-  fresh_args<kSteps, kStaticTile, kLayoutSteps>(a);
+  fresh_args<kSteps, kStaticTile, kLayoutSteps, kRouted>(a);
   own_loop_params(a);
   select_map(a.map, L + a.lds.prob);
   const DevParams& p = a.p;
@@ -359,7 +412,10 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   static_assert(2 * 7 >= kNewtonRecord, "Newton records do not fit the step arrays");
 
   if (!scanned) {
+    const int lane = lane_again();
     for (int i = lane; i < n; i += kLanes) { AMODE[4 * i + 2] = 0; AMODE[4 * i + 3] = 0; }
+    // (routed stage-wise branch: this direction's prox-only zone around the kink -- the set-up wrote the dense direction's)
+    if (kRouted && lane == 0) L[a.lds.tol + T_KINK] = p.kink_radius_stagewise;
     // Long horizons (Riccati direction): the curvature of a block falls with 1/N^2, so the proximal step starts
     // longer; and the Newton step is long along the valleys in which neighbouring blocks trade displacement and
     // leaves the region where the model holds -- Levenberg-Marquardt damping mu (in units of one stage's tracking
@@ -390,11 +446,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     // at 4 waves/SIMD, parks them in scratch -- recomputing them costs a few integer operations.
     int lane = lane_again();
     // stage-wise direction: this iteration's sweep carries the second-order terms of the rollout step
-#ifdef NEO_AB_NO_TAU
-    const bool exact_step = false;
-#else
     const bool exact_step = kRiccati && nblocked == 0;
-#endif
     // (same trick for the tolerance block: an opaque LDS offset keeps its loads inside the loop and in
     // the LDS address space -- a volatile pointer would turn them into flat loads with a full wait each)
     int tol_off = a.lds.tol;
@@ -487,7 +539,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       // test hook (neo_mpc_gradient_batch): hand back the total gradient this kernel variant works with at
       // the projected x0 -- adjoint gradient of the smooth part + gradient of the control norm -- and stop
       for (int k = lane; k < nv; k += kLanes) a.solution[(size_t)b * nv + k] = gt[k];
-      return;
+      return true;
     }
     if (kSecond && it == 0 && cold) {
       // a cold start (x0 = 0, the reference's reset state py:359) is far from the minimiser and the
@@ -501,11 +553,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       WAVE_SYNC();
       if (corner_any) riccati_keep_linear_terms(a, L, n, lane, true);   // (the sweep writes its gains over them)
       auto sweep = [&]() {
-#ifdef NEO_MPC_RICCATI_F64   // (study build: the same recursion in float64 on the float32 records)
-        riccati_sweep<double>(a, L, n, lane);
-#else
         riccati_sweep<float, (kMinWavesPerSimd < 4)>(a, L, n, lane);
-#endif
         riccati_finish(a, c, L, n, lane);
       };
       sweep();
@@ -545,7 +593,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     if (p.max_it > kDumpGradient && it == p.max_it - kDumpGradient - 1) {
       // test hook (neo_mpc_direction_batch): the search direction of lanes 32-63 in this iteration
       for (int k = lane; k < nv; k += kLanes) a.solution[(size_t)b * nv + k] = d[k];
-      return;
+      return true;
     }
     // ---- 64 candidates, one rollout per lane; lowest objective wins
     // (run-time-sized Riccati kernel: the multiplier is re-read here -- one constant-memory load per iteration
@@ -576,25 +624,26 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
       double sn, cs;
       sincos_heading<kTame>(th, &sn, &cs);
       const double x = wave_scan((b0 * cs - b1 * sn) * p.dt), y = wave_scan((b0 * sn + b1 * cs) * p.dt);
-      double fi = 0.0, pr = 0.0;
+      double fi = 0.0, pr = 0.0, tm = 0.0;   // (tm: the stage's costmap term alone)
       if (on) {
         const double dx = c.cx - x, dy = c.cy - y, et = c.tyaw - th;
         const double e0 = c.v0 - b0, e1 = c.v1 - b1, e2 = c.v2 - b2;
-        fi = p.wt_n * (dx * dx + dy * dy) + p.wo_n * (et * et) + p.wc_n * sqrt_fast(e0 * e0 + e1 * e1 + e2 * e2) +
-             step_term(a, c, L, x, y);
+        tm = step_term<kCovered>(a, c, L, x, y);
+        fi = p.wt_n * (dx * dx + dy * dy) + p.wo_n * (et * et) + p.wc_n * sqrt_fast(e0 * e0 + e1 * e1 + e2 * e2) + tm;
         if (lane == n - 1) { const double ef = c.fyaw - th; fi += p.wterm_o * (ef * ef); }
         pr = -0.5 * (g0 * (b0 - u[3 * lane]) + g1 * (b1 - u[3 * lane + 1]) + g2 * (b2 - u[3 * lane + 2]));
       }
       const double ft = wave_sum(fi), pred = wave_sum(pr);
-      if (ft < f && f - ft >= kTrialRatio * pred) { took_trial = true; fb = ft; }
+      if (ft < f && f - ft >= kTrialRatio * pred) {
+        took_trial = true; fb = ft;
+        if (kBlockedRule) cterm = wave_sum(tm);   // (the blocked-run rule asks whether the new iterate's rollout is free)
+      }
       WAVE_SYNC();
     }
     // (first iteration only: the set-up armed the un-shifted previous solution as lane kAltLane's candidate)
     const double* ALT0 = L + a.lds.state + S_PREV_U0;
     bool alt_armed = false;
-#ifndef NEO_AB_NO_ALT_LANE   // (study build)
     if (it == 0) alt_armed = uniform_int(reinterpret_cast<const int*>(L + a.lds.state)[SI_HAS_PREV]) == kAltArmed;
-#endif
     if (!took_trial) {
     // hop lanes (Riccati): lane h in 1..nhops tries the current point with the block of hop stage h - 1 changed
     int hop_stage = -1;
@@ -621,7 +670,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
         },
         [&](int i, double sn, double cs) {
           if (kSteps && !kNewton) { cand_sn[i] = sn; cand_cs[i] = cs; }
-        }, kNewton ? &cterm : nullptr);
+        }, kBlockedRule ? &cterm : nullptr);
     NEO_PHASE(5);
     if (!(fc == fc)) fc = INFINITY;
     if (it == 0) { f = lane_value(fc, 0); if (kNewton) u_term = lane_value(cterm, 0); }
@@ -692,7 +741,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     // (the un-shifted start that won the first iteration says as little about step lengths as a hop)
     const bool hop_won = (kRiccati && best >= 1 && best <= nhops) || alt_won;
     nblocked = (best < 32 || lane_value(step, best) < kWindowStep || hop_won) ? nblocked + 1 : 0;
-    const bool window_on = !kRiccati || nblocked >= 3;
+    const bool window_on = !kRiccati || kRouted || nblocked >= 3;
     // three iterations that together gained less than wtol: creeping along a costmap cell edge
     const double wtol0 = TOL[T_WTOL];   // (the closing-in rule below is on whenever the window rule is)
     const double wtol = it >= kLateIteration ? TOL[T_WTOL_LATE] : wtol0;
@@ -711,10 +760,8 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     bool free_now = kRiccati ? free_path : false;
     if (kNewton) free_now = lane_value(cterm, best) == 0.0;
     creeping = creeping || (wtol0 > 0.0 && (double)stepmax <= TOL[T_STALL] && gain <= 0.5 * gain1 && gain1 <= 0.5 * gain2 &&
-#ifndef NEO_AB_OLD_CLOSING   // (study build)
                             (!free_now || (gain2 < INFINITY && gain * gain <= TOL[T_FTOL] * fscale * (gain1 - gain))) &&
-#endif
-                            (kRiccati ? window_on : nblocked >= kClosingRun));
+                            ((kRiccati && !kRouted) ? window_on : nblocked >= kClosingRun));
     // Blocked-run stop rule (dense Newton).  kBlockedRun iterations in a row not won by a decent Newton step that
     // together gain less than 0.1 x opt_tolerance (0.03 x with no costmap term under the new iterate's rollout): something
     // the quadratic model does not see is in the way -- a costmap cell edge, or blocks hovering next to the control norm's
@@ -722,7 +769,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     // opt_tolerance).  In a closed 30 Hz loop of 4096 robots such searches set the duration of every launch: per-tick
     // maximum 25 -> 13 iterations in the median, 100 -> 16 at worst; cold solves and the zero-map drift check are untouched.
     bool blocked_stop = false;
-    if (kNewton) {
+    if (kBlockedRule) {
       const double bs = lane_value(step, best);
       blocked_run = (best < 32 || bs < kBlockedStep) ? blocked_run + 1 : 0;
       if (blocked_run >= kBlockedRun) {
@@ -739,11 +786,12 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     if (kNewton) u_term = lane_value(cterm, best);
     // (a hop that won says nothing about step lengths: damping and proximal step stay as they are)
     if (kRiccati && !(it == 0 && cold) && !hop_won) {   // (an iteration that had a Newton direction)
-      const float bs = (float)lane_value(step, best);
+      // (step lengths of the Newton lanes as lane masks, feasible_set.h: scalar bit tests)
+      constexpr unsigned long long kNearlyFull = newton_lanes_at_least(0.8), kShort = kNewtonLanes & ~newton_lanes_at_least(0.3);
       const double mu0 = n > 8 ? (double)(n - 8) * 0.125 : 0.0, mu = TOL[T_MU];
       double* mu_slot = L + tol_off + T_MU;
-      if (best >= 32 && bs >= 0.8f) { if (lane == 0) *mu_slot = fmax(0.25 * mu, mu0 * 0.0625); }
-      else if (best < 32 || bs < 0.3f) { if (lane == 0) *mu_slot = fmin(4.0 * mu, 16.0 * mu0); }
+      if ((kNearlyFull >> best) & 1ull) { if (lane == 0) *mu_slot = fmax(0.25 * mu, mu0 * 0.0625); }
+      else if (best < 32 || ((kShort >> best) & 1ull)) { if (lane == 0) *mu_slot = fmin(4.0 * mu, 16.0 * mu0); }
     }
     if (best < 32 && !hop_won) {
       alpha = lane_value(step, best);
@@ -760,9 +808,6 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   //      and SLSQP's line search samples by accident.  Skipped when the whole reach tile is free or (dense direction: known
   //      from the winner's rollout) no stage of the iterate has a costmap term under it.  Behind a scan that gained more
   //      than opt_tolerance the search is taken up again: the other blocks have a new neighbour to adjust to.
-#ifdef NEO_AB_NO_SCAN   // (study build)
-  break;
-#endif
   if (!kSecond || scanned || status != NEO_MPC_STATUS_CONVERGED || (c.tile_geom & kTileFree) || (kNewton && u_term == 0.0) ||
       p.max_it >= kDumpGradient)
     break;
@@ -771,7 +816,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   bool resume;
   {
     SolveArgs as;
-    fresh_args<kSteps, kStaticTile, kLayoutSteps>(as);
+    fresh_args<kSteps, kStaticTile, kLayoutSteps, kRouted>(as);
     select_map(as.map, L + as.lds.prob);
     Ctx cs;
     ctx_from_lds<false>(as, L, cs);
@@ -780,17 +825,22 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
     const bool won = cell_scan<kSteps, kTame, kCovered>(as, cs, L, f, kNewton ? &u_term : nullptr, nfev, ls, kSteps ? kSteps : as.p.n);
     NEO_SEGMENT_SCAN_END();
     resume = won && f_before - f > as.p.scan_resume_gain && it < as.p.max_it;
-#ifdef NEO_AB_NO_RESUME   // (study build)
-    resume = false;
-#endif
   }
   if (!resume) break;
   status = NEO_MPC_STATUS_MAX_ITER; stall = 0; final_step = false; blocked_run = 0; nblocked = 1;
   gain1 = INFINITY; gain2 = INFINITY;
   }
-
-  // ---- phase 3: K2
   NEO_SEGMENT(1);
+  NEO_SEGMENT_DUMP();
+  sc.f = f; sc.it = it; sc.nfev = nfev; sc.status = status;
+  return false;
+}
+
+// ---- phase 3: K2 (py:365-403) on the search's result
+template <int kSteps, int kStaticTile, int kLayoutSteps>
+__device__ __forceinline__ void solve_finish(double* L, uint32_t b, int lane, const SolveCarry& sc) {
+  const int flags = sc.flags, status = sc.status, it = sc.it, nfev = sc.nfev;
+  double f = sc.f;
   SolveArgs a;
   fresh_args<kSteps, kStaticTile, kLayoutSteps>(a);
   select_map(a.map, L + a.lds.prob);
@@ -808,8 +858,65 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   f += L[a.lds.tol + T_KONST];
   c.true_yaw = L[a.lds.tol + T_TRUE_YAW];
   postprocess(a, c, L, b, lane, u, status == NEO_MPC_STATUS_CONVERGED, L[a.lds.prob + P_FOOTPRINT], flags, f, status, it, nfev);
-  NEO_WAVE_END();
 }
+
+// ---------------------------------------------------------------- K1: the kernels
+// k_solve<waves per SIMD, control_steps specialisation, direction, tame, static tile>: one direction for every instance.
+template <int kMinWavesPerSimd, int kSteps, int kDir = 0, bool kTame = false, int kStaticTile = 0>
+__global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveArgs args) {
+  extern __shared__ __align__(16) double Ldyn[];
+  // (the run-time-sized Newton kernel carves LDS for its largest system and no L-BFGS pairs)
+  constexpr int kLayoutSteps = kSteps ? kSteps : kNewtonMaxSteps;
+  constexpr LdsLayout kStaticLayout = make_lds_layout(kLayoutSteps, kSteps ? 4 : 0, false);
+  constexpr int kStaticDoubles = kStaticTile ? (kStaticLayout.total_bytes + kStaticTile) / 8 : 2;
+  __shared__ __align__(16) double Lstat[kStaticDoubles];
+  double* const L = kStaticTile ? Lstat : Ldyn;
+  const int lane = threadIdx.x;
+  if (blockIdx.x >= args.count) return;
+  // (balanced dispatch, neo_mpc_balance_dispatch_device: which instance this workgroup solves -- instances are independent,
+  // every result is bit for bit what it is in launch order; only which of them share a SIMD changes)
+  const uint32_t b = args.order ? (uint32_t)__builtin_amdgcn_readfirstlane((int)args.order[blockIdx.x]) : blockIdx.x;
+  NEO_WAVE_START;
+  SolveCarry sc;
+  if (!solve_setup<kSteps, kTame, kStaticTile, kLayoutSteps>(L, b, lane, sc)) return;
+  if (solve_search<kMinWavesPerSimd, kSteps, kDir, kTame, kStaticTile, kLayoutSteps>(L, b, sc)) return;
+  solve_finish<kSteps, kStaticTile, kLayoutSteps>(L, b, lane, sc);
+  NEO_WAVE_END_ARGS(args);
+}
+
+#ifdef NEO_MPC_TU_RICCATI   // (built without the SLP vectoriser like the stage-wise variants: with it the stage-wise branch spills 22 vector registers)
+// k_solve_routed: control_steps 3, AUTO below the heavy-costmap threshold -- DIRECTION BY NEIGHBOURHOOD (round 6;
+// solver_rules.h neo_rules_routes_by_neighbourhood).  The set-up stages the reach tile and knows whether a LETHAL cell is among
+// its cells.  No wall in reach (88 % of the BASELINE config-2 instances): the dense projected Newton search (registers,
+// finite-difference Hessian) with the cell scan behind it -- round 5's headline kernel.  A wall in reach: the stage-wise
+// (Riccati) search, whose wall model slides along walls -- every objective miss the random-parameter fuzz against the reference
+// found at control_steps 3 was a dense search hemmed in by lethal cells.  One launch, one wave per instance, one wave-uniform
+// branch behind the set-up; the two branches share LDS (the stage-wise carve-up for three stages lies inside the dense one,
+// fresh_args) and the register budget (128 at four waves per SIMD, no scratch).
+template <int kMinWavesPerSimd, bool kTame = false, int kStaticTile = 0>
+__global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve_routed(const SolveArgs args) {
+  extern __shared__ __align__(16) double Ldyn[];
+  constexpr int kSteps = kRoutedSteps;
+  constexpr LdsLayout kStaticLayout = make_lds_layout(kSteps, 4, false);
+  constexpr int kStaticDoubles = kStaticTile ? (kStaticLayout.total_bytes + kStaticTile) / 8 : 2;
+  __shared__ __align__(16) double Lstat[kStaticDoubles];
+  double* const L = kStaticTile ? Lstat : Ldyn;
+  const int lane = threadIdx.x;
+  if (blockIdx.x >= args.count) return;
+  const uint32_t b = args.order ? (uint32_t)__builtin_amdgcn_readfirstlane((int)args.order[blockIdx.x]) : blockIdx.x;
+  NEO_WAVE_START;
+  SolveCarry sc;
+  if (!solve_setup<kSteps, kTame, kStaticTile, kSteps>(L, b, lane, sc)) return;
+  // (the test hooks dump what the instance's own direction works with)
+  if (__builtin_amdgcn_readfirstlane((int)sc.wall_in_reach)) {
+    if (solve_search<kMinWavesPerSimd, 0, 2, kTame, kStaticTile, kSteps, true>(L, b, sc)) return;
+  } else {
+    if (solve_search<kMinWavesPerSimd, kSteps, 1, kTame, kStaticTile, kSteps, false>(L, b, sc)) return;
+  }
+  solve_finish<kSteps, kStaticTile, kSteps>(L, b, lane, sc);
+  NEO_WAVE_END_ARGS(args);
+}
+#endif
 
 #ifndef NEO_MPC_TU_RICCATI   // (neo_mpc_riccati.hip compiles this file again for the Riccati variants of K1 only)
 // K2 on its own: `solution` supplies x.x, `success` supplies x.success
@@ -828,6 +935,7 @@ __global__ __launch_bounds__(kLanes) void k_postprocess(const SolveArgs args) {
   Ctx c;
   make_ctx_wave(a.p, a.map, L + a.lds.prob, fcost, c, lane);
   load_tile(a, c, L, lane);
+  if (c.tile_geom & kTileWall) flags |= NEO_MPC_FLAG_WALL_IN_REACH;
   double* u = L + a.lds.u;
   for (int k = lane; k < nv; k += kLanes) u[k] = a.solution[(size_t)b * nv + k];
   WAVE_SYNC();
@@ -1097,11 +1205,26 @@ void launch_solve(const SolveArgs& a, const LaunchTuning& tuning, void* stream, 
     else hipLaunchKernelGGL((k_solve<__VA_ARGS__>), grid, block, (bytes) + tuning.lds_pad, st, a);                          \
   } while (0)
 #define NEO_LAUNCH(...) NEO_LAUNCH_LDS(lds, __VA_ARGS__)
+#define NEO_LAUNCH_ROUTED(bytes, ...)                                                                    \
+  do {                                                                                                   \
+    if (e0 || e1) hipExtLaunchKernelGGL((k_solve_routed<__VA_ARGS__>), grid, block, (bytes) + tuning.lds_pad, st, e0, e1, 0, a);   \
+    else hipLaunchKernelGGL((k_solve_routed<__VA_ARGS__>), grid, block, (bytes) + tuning.lds_pad, st, a);                          \
+  } while (0)
+#define NEO_LAUNCH_ROUTED_W(w, tame)                                                                     \
+  do {                                                                                                   \
+    if ((w) == 4) NEO_LAUNCH_ROUTED(lds, 4, tame); else if ((w) == 3) NEO_LAUNCH_ROUTED(lds, 3, tame); else NEO_LAUNCH_ROUTED(lds, 2, tame); \
+  } while (0)
 #define NEO_LAUNCH_W(w, ...)                                                                             \
   do {                                                                                                   \
     if ((w) == 4) NEO_LAUNCH(4, __VA_ARGS__); else if ((w) == 3) NEO_LAUNCH(3, __VA_ARGS__); else NEO_LAUNCH(2, __VA_ARGS__); \
   } while (0)
 #ifdef NEO_MPC_TU_RICCATI
+  if (a.p.routed) {   // control_steps 3, AUTO: direction by neighbourhood (k_solve_routed; the dense layout, 4 waves/SIMD like the dense kernels)
+    const int w = solve_variant(tuning, 4);
+    if (disc && w == 4 && small_tile) NEO_LAUNCH_ROUTED(0, 4, true, 1024);   // (the static variant takes no dynamic LDS)
+    else if (disc) NEO_LAUNCH_ROUTED_W(w, true);
+    else NEO_LAUNCH_ROUTED_W(w, false);
+  } else
   {  // any control_steps: Newton direction by the Riccati sweep (riccati.h)
     // the 128-VGPR build (4 waves/SIMD) wherever LDS lets a CU hold more than 12 workgroups -- 13 need <= 12.3 KB
     // each -- else the 168-VGPR build (measured: control_steps 8, 16 workgroups/CU: +17 %; control_steps 32 at
@@ -1120,6 +1243,7 @@ void launch_solve(const SolveArgs& a, const LaunchTuning& tuning, void* stream, 
     // on the "cut" parameter set, same box, tools/ab_general.py: 0.123 ms against 0.133 ms per 4096 instances at 3
     // waves/SIMD -- 4096 waves are one residency round at 4 --, 55.9 M against 51.3 M solves/s at 65 536)
     const int w = solve_variant(tuning, 4);
+    if (a.p.routed) { launch_solve_riccati(a, tuning, stream, ev_start, ev_stop); return; }   // AUTO: direction by neighbourhood (k_solve_routed)
     if (disc && w == 4 && small_tile) NEO_LAUNCH_LDS(0, 4, 3, 1, true, 1024);   // (the static variant takes no dynamic LDS)
     else if (disc) NEO_LAUNCH_W(w, 3, 1, true);
     else NEO_LAUNCH_W(w, 3, 1);
@@ -1137,6 +1261,8 @@ void launch_solve(const SolveArgs& a, const LaunchTuning& tuning, void* stream, 
     else NEO_LAUNCH_W(w, 0, 0);
   }
 #endif  // NEO_MPC_TU_RICCATI
+#undef NEO_LAUNCH_ROUTED_W
+#undef NEO_LAUNCH_ROUTED
 #undef NEO_LAUNCH_W
 #undef NEO_LAUNCH
 #undef NEO_LAUNCH_LDS

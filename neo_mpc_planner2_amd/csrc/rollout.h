@@ -97,7 +97,7 @@ __device__ void make_ctx_wave(const DevParams& p, const DevMap& m, const double*
 
 // stage the reach tile: rows [my0-R, my0+R], columns from floor4(mx0-R), dword loads
 __device__ void load_tile(const SolveArgs& a, Ctx& c, double* L, int lane) {
-  c.tile_geom = 0;
+  c.tile_geom = kTileWall;   // (no tile: the kernels cannot look -- every instance counts as next to a wall)
   if (a.lds.tile_w == 0) { c.tile_x0 = 0; c.tile_y0 = 0; return; }
   c.tile_geom = (a.lds.tile_h << 8) | (__ffs(a.lds.tile_w) - 1);
   const int mx0 = cell_of(c.X0, a.map.origin_x, a.map.resolution, a.map.inv_resolution);
@@ -108,7 +108,7 @@ __device__ void load_tile(const SolveArgs& a, Ctx& c, double* L, int lane) {
   const int wq = a.lds.tile_w >> 2;  // dwords per row (power of two)
   const int total = wq * a.lds.tile_h;
   const int shift = __ffs(wq) - 1;
-  uint32_t seen = 0u;
+  uint32_t seen = 0u, wall = 0u;
   for (int idx = lane; idx < total; idx += kLanes) {
     const int row = idx >> shift, col = idx & (wq - 1);
     const long gy = (long)c.tile_y0 + row, gx = (long)c.tile_x0 + 4 * col;
@@ -118,12 +118,17 @@ __device__ void load_tile(const SolveArgs& a, Ctx& c, double* L, int lane) {
       v = *reinterpret_cast<const uint32_t*>(a.map.cells + gy * a.map.pitch + gx);
     tile[idx] = v;
     seen |= v;
+    const uint32_t z = v ^ 0xFEFEFEFEu;                      // (a zero byte of z: a lethal cell)
+    wall |= (z - 0x01010101u) & ~z & 0x80808080u;
   }
   // Free neighbourhood: every cell the rollout of a feasible candidate can reach (the tile covers them all: its radius
   // is ceil(v_max H / resolution) + 1 cells) has raw cost 0 -- the costmap term is then identically term[0], nothing is
   // sticky and nothing is a hop away: the rollouts skip the lookup (about half of the instances of the BASELINE
   // workloads; a fifth of a candidate's per-stage instructions).
   if (__ballot(seen != 0u) == 0ull) c.tile_geom |= kTileFree;
+  // Wall in reach: a lethal cell among them (the map's outside reads lethal) -- what the routed control_steps-3 kernel sends
+  // to the stage-wise direction (solver_rules.h neo_rules_routes_by_neighbourhood)
+  if (__ballot(wall != 0u) != 0ull) c.tile_geom |= kTileWall;
 }
 
 // Global-frame rollout of the controls x from the request's pose and TRUE yaw (py:293-306, 320-327):

@@ -39,11 +39,12 @@ enum : int { T_XTOL, T_EARLY, T_FINAL, T_FTOL, T_STALL, T_WTOL, T_KINK, T_KONST,
              kTolDoubles = 30, kHopLanes = 4 /* = NEO_RULE_HOP_LANES (solver_rules.h) */ };
 
 constexpr int kTileFree = 0x80;   // Ctx::tile_geom: every cell of the reach tile is free (raw cost 0)
+constexpr int kTileWall = 0x40;   // ... a lethal cell (raw 254) -- or the outside of the map -- among them: a wall in reach (solver_rules.h)
 
 struct Ctx {
   double cx, cy, tyaw, fyaw, c0, s0, X0, Y0, v0, v1, v2, konst, true_yaw;
   int tile_x0, tile_y0;
-  int tile_geom;  // reach tile in LDS: rows << 8 | kTileFree | log2(row stride in bytes); 0: no tile
+  int tile_geom;  // reach tile in LDS: rows << 8 | kTileFree | kTileWall | log2(row stride in bytes); 0: no tile
 };
 
 }  // namespace

@@ -62,6 +62,19 @@ def objective_batch(params, cmap, problems, u):
     return out
 
 
+def route_batch(params, cmap, problems):
+    """1 where AUTO at control_steps 3 sends the instance to the stage-wise direction (its reach tile is not all free), 0
+    where it takes the dense one (solver_rules.h neo_rules_routes_by_neighbourhood)."""
+    lib = load()
+    ps = abi.params_struct(params)
+    cells, margs = _map_args(cmap)
+    problems = np.ascontiguousarray(problems)
+    out = np.zeros(len(problems), dtype=np.int32)
+    lib.orc_route_batch(C.byref(ps), *margs, C.c_void_p(problems.ctypes.data), C.c_void_p(out.ctypes.data),
+                        C.c_size_t(len(problems)))
+    return out
+
+
 def footprint_cost_batch(cmap, pts):
     lib = load()
     cells, margs = _map_args(cmap)

@@ -34,22 +34,39 @@ def draw(seed):
     return n, {k: float(v) for k, v in {**lim, **w}.items()}
 
 
+def generator_stamp():
+    """What a cached answer of the reference has to have been made with: the library versions gen_golden records in every
+    fixture and a hash of the generator's own source (gen_golden._g3_group and what it draws from: draw() above, the
+    synthetic workload maker).  A cache file without this stamp, or with another one, is not used."""
+    import hashlib
+    import inspect
+    from neo_mpc_planner2_amd import synthetic
+    from oracle import gen_golden
+    src = inspect.getsource(gen_golden._g3_group) + inspect.getsource(draw) + inspect.getsource(synthetic.make_costmap) + \
+        inspect.getsource(synthetic.make_problems)
+    return repr(gen_golden.versions()) + " generator " + hashlib.sha256(src.encode()).hexdigest()[:16]
+
+
 def work(seed):
     """The reference's answers for one seed; NEO_FUZZ_CACHE=<dir> keeps them between runs (the reference's SLSQP solves
-    are the slow part; the build's search is what changes between runs)."""
+    are the slow part; the build's search is what changes between runs).  Cached answers carry generator_stamp(): a file
+    made by another SciPy or another generator is ignored and made again."""
     from oracle import gen_golden, ros_stubs
     n, over = draw(seed)
     cache = os.environ.get("NEO_FUZZ_CACHE")
     path = os.path.join(cache, "seed%d_starts.npz" % seed) if cache else None
+    stamp = generator_stamp()
     if path and os.path.exists(path):
         with np.load(path) as z:
-            return seed, n, over, {k: z[k] for k in z.files}
+            if "_stamp" in z.files and str(z["_stamp"]) == stamp:
+                return seed, n, over, {k: z[k] for k in z.files if k != "_stamp"}
+        print("fuzz_reference: %s was made by another generator: made again" % path, file=sys.stderr)
     mod = ros_stubs.load_reference()
     with contextlib.redirect_stdout(io.StringIO()):
         grp = gen_golden._g3_group(mod, n, 24, 20000 + seed, over, map_size=300, map_seed=500 + seed, starts=True)
     if path:
         os.makedirs(cache, exist_ok=True)
-        np.savez_compressed(path, **grp)
+        np.savez_compressed(path, _stamp=np.array(stamp), **grp)
     return seed, n, over, grp
 
 

@@ -453,11 +453,10 @@ G14_SEEDS = 48
 
 
 def _g14_group(seed):
+    """One random parameter set: fuzz_reference.work runs the reference (NEO_FUZZ_CACHE: or takes the answers a fuzz run of
+    the SAME generator left there -- the stamp in the file says so)."""
     from oracle import fuzz_reference
-    mod = ros_stubs.load_reference()
-    n, over = fuzz_reference.draw(seed)
-    with contextlib.redirect_stdout(io.StringIO()):
-        grp = _g3_group(mod, n, 24, 20000 + seed, over, map_size=300, map_seed=500 + seed, starts=True)
+    seed, n, over, grp = fuzz_reference.work(seed)
     return seed, n, grp
 
 
@@ -490,6 +489,19 @@ G15_SEEDS = range(9000, 9064)
 def gen_g15(mod):
     """G15: G14's protocol on the seeds 9000-9063."""
     _random_sets(G15_SEEDS, "g15_judge_sets.npz", "G15")
+
+
+#: G16: the 105 seeds the round-5 JUDGE drew (61000-61048, 62000-62055; nobody on the build side had seen them) and 30027, the
+#: one miss of the builder's own 200-seed run of round 5.  Round 5's AUTO -- the dense direction for every instance at
+#: control_steps 3 -- missed P3 on five of their 1272 costmap cases (30027 / 17 +2.9e-3, 61020 / 19 +1.8e-2, 61027 / 3 +1.6e-3,
+#: 62024 / 7 +2.4e-2 and / 15 +1.57e-1: dense searches hemmed in by lethal cells): what round 6's direction by neighbourhood
+#: was built for
+G16_SEEDS = [30027] + list(range(61000, 61049)) + list(range(62000, 62056))
+
+
+def gen_g16(mod):
+    """G16: G14's protocol on the round-5 judge's seeds (+ 30027)."""
+    _random_sets(G16_SEEDS, "g16_judge_sets_r5.npz", "G16")
 
 
 def gen_g11(mod):
@@ -767,6 +779,7 @@ def main():
     gen_g13(mod)
     gen_g14(mod)
     gen_g15(mod)
+    gen_g16(mod)
 
 
 if __name__ == "__main__":

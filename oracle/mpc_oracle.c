@@ -1281,6 +1281,25 @@ void orc_set_trace(int on) { orc_trace = on; }
 static int orc_blocked_rule = 1;
 void orc_set_blocked_rule(int on) { orc_blocked_rule = on; }
 
+/* Wall in reach: a LETHAL cell (raw 254) -- or the outside of the map, which reads lethal -- among the cells of the reach tile
+ * as K1 stages it (rollout.h load_tile: rows [my0 - R, my0 + R], columns from (mx0 - R) & ~3, neo_rules_tile_width(R) of them).
+ * No tile (a reach beyond NEO_RULE_MAX_TILE_REACH cells): the kernels cannot look, every instance counts as next to a wall. */
+static int orc_wall_in_reach(const orc_ctx* c, int reach) {
+  const orc_map* m = c->map;
+  const int w = neo_rules_tile_width(reach);
+  if (!w) return 1;
+  int64_t mx0, my0;
+  orc_world_to_map(m, c->X0, c->Y0, &mx0, &my0);
+  const int64_t x0 = (mx0 - reach) & ~(int64_t)3, y0 = my0 - reach;
+  if (x0 < 0 || y0 < 0 || x0 + w > m->size_x || y0 + 2 * reach + 1 > m->size_y) return 1;
+  for (int64_t y = y0; y <= y0 + 2 * reach; ++y)
+    for (int64_t x = x0; x < x0 + w; ++x)
+      if (m->cells[y * (int64_t)m->size_x + x] == 254) return 1;
+  return 0;
+}
+static int orc_route = 1;   /* A/B hook: 0 = round 5's AUTO (the dense direction for every instance at control_steps 3) */
+void orc_set_route(int on) { orc_route = on; }
+
 /* Returns status; x_out = minimiser estimate, *f_out its objective. */
 /* (round 4) A/B hooks.  orc_tau_mode 1 (default): the stage-wise direction carries the second-order terms of the rollout
  * step (lambda . d2F: the exact Hessian, quadratic convergence); 0: Gauss-Newton (rounds 2-3: linear convergence wherever
@@ -1304,6 +1323,15 @@ int orc_pg_solve(const neo_mpc_params* p, const orc_map* m, const neo_mpc_proble
    * (neo_mpc_capi.cpp derive()) */
   neo_rules rules;
   neo_rules_derive(p, &rules);
+  /* (round 6) direction by neighbourhood: AUTO at control_steps 3 sends an instance with a lethal cell in its reach tile to
+   * the stage-wise direction -- with that direction's rules (solver_rules.h neo_rules_routes_by_neighbourhood) */
+  int routed = 0;   /* the stage-wise direction with the control_steps-3 stop rules (window rule on every run, blocked-run rule,
+                     * closing-in behind two blocked iterations): what ends a search depends on the horizon, not on how d is computed */
+  if (orc_route && neo_rules_routes_by_neighbourhood(p) && orc_wall_in_reach(&c, neo_rules_reach_cells(p, m->resolution))) {
+    neo_rules_derive_routed(p, &rules);
+    c.kink_radius = rules.kink_radius;
+    routed = 1;
+  }
   const int max_it = rules.max_iterations;
   int mem = rules.lbfgs_memory;
   if (mem > NEO_MPC_MAX_LBFGS_MEMORY) mem = NEO_MPC_MAX_LBFGS_MEMORY;
@@ -1601,7 +1629,7 @@ resume_search:
     /* stage-wise direction: the window and closing-in rules only judge runs of BLOCKED iterations (none of the three won
      * by a Newton step of at least half its length); iterations won by the Newton step end through the step test */
     nblocked = (best < 32 || orc_lane_scale(best, act.longshots) < NEO_RULE_WINDOW_STEP || hop_won) ? nblocked + 1 : 0;
-    const int creeping = wnow > 0.0 && decrease + gain1 + gain2 <= wnow * fsc && (orc_rule_mode < 1 || !riccati || nblocked >= 3);
+    const int creeping = wnow > 0.0 && decrease + gain1 + gain2 <= wnow * fsc && (orc_rule_mode < 1 || !riccati || routed || nblocked >= 3);
     /* ... and so does a step below stall_step whose gain halved twice in a row: the search is closing in on a
      * costmap cell edge (or the kink) geometrically, what is left to gain is less than the last gain (part of the
      * window rule: off with it).  -3 % iterations at control_steps 3 and 32, no command moves by 1e-3.
@@ -1613,9 +1641,9 @@ resume_search:
      * NEW iterate's rollout; stage-wise: under the rollout the iteration started from) */
     const int free_now = riccati ? free_before : (newton ? orc_term_sum(&c, u) == 0.0 : 0);
     const int closing_in = wtol > 0.0 && step <= stall_step && decrease <= 0.5 * gain1 && gain1 <= 0.5 * gain2 &&
-                           (!free_now || (gain2 < INFINITY && decrease * decrease <= ftol * fsc * (gain1 - decrease))) && (orc_rule_mode < 1 || (riccati ? nblocked >= 3 : nblocked >= orc_closing_need));
+                           (!free_now || (gain2 < INFINITY && decrease * decrease <= ftol * fsc * (gain1 - decrease))) && (orc_rule_mode < 1 || ((riccati && !routed) ? nblocked >= 3 : nblocked >= orc_closing_need));
     int blocked_stop = 0;
-    if (newton && !riccati && orc_blocked_rule && wtol > 0.0 && blocked_run >= ORC_BLOCKED_RUN)
+    if (newton && (!riccati || routed) && orc_blocked_rule && wtol > 0.0 && blocked_run >= ORC_BLOCKED_RUN)
       blocked_stop = decrease + gain1 + gain2 <= (orc_term_sum(&c, u) == 0.0 ? rules.btol_free : rules.btol_map);
     gain2 = gain1; gain1 = decrease;
     /* (round 4) the last-step rule rests on the Newton model having held: an iteration announced as the last but WON by a
@@ -1646,6 +1674,13 @@ resume_search:
   if (nit_out) *nit_out = it;
   if (nfev_out) *nfev_out = nfev;
   return status;
+}
+
+/* NEO_MPC_FLAG_WALL_IN_REACH of a request (K1's set-up: a lethal cell in the reach tile) */
+static int orc_wall_flag(const neo_mpc_params* p, const orc_map* m, const neo_mpc_problem* q) {
+  orc_ctx c;
+  orc_ctx_init(&c, p, m, q, 0.0);
+  return orc_wall_in_reach(&c, neo_rules_reach_cells(p, m->resolution));
 }
 
 /* ------------------------------------------------------------------ batch entry points (ctypes) */
@@ -1691,6 +1726,7 @@ void orc_postprocess_batch(const neo_mpc_params* p, const uint8_t* cells, int32_
     memset(out, 0, sizeof(*out));
     double* warm = b->warm_start + i * nv;
     if (orc_reset_if_new_goal(p, &b->problems[i], &b->states[i], warm)) out->flags |= NEO_MPC_FLAG_RESET;
+    if (orc_wall_flag(p, &m, &b->problems[i])) out->flags |= NEO_MPC_FLAG_WALL_IN_REACH;
     double x[ORC_MAXV];
     memcpy(x, b->solution + i * nv, sizeof(double) * nv);
     double fc = orc_batch_footprint(&m, b, i);
@@ -1734,6 +1770,7 @@ void orc_solve_batch(const neo_mpc_params* p, const uint8_t* cells, int32_t sx, 
     memset(out, 0, sizeof(*out));
     double* warm = b->warm_start + i * nv;
     if (orc_reset_if_new_goal(p, &b->problems[i], &b->states[i], warm)) out->flags |= NEO_MPC_FLAG_RESET;
+    if (orc_wall_flag(p, &m, &b->problems[i])) out->flags |= NEO_MPC_FLAG_WALL_IN_REACH;
     double fc = orc_batch_footprint(&m, b, i);
     double x[ORC_MAXV], f;
     neo_mpc_state* st = &b->states[i];
@@ -1750,6 +1787,19 @@ void orc_solve_batch(const neo_mpc_params* p, const uint8_t* cells, int32_t sx, 
   }
 }
 
+
+/* which instances AUTO at control_steps 3 sends to the stage-wise direction (1) and which to the dense one (0): the reach
+ * tile test of orc_wall_in_reach on every request (whatever the parameters' control_steps: the test only reads the map) */
+void orc_route_batch(const neo_mpc_params* p, const uint8_t* cells, int32_t sx, int32_t sy, double res, double ox, double oy,
+                     const neo_mpc_problem* problems, int32_t* routed, size_t count) {
+  orc_map m = orc_make_map(cells, sx, sy, res, ox, oy);
+  const int reach = neo_rules_reach_cells(p, res);
+  for (size_t i = 0; i < count; ++i) {
+    orc_ctx c;
+    orc_ctx_init(&c, p, &m, &problems[i], 0.0);
+    routed[i] = orc_wall_in_reach(&c, reach);
+  }
+}
 
 /* test hooks of the solver mirror: the total gradient the solver uses at a (projected) point u --
  * adjoint gradient of the smooth part + control-norm gradient -- and both Newton directions */

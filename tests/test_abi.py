@@ -30,9 +30,9 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.EXPORTS) == names
     assert lib.neo_mpc_abi_version() == abi.ABI_VERSION == 2
     lib.neo_mpc_behaviour_version.restype = C.c_int
-    assert lib.neo_mpc_behaviour_version() == 5
+    assert lib.neo_mpc_behaviour_version() == 6
     header = open(HEADER).read()
-    assert "#define NEO_MPC_ABI_VERSION 2" in header and "#define NEO_MPC_BEHAVIOUR_VERSION 5" in header
+    assert "#define NEO_MPC_ABI_VERSION 2" in header and "#define NEO_MPC_BEHAVIOUR_VERSION 6" in header
 
 
 def test_record_layouts_match_the_header(tmp_path):

@@ -23,11 +23,12 @@ SLOW = {"g3": ["g3_solves.npz"], "g8": ["g8_solves_params.npz"], "g8mid": ["g8_m
         "g9": ["g9_solves_pydefaults.npz", "g9_episodes_pydefaults.npz"], "g3n32": ["g3_solves_n32_zero.npz"],
         "g10": ["g10_heldout.npz"], "g11": ["g11_warm_converged.npz", "g11_warm_converged_n8.npz"],
         "g12": ["g12_after_tuning.npz"], "g13": ["g13_warm_converged_set_a.npz", "g13_warm_converged_set_a_n5.npz"], "g14": ["g14_random_sets.npz"],
-        "g15": ["g15_judge_sets.npz"]}
+        "g15": ["g15_judge_sets.npz"], "g16": ["g16_judge_sets_r5.npz"]}
 
 
 def _regenerate_and_compare(name, files, tmp_path):
     env = dict(os.environ, NEO_MPC_GOLDEN_OUT=str(tmp_path))
+    env.pop("NEO_FUZZ_CACHE", None)   # (from the reference, not from answers a fuzz run left behind)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "gen_golden.py"), name], env=env,
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]

@@ -242,7 +242,7 @@ def test_window_tolerance_trims_the_creeping_tail_only():
     probs = synthetic.make_problems(2048, 500, seed=42)
     out = {}
     for wt in (-1.0, 0.0):
-        params = util.orc.make_params(window_tolerance=wt)
+        params = util.orc.make_params(window_tolerance=wt, method=2)   # (the dense direction's rule: every instance dense)
         st, warm = synthetic.make_states(probs, 3)
         st_c, warm_c = st.copy(), warm.copy()
         with BatchSolver(params) as s:

@@ -355,7 +355,7 @@ def test_forced_directions_without_a_wall_model_are_refused_at_heavy_costmap_wei
     import ctypes as C
     from neo_mpc_planner2_amd import _lib
     lib = _lib.load()
-    assert lib.neo_mpc_abi_version() == abi.ABI_VERSION == 2 and lib.neo_mpc_behaviour_version() == 5
+    assert lib.neo_mpc_abi_version() == abi.ABI_VERSION == 2 and lib.neo_mpc_behaviour_version() == 6
     heavy = util.orc.make_params(w_costmap=0.3)          # 0.3 > 0.82 / 4
     for method in (1, 2):
         with pytest.raises(_lib.NeoMpcError) as e:
@@ -902,7 +902,9 @@ def test_plugin_seam_ticks_replayed_through_the_oracle(tmp_path):
             assert st[f][0] == t["state_after"][f], (k, f)
         assert abs(st["waiting_time"][0] - t["state_after"]["waiting_time"]) <= 1e-12, k
         assert np.abs(st["last_control"][0] - t["state_after"]["last_control"]).max() <= 2e-5, k
-        assert np.abs(warm[0] - t["warm_after"]).max() <= 2e-5, k
+        # (the raw solution behind the low-pass: next to the lethal block the robot has a wall in reach and round 6's AUTO
+        # solves it with the stage-wise direction, whose sweep is float32 on the device and float64 in the mirror)
+        assert np.abs(warm[0] - t["warm_after"]).max() <= 1e-4, k
         # the seam threads its state from tick to tick itself
         if k + 1 < len(ticks):
             assert ticks[k + 1]["state_before"].tobytes() == t["state_after"].tobytes()
@@ -916,8 +918,9 @@ def test_closed_loop_warm_ticks_have_no_creeping_tail(solver_mod):
     """The deployed mode: 4096 robots in a closed 30 Hz loop on the device (neo_mpc_planner2_amd/fleet.py), every tick
     warm-started the reference's way (py:397-400).  A launch lasts as long as its slowest wave: every search converges
     (status 0 -- no tick runs into the iteration cap), the per-tick maximum stays at 15 iterations in the median (it was
-    25, and 100 at worst, before the blocked-run rule), the mean below a cold tick's -- and the same loop on the CPU
-    mirror takes the same number of iterations."""
+    25, and 100 at worst, before the blocked-run rule; round 6: the robots with a wall in reach run the stage-wise direction,
+    whose searches along walls are the longer ones -- 13 in the median, 15 to 22 at worst on the mirror), the mean below a cold
+    tick's -- and the same loop on the CPU mirror takes the same number of iterations."""
     import torch
     from neo_mpc_planner2_amd import fleet
     cfg, cmap, probs, st, warm = synthetic.make_workload("C2", seed=0)
@@ -929,7 +932,7 @@ def test_closed_loop_warm_ticks_have_no_creeping_tail(solver_mod):
         torch.cuda.synchronize()
     summary = fleet.summary(loop)
     assert sum(status) == 0
-    assert summary["max_iterations_median"] <= 15 and summary["max_iterations_max"] <= 20, summary
+    assert summary["max_iterations_median"] <= 15 and summary["max_iterations_max"] <= 24, summary
     assert summary["mean_iterations"] <= summary["cold_tick_mean_iterations"], summary
     mirror = util.closed_loop_on_the_mirror(params, cmap, probs, 12)
     for t in range(12):
@@ -1170,6 +1173,37 @@ def test_random_parameter_sets_have_no_misses(solver_mod, fixture):
     m = util.random_sets_miss_rates(solve, fixture)
     print(fixture, m)
     util.assert_random_sets(m, fixture)
+
+
+def test_direction_by_neighbourhood(solver_mod):
+    """Round 6, AUTO at control_steps 3: one launch of k_solve_routed, every instance solved by the direction its neighbourhood
+    asks for (solver_rules.h).  NEO_MPC_FLAG_WALL_IN_REACH equals the mirror's reach-tile test on every instance (the README
+    kernel and the general one); instances with no wall in reach get the dense kernel's answer (method = NEWTON, the
+    stand-alone dense kernel, on the same batch); those with a wall in reach follow the mirror's stage-wise search."""
+    from oracle import c_oracle
+    general = dict(max_vel_x=0.5, min_vel_x=-0.2, max_vel_y=0.3, min_vel_y=-0.3)   # (the box cuts the disc: the general kernels)
+    for name, over in (("readme", {}), ("box cuts the disc", general)):
+        params = util.orc.make_params(**over)
+        cfg, cmap, probs, st0, warm0 = synthetic.make_workload("C2", seed=5, batch=2048)
+        routed = c_oracle.route_batch(params, cmap, probs).astype(bool)
+        assert 0.05 < routed.mean() < 0.2
+        with _solver(solver_mod, params, cmap) as s:
+            auto, xa = s.solve(probs, st0.copy(), warm0.copy())
+        with _solver(solver_mod, dict(params, method=2), cmap) as s:
+            dense, xd = s.solve(probs, st0.copy(), warm0.copy())
+        assert ((auto["flags"] & abi.FLAG_WALL_IN_REACH) != 0).tolist() == routed.tolist(), name
+        assert ((dense["flags"] & abi.FLAG_WALL_IN_REACH) != 0).tolist() == routed.tolist(), name
+        # (the same source compiled in two translation units -- the routed kernel without the SLP vectoriser: equal up to
+        # rounding, and an arg-min over 64 candidates turns a last-bit difference into another path now and then)
+        same = (np.abs(xa - xd).max(axis=1) <= 1e-9) & (auto["iterations"] == dense["iterations"])
+        assert same[~routed].mean() >= 0.99 and (np.abs(auto["cost"] - dense["cost"])[~routed] <= 1e-6).mean() >= 0.995, (name, same[~routed].mean())
+        cc, xc, _ = c_oracle.solve_batch(params, cmap, probs, st0.copy(), warm0.copy())
+        close = np.abs(auto["vel"] - cc["vel"]).max(axis=1) <= 1e-3
+        assert close[routed].mean() >= 0.95 and close[~routed].mean() >= 0.98, (name, close[routed].mean(), close[~routed].mean())
+        assert abs(auto["iterations"][routed].mean() - cc["iterations"][routed].mean()) <= 0.25, name
+        assert (auto["cost"][routed] <= cc["cost"][routed] + 1e-6).mean() >= 0.95, name
+        print("direction by neighbourhood (%s): %.1f %% with a wall in reach, iterations %.2f there (mirror %.2f), %.2f elsewhere"
+              % (name, 100 * routed.mean(), auto["iterations"][routed].mean(), cc["iterations"][routed].mean(), auto["iterations"][~routed].mean()))
 
 
 def test_non_finite_warm_starts_do_not_disturb_their_neighbours(solver_mod):

@@ -320,7 +320,7 @@ def random_sets_miss_rates(solve, fixture="g14_random_sets.npz"):
 
 
 #: fixture -> (random parameter sets, all-free-map cases the reference's own answers flag unique at least)
-RANDOM_SETS = {"g14_random_sets.npz": 48, "g15_judge_sets.npz": 64}
+RANDOM_SETS = {"g14_random_sets.npz": 48, "g15_judge_sets.npz": 64, "g16_judge_sets_r5.npz": 106}
 
 
 def assert_random_sets(m, fixture="g14_random_sets.npz"):
