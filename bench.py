@@ -755,8 +755,10 @@ def main():
             # the other BASELINE configs and the deployed (closed-loop, warm-started) mode, a few launches each, so
             # that the driver's line carries them; the inputs are generated here, outside every timed region
             others = []
+            # ("C2/dense direction only": method = NEWTON -- round 5's AUTO at control_steps 3, the A/B partner of the
+            # routed headline kernel: no wall model, 5 objective misses in 7332 random-parameter costmap cases against the reference)
             for name, over, label in [("C3", None, None), ("C5", None, None), ("C4", None, "C4 per-GPU shard")] + \
-                    [("C2", GENERAL_SETS[k], k) for k in sorted(GENERAL_SETS)]:
+                    [("C2", GENERAL_SETS[k], k) for k in sorted(GENERAL_SETS)] + [("C2", dict(method=2), "C2/dense direction only")]:
                 try:
                     # (4096-instance launches last 0.1-0.3 ms: a dozen of them, so that the wall-clock rate is the stream's)
                     others.append(other_workload(name, dev, local_rank, steps=12 if over else 8, params_over=over, label=label))

@@ -21,9 +21,12 @@ namespace {
 
 // exact_step: the stage records carry the position costates (second-order terms of the rollout step, riccati.h).
 // free_path: every stage of the rollout at u sits in a free cell; nhops: hop candidates in the tolerance block's table.
-template <bool kTame, bool kRiccati>
+// kFew > 0: control_steps == kFew at compile time (at most 16): the prefix sums stop after the DPP steps that reach the stages
+template <bool kTame, bool kRiccati, int kFew = 0>
 __device__ __forceinline__ void adjoint_by_scans(const SolveArgs& a, const Ctx& c, double* L, bool exact_step, int lane, int n,
                                                  bool& free_path, int& nhops) {
+  auto scan = [](double v) { if constexpr (kFew > 0) return wave_scan_few<kFew>(v); else return wave_scan(v); };
+  constexpr int kLast = kFew > 0 ? kFew - 1 : 63;   // (the lane that holds a prefix sum's total)
   const DevParams& p = a.p;
   const double* u = L + a.lds.u;
   double* gs = L + a.lds.gs;
@@ -33,20 +36,20 @@ __device__ __forceinline__ void adjoint_by_scans(const SolveArgs& a, const Ctx& 
   // prefix sums, the adjoint three suffix sums -- one sincos per lane instead of N in a row
   const bool on = lane < n;
   const double vx = on ? u[3 * lane] : 0.0, vy = on ? u[3 * lane + 1] : 0.0, w = on ? u[3 * lane + 2] : 0.0;
-  const double th = wave_scan(w * p.dt);
+  const double th = scan(w * p.dt);
   double sn, cs;
   sincos_heading<kTame>(th, &sn, &cs);
   const double ddx = (vx * cs - vy * sn) * p.dt, ddy = (vx * sn + vy * cs) * p.dt;
-  const double x = wave_scan(ddx), y = wave_scan(ddy);
+  const double x = scan(ddx), y = scan(ddy);
   double rt = on ? -2.0 * p.wo_n * (c.tyaw - th) : 0.0;
   if (lane == n - 1) rt += -2.0 * p.wterm_o * (c.fyaw - th);
   const double rx = on ? -2.0 * p.wt_n * (c.cx - x) : 0.0, ry = on ? -2.0 * p.wt_n * (c.cy - y) : 0.0;
   // suffix sums: S_k = sum_{i >= k} r_i = total - prefix_k + r_k
-  const double px = wave_scan(rx), py = wave_scan(ry);
-  const double SX = lane_value(px, 63) - px + rx, SY = lane_value(py, 63) - py + ry;
+  const double px = scan(rx), py = scan(ry);
+  const double SX = lane_value(px, kLast) - px + rx, SY = lane_value(py, kLast) - py + ry;
   const double tt = on ? rt - ddy * SX + ddx * SY : 0.0;
-  const double pt = wave_scan(tt);
-  const double ST = lane_value(pt, 63) - pt + tt;
+  const double pt = scan(tt);
+  const double ST = lane_value(pt, kLast) - pt + tt;
   int raw_here = 0;
   bool has_hop = false;
   float hop_x = 0.0f, hop_y = 0.0f;

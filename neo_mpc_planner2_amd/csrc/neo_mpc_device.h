@@ -95,7 +95,7 @@ constexpr LdsLayout make_lds_layout(int n, int mem, bool riccati, bool corners =
   int off = 0;
   l.prob = off; off += 32;
   l.state = off; off += 16;
-  l.tol = off; off += 30;   // (= kTolDoubles, solver_context.h) stop tolerances + two cold per-instance constants (read once per iteration; kept out of the scalar
+  l.tol = off; off += 32;   // (= kTolDoubles, solver_context.h) stop tolerances + two cold per-instance constants (read once per iteration; kept out of the scalar
                             // registers), then the hop candidates of the current iteration (solver_context.h)
   l.term = off; off += 256;
   l.u = off; off += nv;

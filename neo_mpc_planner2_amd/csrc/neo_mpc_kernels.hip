@@ -350,8 +350,11 @@ __device__ __forceinline__ bool solve_search(double* L, uint32_t b, SolveCarry& 
   // rule, closing-in behind two blocked iterations -- also end the stage-wise searches of the routed kernel: what ends a search
   // depends on the horizon, not on how the direction was computed (solver_rules.h neo_rules_derive_routed)
   constexpr bool kBlockedRule = kNewton || kRouted;
-  static_assert(!kRiccati || kSteps == 0, "the Riccati direction lives in the run-time-sized code");
-  static_assert(!kRouted || kRiccati, "the routed branch is the stage-wise one");
+  static_assert(!kRiccati || kSteps == 0 || kRouted, "the stage-wise direction: run-time-sized, or the routed kernel's control_steps-3 branch");
+  static_assert(!kRouted || (kRiccati && kSteps == kRoutedSteps), "the routed branch is the stage-wise one, three stages in registers");
+  // (kSteps > 0 with the stage-wise direction -- the routed branch: candidates in registers, unrolled rollouts, the winner
+  // stored without being recomputed like the dense specialisation; gradient and sweep run lane = stage on three lanes)
+  constexpr int kFew = (kRiccati && kSteps > 0) ? kSteps : 0;
   // Newton: control_steps == kSteps, or (kSteps == 0) any control_steps <= kNewtonMaxSteps -- the
   // system's arrays are sized for the bound and every loop over them is guarded by the run-time size
   constexpr int kNwSteps = !kNewton ? 1 : kSteps ? kSteps : kNewtonMaxSteps;
@@ -422,6 +425,9 @@ __device__ __forceinline__ bool solve_search(double* L, uint32_t b, SolveCarry& 
     // weights, riccati_prepare), relaxed x1/4 after an iteration won by the (nearly) full Newton step, tightened
     // x4 after one won by a proximal step or a short Newton step.  Nothing of it at control_steps <= 8.
     alpha = kRiccati ? fmax(1.0, n * 0.125) : 1.0;
+    // (routed stage-wise branch: what the search carries between iterations waits in the tolerance block of LDS -- kept in
+    // registers across the 64-candidate pass, whose candidates sit in registers themselves, it came out spilled to scratch)
+    if (kFew && lane == 0) { double* t = L + a.lds.tol; t[T_GAIN1] = INFINITY; t[T_GAIN2] = INFINITY; t[T_ALPHA] = alpha; }
     // (mu lives in the tolerance block of LDS: two scalar registers fewer across the loop)
     if (kRiccati && lane == 0) L[a.lds.tol + T_MU] = n > 8 ? (double)(n - 8) * 0.125 : 0.0;
   }
@@ -429,6 +435,7 @@ __device__ __forceinline__ bool solve_search(double* L, uint32_t b, SolveCarry& 
   bool v_feasible = false;
   if (kRiccati) {
     double b0 = c.v0, b1 = c.v1, b2 = c.v2;
+    asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2));   // (copies of their own: vector copies of v_cur must not outlive this test)
     project_block<kTame>(p, b0, b1, b2);
     v_feasible = b0 == c.v0 && b1 == c.v1 && b2 == c.v2;
   }
@@ -524,7 +531,7 @@ __device__ __forceinline__ bool solve_search(double* L, uint32_t b, SolveCarry& 
       }
       WAVE_SYNC();
     }
-    else if (!kSteps) adjoint_by_scans<kTame, kRiccati>(a, c, L, exact_step, lane, n, free_path, nhops);
+    else if (!kSteps || kRiccati) adjoint_by_scans<kTame, kRiccati, kFew>(a, c, L, exact_step, lane, n, free_path, nhops);
     else adjoint_short_sweep<kSteps, kTame>(a, c, L, have_trig, lane, n);
     NEO_PHASE(1);
     // ---- total gradient (control norm: minimal-norm subgradient at the kink), tangent-cone reduction at active bounds,
@@ -553,7 +560,7 @@ __device__ __forceinline__ bool solve_search(double* L, uint32_t b, SolveCarry& 
       WAVE_SYNC();
       if (corner_any) riccati_keep_linear_terms(a, L, n, lane, true);   // (the sweep writes its gains over them)
       auto sweep = [&]() {
-        riccati_sweep<float, (kMinWavesPerSimd < 4)>(a, L, n, lane);
+        riccati_sweep<float, (kMinWavesPerSimd < 4), kFew>(a, L, n, lane);
         riccati_finish(a, c, L, n, lane);
       };
       sweep();
@@ -599,7 +606,8 @@ __device__ __forceinline__ bool solve_search(double* L, uint32_t b, SolveCarry& 
     // (run-time-sized Riccati kernel: the multiplier is re-read here -- one constant-memory load per iteration
     // against 2 x control_steps stages of work, and two registers fewer across the sweep)
     const double lscale = kRiccati ? lane_scale<kSecond>(lane) : my_scale;
-    const double pstep = alpha * lscale;
+    const double alpha_now = kFew ? TOL[T_ALPHA] : alpha;
+    const double pstep = alpha_now * lscale;
     const double step = lane < 32 ? pstep : lscale;
     // Riccati, rollout in free space (no costmap term at any stage: the objective is smooth up to the control
     // norm's kink): the full Newton step -- lane 32's candidate -- is tried on its own first, one objective
@@ -616,14 +624,16 @@ __device__ __forceinline__ bool solve_search(double* L, uint32_t b, SolveCarry& 
       const bool on = lane < n;
       double b0 = 0.0, b1 = 0.0, b2 = 0.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;
       if (on) {
-        candidate_block<kTame, kRiccati>(a, c, L, 32, 1.0, alpha, lane, b0, b1, b2);   // (lane 32: step length 1)
+        candidate_block<kTame, kRiccati>(a, c, L, 32, 1.0, alpha_now, lane, b0, b1, b2);   // (lane 32: step length 1)
         g0 = gr[3 * lane]; g1 = gr[3 * lane + 1]; g2 = gr[3 * lane + 2];   // (u_new takes the reduced gradient's place)
         u_new[3 * lane] = b0; u_new[3 * lane + 1] = b1; u_new[3 * lane + 2] = b2;
       }
-      const double th = wave_scan(b2 * p.dt);
+      auto scan = [](double v) { if constexpr (kFew > 0) return wave_scan_few<kFew>(v); else return wave_scan(v); };
+      auto sum = [](double v) { if constexpr (kFew > 0) return wave_sum_few<kFew>(v); else return wave_sum(v); };
+      const double th = scan(b2 * p.dt);
       double sn, cs;
       sincos_heading<kTame>(th, &sn, &cs);
-      const double x = wave_scan((b0 * cs - b1 * sn) * p.dt), y = wave_scan((b0 * sn + b1 * cs) * p.dt);
+      const double x = scan((b0 * cs - b1 * sn) * p.dt), y = scan((b0 * sn + b1 * cs) * p.dt);
       double fi = 0.0, pr = 0.0, tm = 0.0;   // (tm: the stage's costmap term alone)
       if (on) {
         const double dx = c.cx - x, dy = c.cy - y, et = c.tyaw - th;
@@ -633,10 +643,10 @@ __device__ __forceinline__ bool solve_search(double* L, uint32_t b, SolveCarry& 
         if (lane == n - 1) { const double ef = c.fyaw - th; fi += p.wterm_o * (ef * ef); }
         pr = -0.5 * (g0 * (b0 - u[3 * lane]) + g1 * (b1 - u[3 * lane + 1]) + g2 * (b2 - u[3 * lane + 2]));
       }
-      const double ft = wave_sum(fi), pred = wave_sum(pr);
+      const double ft = sum(fi), pred = sum(pr);
       if (ft < f && f - ft >= kTrialRatio * pred) {
         took_trial = true; fb = ft;
-        if (kBlockedRule) cterm = wave_sum(tm);   // (the blocked-run rule asks whether the new iterate's rollout is free)
+        if (kBlockedRule) cterm = sum(tm);   // (the blocked-run rule asks whether the new iterate's rollout is free)
       }
       WAVE_SYNC();
     }
@@ -669,7 +679,7 @@ __device__ __forceinline__ bool solve_search(double* L, uint32_t b, SolveCarry& 
           if (kSteps) { cand[3 * i] = b0; cand[3 * i + 1] = b1; cand[3 * i + 2] = b2; }
         },
         [&](int i, double sn, double cs) {
-          if (kSteps && !kNewton) { cand_sn[i] = sn; cand_cs[i] = cs; }
+          if (kSteps && !kSecond) { cand_sn[i] = sn; cand_cs[i] = cs; }
         }, kBlockedRule ? &cterm : nullptr);
     NEO_PHASE(5);
     if (!(fc == fc)) fc = INFINITY;
@@ -682,9 +692,9 @@ __device__ __forceinline__ bool solve_search(double* L, uint32_t b, SolveCarry& 
     if (!(fb < f)) { status = NEO_MPC_STATUS_CONVERGED; ++it; break; }
     const bool alt_won = alt_armed && best == kAltLane;
     float stepmax = 0.0f;
-    if (kSteps && kNewton) {
+    if (kSteps && kSecond && !took_trial) {
       // the winner holds its candidate in registers: it measures the step against u and overwrites u
-      // in place -- one LDS round trip, no staging copy, no wave-wide maximum (the Newton path keeps
+      // in place -- one LDS round trip, no staging copy, no wave-wide maximum (the Newton paths keep
       // no previous iterate or gradient)
       if (lane == best) {
 #pragma unroll
@@ -696,15 +706,15 @@ __device__ __forceinline__ bool solve_search(double* L, uint32_t b, SolveCarry& 
       stepmax = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, stepmax), best));
       have_trig = true;
     } else {
-      if (kSteps) {
+      if (kSteps && !kSecond) {
         if (lane == best) {
 #pragma unroll
           for (int i = 0; i < kRegSteps; ++i) {
             u_new[3 * i] = cand[3 * i]; u_new[3 * i + 1] = cand[3 * i + 1]; u_new[3 * i + 2] = cand[3 * i + 2];
-            if (!kNewton) { ASN[i] = cand_sn[i]; ACS[i] = cand_cs[i]; }
+            ASN[i] = cand_sn[i]; ACS[i] = cand_cs[i];
           }
         }
-      } else if (!took_trial) {
+      } else if (!kSteps && !took_trial) {
         // rebuild the winning candidate cooperatively: lane i takes control block i
         const double bstep = lane_value(step, best), bpstep = lane_value(pstep, best);
         int bhop = -1;
@@ -745,7 +755,8 @@ __device__ __forceinline__ bool solve_search(double* L, uint32_t b, SolveCarry& 
     // three iterations that together gained less than wtol: creeping along a costmap cell edge
     const double wtol0 = TOL[T_WTOL];   // (the closing-in rule below is on whenever the window rule is)
     const double wtol = it >= kLateIteration ? TOL[T_WTOL_LATE] : wtol0;
-    bool creeping = wtol > 0.0 && gain + gain1 + gain2 <= wtol * fscale && window_on;
+    const double g1 = kFew ? TOL[T_GAIN1] : gain1, g2 = kFew ? TOL[T_GAIN2] : gain2;   // (the previous two iterations' gains)
+    bool creeping = wtol > 0.0 && gain + g1 + g2 <= wtol * fscale && window_on;
     // ... and so does a step below stall_step whose gain halved twice in a row: the search is closing in on a
     // costmap cell edge (or the kink) geometrically; what is left to gain is less than the last gain (in free space three
     // gains it takes: round 5 -- the INFINITY the two older ones start at used to pass for a gain, and a warm search that began next to the
@@ -759,8 +770,8 @@ __device__ __forceinline__ bool solve_search(double* L, uint32_t b, SolveCarry& 
     // NEW iterate's rollout; stage-wise: under the rollout the iteration started from)
     bool free_now = kRiccati ? free_path : false;
     if (kNewton) free_now = lane_value(cterm, best) == 0.0;
-    creeping = creeping || (wtol0 > 0.0 && (double)stepmax <= TOL[T_STALL] && gain <= 0.5 * gain1 && gain1 <= 0.5 * gain2 &&
-                            (!free_now || (gain2 < INFINITY && gain * gain <= TOL[T_FTOL] * fscale * (gain1 - gain))) &&
+    creeping = creeping || (wtol0 > 0.0 && (double)stepmax <= TOL[T_STALL] && gain <= 0.5 * g1 && g1 <= 0.5 * g2 &&
+                            (!free_now || (g2 < INFINITY && gain * gain <= TOL[T_FTOL] * fscale * (g1 - gain))) &&
                             ((kRiccati && !kRouted) ? window_on : nblocked >= kClosingRun));
     // Blocked-run stop rule (dense Newton).  kBlockedRun iterations in a row not won by a decent Newton step that
     // together gain less than 0.1 x opt_tolerance (0.03 x with no costmap term under the new iterate's rollout): something
@@ -775,10 +786,12 @@ __device__ __forceinline__ bool solve_search(double* L, uint32_t b, SolveCarry& 
       if (blocked_run >= kBlockedRun) {
         const bool free_rollout = lane_value(cterm, best) == 0.0;
         const double btol = free_rollout ? TOL[T_BTOL_FREE] : TOL[T_BTOL_MAP];
-        blocked_stop = gain + gain1 + gain2 <= btol;   // (btol 0: the rule is off -- a gain is never <= 0 here)
+        blocked_stop = gain + g1 + g2 <= btol;   // (btol 0: the rule is off -- a gain is never <= 0 here)
       }
     }
-    gain2 = gain1; gain1 = gain;
+    double* TOLW = L + tol_off;
+    if (kFew) { if (lane == 0) { TOLW[T_GAIN2] = g1; TOLW[T_GAIN1] = gain; } }
+    else { gain2 = gain1; gain1 = gain; }
     f = fb;
     // the last-step rule rests on the Newton model having held: an iteration announced as the last but WON by a proximal
     // step or a short Newton step (a bound about to become active, the kink) is not the last
@@ -794,8 +807,9 @@ __device__ __forceinline__ bool solve_search(double* L, uint32_t b, SolveCarry& 
       else if (best < 32 || ((kShort >> best) & 1ull)) { if (lane == 0) *mu_slot = fmin(4.0 * mu, 16.0 * mu0); }
     }
     if (best < 32 && !hop_won) {
-      alpha = lane_value(step, best);
-      alpha = clampd(alpha, 1e-6, 1e6);
+      const double al = clampd(lane_value(step, best), 1e-6, 1e6);
+      if (kFew) { if (lane == 0) TOLW[T_ALPHA] = al; }
+      else alpha = al;
     }
     WAVE_SYNC();
     NEO_PHASE(6);
@@ -825,6 +839,10 @@ __device__ __forceinline__ bool solve_search(double* L, uint32_t b, SolveCarry& 
     const bool won = cell_scan<kSteps, kTame, kCovered>(as, cs, L, f, kNewton ? &u_term : nullptr, nfev, ls, kSteps ? kSteps : as.p.n);
     NEO_SEGMENT_SCAN_END();
     resume = won && f_before - f > as.p.scan_resume_gain && it < as.p.max_it;
+    if (kFew && resume) {
+      if (ls == 0) { L[as.lds.tol + T_GAIN1] = INFINITY; L[as.lds.tol + T_GAIN2] = INFINITY; }
+      WAVE_SYNC();
+    }
   }
   if (!resume) break;
   status = NEO_MPC_STATUS_MAX_ITER; stall = 0; final_step = false; blocked_run = 0; nblocked = 1;
@@ -909,7 +927,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve_routed(const
   if (!solve_setup<kSteps, kTame, kStaticTile, kSteps>(L, b, lane, sc)) return;
   // (the test hooks dump what the instance's own direction works with)
   if (__builtin_amdgcn_readfirstlane((int)sc.wall_in_reach)) {
-    if (solve_search<kMinWavesPerSimd, 0, 2, kTame, kStaticTile, kSteps, true>(L, b, sc)) return;
+    if (solve_search<kMinWavesPerSimd, kSteps, 2, kTame, kStaticTile, kSteps, true>(L, b, sc)) return;
   } else {
     if (solve_search<kMinWavesPerSimd, kSteps, 1, kTame, kStaticTile, kSteps, false>(L, b, sc)) return;
   }

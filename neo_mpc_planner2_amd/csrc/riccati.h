@@ -152,7 +152,8 @@ __device__ __forceinline__ void riccati_keep_linear_terms(const SolveArgs& a, do
 // in d (float64 slots), and per block tokink (AMODE slot 3): the stage model's minimiser is the kink itself.
 // kPrefetch: fetch the next stage's record one stage ahead (28 more live registers: the 4-waves/SIMD build
 // reads each record when it needs it instead)
-template <typename T, bool kPrefetch = true>
+// kFew > 0: control_steps == kFew at compile time (the loops unroll and the first stage takes its shortcut)
+template <typename T, bool kPrefetch = true, int kFew = 0>
 __device__ __forceinline__ void riccati_sweep(const SolveArgs& a, double* L, int n, int lane) {
   const DevParams& p = a.p;
   float* RS = static_cast<float*>(__builtin_assume_aligned(reinterpret_cast<float*>(L + a.lds.ric), 16));
@@ -169,7 +170,11 @@ __device__ __forceinline__ void riccati_sweep(const SolveArgs& a, double* L, int
     const ric_f4* R4 = reinterpret_cast<const ric_f4*>(RS + kRicStage * (n - 1));
     r0 = R4[0]; r1 = R4[1]; r2 = R4[2]; r3 = R4[3]; r4 = R4[4]; r5 = R4[5]; r6 = R4[6];
   }
-  for (int i = n - 1; i >= 0; --i) {
+  // (the first stage, i == 0, has nothing behind it: its feedback gains K would multiply dz_{-1} = 0 and the value function
+  // V, v it would hand on is never read -- in the unrolled sweeps every case below stops after the stage's own step k; K
+  // stays zero.  The run-time-sized sweep does the work: one stage of eight or more, against a test in every stage.)
+  for (int i = (kFew ? kFew : n) - 1; i >= 0; --i) {
+    const bool first = kFew > 0 && i == 0;
     if (!kPrefetch) {
       const ric_f4* R4 = reinterpret_cast<const ric_f4*>(RS + kRicStage * i);
       r0 = R4[0]; r1 = R4[1]; r2 = R4[2]; r3 = R4[3]; r4 = R4[4]; r5 = R4[5]; r6 = R4[6];
@@ -235,6 +240,7 @@ __device__ __forceinline__ void riccati_sweep(const SolveArgs& a, double* L, int
           x0_ = y0 * i0 - l10 * x1_ - l20 * x2_;                                                 \
         }
         NEO_RIC_SOLVE3(q0, q1, q2, k0, k1, k2)
+        if (first) break;   // (the first stage: no gains, no value function behind it -- see the top of the loop)
         NEO_RIC_SOLVE3(S00, S01, M02, K00, K10, K20)
         NEO_RIC_SOLVE3(S01, S11, M12, K01, K11, K21)
         NEO_RIC_SOLVE3(Z02, Z12, Z22, K02, K12, K22)
@@ -274,6 +280,11 @@ __device__ __forceinline__ void riccati_sweep(const SolveArgs& a, double* L, int
           xa_ = y0 * i0 - l * xb_;                                 \
         }
         NEO_RIC_SOLVE2(ga, gb, ka, kb)
+        if (first) {   // (the first stage: the step alone)
+          k0 = ax * ka; k1 = ay * ka;
+          if (bw) k2 = kb; else k1 = kb;
+          break;
+        }
         NEO_RIC_SOLVE2(Za0, Zb0, Ka0, Kb0)
         NEO_RIC_SOLVE2(Za1, Zb1, Ka1, Kb1)
         NEO_RIC_SOLVE2(Za2, Zb2, Ka2, Kb2)
@@ -292,6 +303,7 @@ __device__ __forceinline__ void riccati_sweep(const SolveArgs& a, double* L, int
         const T i0 = -ric_rcp(ric_pivot(haa, ric_max((T)1e-6 * ric_abs(haa), (T)1e-30)));
         const T Za0 = rtx * S00 + rty * S01, Za1 = rtx * S01 + rty * S11, Za2 = rtx * Z02 + rty * Z12;
         const T ka = (rtx * q0 + rty * q1) * i0, Ka0 = Za0 * i0, Ka1 = Za1 * i0, Ka2 = Za2 * i0;
+        if (first) { k0 = rtx * ka; k1 = rty * ka; break; }
         v0 = z0 + Za0 * ka; v1 = z1 + Za1 * ka; v2 = z2 + Za2 * ka;
         V00 = S00 + Za0 * Ka0; V01 = S01 + Za0 * Ka1; V02 = M02 + Za0 * Ka2;
         V11 = S11 + Za1 * Ka1; V12 = M12 + Za1 * Ka2; V22 = Z22 + Za2 * Ka2;
@@ -301,7 +313,9 @@ __device__ __forceinline__ void riccati_sweep(const SolveArgs& a, double* L, int
       case RC_W: {         // omega only (velocity pinned)
         const T hbb = Z22 + c22;
         const T i0 = -ric_rcp(ric_pivot(hbb, ric_max((T)1e-6 * ric_abs(hbb), (T)1e-30)));
-        k2 = q2 * i0; K20 = M02 * i0; K21 = M12 * i0; K22 = Z22 * i0;
+        k2 = q2 * i0;
+        if (first) break;
+        K20 = M02 * i0; K21 = M12 * i0; K22 = Z22 * i0;
         v0 = z0 + M02 * k2; v1 = z1 + M12 * k2; v2 = z2 + Z22 * k2;
         V00 = S00 + M02 * K20; V01 = S01 + M02 * K21; V02 = M02 + M02 * K22;
         V11 = S11 + M12 * K21; V12 = M12 + M12 * K22; V22 = Z22 + Z22 * K22;
@@ -309,6 +323,7 @@ __device__ __forceinline__ void riccati_sweep(const SolveArgs& a, double* L, int
       }
       case RC_KINK:        // fixed step onto the kink, no feedback
         k0 = e0; k1 = e1; k2 = e2;
+        if (first) break;
         v0 = z0 + S00 * k0 + S01 * k1 + M02 * k2;
         v1 = z1 + S01 * k0 + S11 * k1 + M12 * k2;
         v2 = z2 + Z02 * k0 + Z12 * k1 + Z22 * k2;

@@ -35,8 +35,11 @@ enum : int { T_XTOL, T_EARLY, T_FINAL, T_FTOL, T_STALL, T_WTOL, T_KINK, T_KONST,
              T_BTOL_MAP = 20, T_BTOL_FREE = 21,
              // what the out-of-line cell scan (cell_scan.h) reads instead of taking arguments: the rest of Ctx ...
              T_C0 = 22, T_S0 = 23, T_TYAW = 24, T_FYAW = 25, T_TILE = 26 /* int32[3]: tile_x0, tile_y0, tile_geom */,
-             T_F = 28 /* ... in: the objective at u; out: the winner's */, T_TERM = 29 /* out: the winner's costmap terms */,
-             kTolDoubles = 30, kHopLanes = 4 /* = NEO_RULE_HOP_LANES (solver_rules.h) */ };
+             // the routed kernel's stage-wise branch parks what its search carries from one iteration to the next here (gains of
+             // the previous two iterations, proximal step length): as registers they were live across the 64-candidate pass,
+             // where the candidates themselves sit in registers, and came out spilled to scratch
+             T_GAIN1 = 28, T_GAIN2 = 29, T_ALPHA = 30,
+             kTolDoubles = 32, kHopLanes = 4 /* = NEO_RULE_HOP_LANES (solver_rules.h) */ };
 
 constexpr int kTileFree = 0x80;   // Ctx::tile_geom: every cell of the reach tile is free (raw cost 0)
 constexpr int kTileWall = 0x40;   // ... a lethal cell (raw 254) -- or the outside of the map -- among them: a wall in reach (solver_rules.h)

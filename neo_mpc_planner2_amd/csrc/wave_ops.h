@@ -48,6 +48,21 @@ __device__ __forceinline__ double wave_scan(double v) {
   v += dpp_move<0x143, 0xc, false>(v, 0.0);
   return v;
 }
+// ... over the first kFew lanes only (kFew a compile-time bound; the other lanes hold zeros): the ladder stops where the
+// lanes it would still reach hold nothing -- two DPP steps for three stages instead of six.  Lanes < kFew get, bit for bit,
+// what wave_scan gives them (the steps left out add zero-filled values there).
+template <int kFew>
+__device__ __forceinline__ double wave_scan_few(double v) {
+  static_assert(kFew >= 1 && kFew <= 16, "one DPP row");
+  if (kFew > 1) v += dpp_move<0x111, 0xf, true>(v, 0.0);
+  if (kFew > 2) v += dpp_move<0x112, 0xf, true>(v, 0.0);
+  if (kFew > 4) v += dpp_move<0x114, 0xf, true>(v, 0.0);
+  if (kFew > 8) v += dpp_move<0x118, 0xf, true>(v, 0.0);
+  return v;
+}
+// sum over the first kFew lanes (the other lanes hold zeros), every lane returns it
+template <int kFew>
+__device__ __forceinline__ double wave_sum_few(double v) { return lane_value(wave_scan_few<kFew>(v), kFew - 1); }
 __device__ __forceinline__ double wave_max(double v) {
   v = fmax(v, dpp_move<0x111, 0xf, false>(v, v));
   v = fmax(v, dpp_move<0x112, 0xf, false>(v, v));

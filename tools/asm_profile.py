@@ -10,7 +10,7 @@ riccati = "ELi0ELi2E" in key
 src = os.path.join(root, "neo_mpc_planner2_amd/csrc", "neo_mpc_riccati.hip" if riccati else "neo_mpc_kernels.hip")
 out = "/tmp/asm_profile.s"
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-pass-failed"] +
-               (["-fno-slp-vectorize"] if riccati else []) +
+               (["-fno-slp-vectorize", "-mllvm", "-disable-machine-licm"] if riccati else []) +
                ["-gline-tables-only", "-x", "hip", "--cuda-device-only", "-S", src, "-o", out],
                check=True, stderr=subprocess.DEVNULL)
 lo, hi = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (0, 10**9)

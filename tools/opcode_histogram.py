@@ -18,7 +18,7 @@ csrc = os.path.join(root, "neo_mpc_planner2_amd/csrc")
 src = os.path.join(csrc, "neo_mpc_riccati.hip" if riccati else "neo_mpc_kernels.hip")
 out = "/tmp/opcode_histogram.s"
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-pass-failed"] +
-               (["-fno-slp-vectorize"] if riccati else []) +
+               (["-fno-slp-vectorize", "-mllvm", "-disable-machine-licm"] if riccati else []) +
                ["-gline-tables-only", "-x", "hip", "--cuda-device-only", "-S", src, "-o", out],
                check=True, stderr=subprocess.DEVNULL)
 ksrc = open(os.path.join(csrc, "neo_mpc_kernels.hip")).read().split("\n")

@@ -2,7 +2,7 @@
 # per-variant register / spill / scratch summary of K1 (both translation units)   usage: bash tools/resource_usage.sh [filter]
 cd "$(dirname "$0")/../neo_mpc_planner2_amd/csrc"
 for tu in neo_mpc_kernels.hip neo_mpc_riccati.hip; do
-  extra=""; [ $tu = neo_mpc_riccati.hip ] && extra="-fno-slp-vectorize"
+  extra=""; [ $tu = neo_mpc_riccati.hip ] && extra="-fno-slp-vectorize -mllvm -disable-machine-licm"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-pass-failed $extra \
     -Rpass-analysis=kernel-resource-usage -x hip -c $tu -o /dev/null 2>&1 | python3 -c "
 import re,sys
