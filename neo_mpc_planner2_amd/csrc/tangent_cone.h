@@ -68,10 +68,14 @@ __device__ __forceinline__ bool tangent_cone_pass(const SolveArgs& a, const Ctx&
     double nx0 = 0.0, ny0 = 0.0, nx1 = 0.0, ny1 = 0.0, nx2 = 0.0, ny2 = 0.0;
     bool v0 = false, v1 = false, v2 = false;
     if (!kTame && !p.disc_in_box) {  // (inside the box a bound can only touch where the disc touches too)
-      if (u0 <= p.lo[0]) { nx0 = -1.0; v0 = true; }
-      else if (u0 >= p.hi[0]) { nx0 = 1.0; v0 = true; }
-      if (u1 <= p.lo[1]) { ny1 = -1.0; v1 = true; }
-      else if (u1 >= p.hi[1]) { ny1 = 1.0; v1 = true; }
+      // (active within NEO_RULE_CORNER_ROOM: the projection's radial rescale leaves a block that sat on a bound a rounding
+      // error inside it -- seen as free, a block in the corner between the disc and a bound slid along the disc INTO the
+      // bound, was pinned by the corner re-pin and never tried the slide along the bound: round-5 review, seed 62022)
+      constexpr double kRoom = NEO_RULE_CORNER_ROOM;
+      if (u0 <= p.lo[0] + kRoom) { nx0 = -1.0; v0 = true; }
+      else if (u0 >= p.hi[0] - kRoom) { nx0 = 1.0; v0 = true; }
+      if (u1 <= p.lo[1] + kRoom) { ny1 = -1.0; v1 = true; }
+      else if (u1 >= p.hi[1] - kRoom) { ny1 = 1.0; v1 = true; }
     }
     const double nvv2 = u0 * u0 + u1 * u1, rlim = p.r * (1.0 - 1e-12);
     if (nvv2 > 0.0 && nvv2 >= rlim * rlim) { const double iv = rsq_fast(nvv2); nx2 = u0 * iv; ny2 = u1 * iv; v2 = true; }

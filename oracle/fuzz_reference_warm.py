@@ -7,7 +7,11 @@ commands, carrot re-drawn every 10 calls, new goal mid-episode, every tick solve
 the CPU mirror of the build's search, at the set's own shipped tolerance, solves every call from the reference's own state
 (tests/util.warm_gate).  Reported per set and in total: settled ticks, how many of them have the build's command more than
 1e-3 from the reference's converged command, the largest difference.
-Test infrastructure: nothing here is shipped.   usage: fuzz_reference_warm.py <first seed> <last seed + 1> [episodes] [calls]"""
+COSTMAP MODE (round 6; `--costmap` in front of the seeds): P3w's protocol at random parameter sets -- the reference AS SHIPPED
+(the set's own opt_tolerance) on the 200 x 200 costmap of G4, 4 episodes x 30 calls per set (gen_golden.warm_costmap_group:
+what G17 holds for its first 16 seeds), every call solved by the mirror from the reference's own state: f(build) <=
+f(reference's raw x.x) + 1e-3 (tests/util.p3w_group).
+Test infrastructure: nothing here is shipped.   usage: fuzz_reference_warm.py [--costmap] <first seed> <last seed + 1> [episodes] [calls]"""
 import contextlib
 import io
 import multiprocessing as mp
@@ -61,7 +65,49 @@ def work(args):
         int((bad & (df > 1e-3)).sum()), int((bad & (df < -1e-3)).sum()), float(df[bad].max()) if bad.any() else 0.0
 
 
+def work_costmap(args):
+    seed, n_ep, n_calls = args
+    from oracle import gen_golden, c_oracle
+    import util
+    seed, n, grp = gen_golden.warm_costmap_group(seed, n_ep, n_calls)
+    params = util.params_from(np.array(gen_golden.PARAM_KEYS), grp["params"])
+    cmap = (grp["cells"],) + tuple(grp["map_meta"])
+    c_oracle.set_threads(1)
+
+    def solve(p, cm, rows, st, wm):
+        c, x, _ = c_oracle.solve_batch(p, cm, rows, st, wm)
+        return c, x
+
+    def post(p, cm, rows, st, wm, x, ok):
+        c_oracle.postprocess_batch(p, cm, rows, st, wm, x, ok)
+    worse, its, capped = util.p3w_group(solve, post, params, cmap, grp)
+    return seed, n, params["opt_tolerance"], float(worse.max()), int((worse > 1e-3).sum()), int(worse.size), float(np.median(worse)), \
+        float(its.mean()), int(its.max()), capped
+
+
+def main_costmap(argv):
+    seeds = list(range(int(argv[0]), int(argv[1])))
+    n_ep = int(argv[2]) if len(argv) > 2 else 4
+    n_calls = int(argv[3]) if len(argv) > 3 else 30
+    with mp.Pool(max(1, (os.cpu_count() or 2) - 1)) as pool:
+        rows = pool.map(work_costmap, [(s, n_ep, n_calls) for s in seeds], chunksize=1)
+    miss = calls = caps = 0
+    for seed, n, tol, mx, above, cnt, med, it, itmax, capped in rows:
+        miss += above
+        calls += cnt
+        caps += capped
+        print("seed %d control_steps %2d opt_tolerance %.0e: %3d calls, f(build) - f(reference's x.x): max %+.2e, median %+.2e, "
+              "more than 1e-3 above on %d; iterations %.2f (max %d)%s"
+              % (seed, n, tol, cnt, mx, med, above, it, itmax, "; %d searches ran into the iteration cap" % capped if capped else ""))
+    print("%d parameter sets on the costmap, the reference as shipped, every call from the reference's own state: the build's "
+          "objective more than 1e-3 above the reference's on %d of %d calls (largest f - f_ref %+.2e); %d searches ran into the "
+          "iteration cap" % (len(rows), miss, calls, max(r[3] for r in rows), caps))
+
+
 if __name__ == "__main__":
+    if sys.argv[1] == "--costmap":
+        main_costmap(sys.argv[2:])
+        sys.exit(0)
     seeds = list(range(int(sys.argv[1]), int(sys.argv[2])))
     n_ep = int(sys.argv[3]) if len(sys.argv) > 3 else 4
     n_calls = int(sys.argv[4]) if len(sys.argv) > 4 else 30

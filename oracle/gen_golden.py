@@ -21,6 +21,7 @@ optimizer() episodes of the reference run to convergence (opt_tolerance 1e-12) o
     python oracle/gen_golden.py g8 g4b     # regenerates single sets
 """
 import contextlib
+import shutil
 import io
 import math
 import os
@@ -504,6 +505,54 @@ def gen_g16(mod):
     _random_sets(G16_SEEDS, "g16_judge_sets_r5.npz", "G16")
 
 
+#: G17 (round 6): the deployed mode on costmaps away from the four recorded episode files -- P3w's protocol at RANDOM parameter
+#: sets: fuzz_reference.draw(seed), 4 optimizer() episodes x 30 calls of the reference AS SHIPPED (the set's own opt_tolerance)
+#: on the 200 x 200 costmap of G4 (episode 2 starts in front of a lethal disc, episode 1 carries a footprint), robots moved by
+#: the reference's own commands.  The first 16 seeds of oracle/fuzz_reference_warm.py's costmap mode.
+G17_SEEDS = range(80000, 80016)
+
+
+def warm_costmap_group(seed, n_ep=4, n_calls=30):
+    """The reference's episodes for one random parameter set (a scratch directory takes gen_g4's file)."""
+    import tempfile
+    from oracle import fuzz_reference
+    global OUT
+    n, over = fuzz_reference.draw(seed)
+    mod = ros_stubs.load_reference()
+    keep, tmp = OUT, tempfile.mkdtemp(prefix="neo_warm_costmap_")
+    OUT = tmp
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            gen_g4(mod, n_steps=n, n_ep=n_ep, n_calls=n_calls, fname="w.npz", overrides=over, seed_base=60000 + 10 * seed)
+        with np.load(os.path.join(tmp, "w.npz")) as z:
+            grp = {k: z[k] for k in z.files}
+    finally:
+        OUT = keep
+        shutil.rmtree(tmp, ignore_errors=True)
+    return seed, n, grp
+
+
+def gen_g17(mod):
+    """G17: warm_costmap_group on G17_SEEDS, one file (keys s<seed>_*; the costmap, the same for every set, once)."""
+    import multiprocessing as mp
+    t0 = time.time()
+    out = dict(versions=np.array(repr(versions())), param_keys=np.array(PARAM_KEYS), seeds=np.array(list(G17_SEEDS)))
+    steps = []
+    with mp.Pool(max(1, (os.cpu_count() or 2) - 1)) as pool:
+        for seed, n, grp in sorted(pool.imap_unordered(warm_costmap_group, G17_SEEDS), key=lambda r: r[0]):
+            steps.append(n)
+            cells, meta = grp.pop("cells"), grp.pop("map_meta")
+            for k in ("versions", "param_keys"):
+                grp.pop(k)
+            if "cells" in out:
+                assert np.array_equal(out["cells"], cells) and np.array_equal(out["map_meta"], meta)
+            out["cells"], out["map_meta"] = cells, meta
+            out.update({"s%d_%s" % (seed, k): v for k, v in grp.items()})
+    out["steps"] = np.array(steps)
+    np.savez_compressed(os.path.join(OUT, "g17_warm_costmap_sets.npz"), **out)
+    print("G17: %d random parameter sets x 4 episodes x 30 calls on the costmap in %.0fs" % (len(steps), time.time() - t0), flush=True)
+
+
 def gen_g11(mod):
     """G11: optimizer() episodes of the reference RUN TO CONVERGENCE -- `opt_tolerance` 1e-12 (py:72, 364) and SLSQP's
     iteration cap raised to 500 inside the call of py:363-364 -- on an all-free map (unique minimisers): the converged
@@ -780,6 +829,7 @@ def main():
     gen_g14(mod)
     gen_g15(mod)
     gen_g16(mod)
+    gen_g17(mod)
 
 
 if __name__ == "__main__":

@@ -405,10 +405,14 @@ static void orc_tangent(const orc_ctx* c, const double* ui, const double* gi, do
    * is the disc's, with its curvature and without the corner stop of a bound slide) */
   double nv = sqrt(ui[0] * ui[0] + ui[1] * ui[1]);
   if (nv > 0.0 && nv >= c->r * (1.0 - 1e-12)) { nx[na] = ui[0] / nv; ny[na] = ui[1] / nv; isdisc[na] = 1; ++na; }
-  if (ui[0] <= c->lo[0]) { nx[na] = -1.0; ny[na] = 0.0; ++na; }
-  else if (ui[0] >= c->hi[0]) { nx[na] = 1.0; ny[na] = 0.0; ++na; }
-  if (ui[1] <= c->lo[1]) { nx[na] = 0.0; ny[na] = -1.0; ++na; }
-  else if (ui[1] >= c->hi[1]) { nx[na] = 0.0; ny[na] = 1.0; ++na; }
+  /* (a bound is active within NEO_RULE_CORNER_ROOM of it: the projection's radial rescale leaves a block that sat on a bound
+   * a rounding error inside it -- seen as free, a block in the corner between the disc and a bound slid along the disc INTO the
+   * bound, was pinned by the corner re-pin, and never tried the slide along the bound that led on: round-5 review, seed 62022) */
+  const double room = NEO_RULE_CORNER_ROOM;
+  if (ui[0] <= c->lo[0] + room) { nx[na] = -1.0; ny[na] = 0.0; ++na; }
+  else if (ui[0] >= c->hi[0] - room) { nx[na] = 1.0; ny[na] = 0.0; ++na; }
+  if (ui[1] <= c->lo[1] + room) { nx[na] = 0.0; ny[na] = -1.0; ++na; }
+  else if (ui[1] >= c->hi[1] - room) { nx[na] = 0.0; ny[na] = 1.0; ++na; }
   const double dx = -gi[0], dy = -gi[1]; /* steepest descent */
   *mode = 0; *nxo = 0.0; *nyo = 0.0; *disc = 0; *lambda = 0.0;
   int violated = 0;

@@ -519,6 +519,18 @@ def test_g16_has_teeth_the_dense_direction_alone_misses_the_wall_cases():
         assert cm["cost"][0] <= grp["f_loose"][case] + 1e-3 and (cm["flags"][0] & abi.FLAG_WALL_IN_REACH)
 
 
+def test_g16_stagewise_direction_pinned_at_control_steps_3():
+    """The round-5 review ran its 105 sets with method = RICCATI forced: no objective miss, and ONE first-control miss on an
+    all-free map (seed 62022 / case 0, 1.3e-3): a block in the corner between the speed disc and the vy bound, left a
+    rounding error inside the bound by the projection, was not seen as ON the bound, slid along the disc into it, got pinned
+    by the corner re-pin and never tried the slide along the bound (bounds are active within NEO_RULE_CORNER_ROOM since).
+    The control_steps-3 sets of G16, stage-wise direction for every instance: exact gates."""
+    m = util.random_sets_miss_rates(_cold_solve, "g16_judge_sets_r5.npz", only_steps=3, over=dict(method=3))
+    print("G16, control_steps 3, method RICCATI (mirror):", {k: v for k, v in m.items() if k != "misses"})
+    assert m["cases_free"] >= 300 and m["p3_miss_free"] == 0 and m["p3_miss_map"] == 0 and m["p2_miss"] == 0, m["misses"]
+    assert m["p2_worst"] <= 2e-4
+
+
 def test_direction_by_neighbourhood_on_the_benchmark_workload():
     """AUTO at control_steps 3 (solver_rules.h neo_rules_routes_by_neighbourhood): an instance with no lethal cell in its
     reach tile gets the dense direction's answer bit for bit (method = NEWTON on the same instance), one with a wall in reach
@@ -590,3 +602,19 @@ def test_p3_on_the_reference_warm_starts_mirror(fixture):
         c_oracle.postprocess_batch(params, cmap, rows, states, warm, g["raw_x"][:, k], g["success"][:, k])
     worse = np.array(worse)
     assert worse.max() <= 1e-3, worse.max()
+
+
+def test_g17_p3_on_warm_starts_at_random_parameter_sets_mirror():
+    """G17 (round 6): P3w away from the four recorded episode files -- 16 random parameter sets x 4 episodes x 30 calls of the
+    reference as shipped on the costmap, every call solved from the reference's own state: f(build) <= f(reference's raw
+    x.x) + 1e-3 on EVERY call (the GPU test of the same name runs K1)."""
+    def solve(params, cmap, rows, st, wm):
+        cm, x, _ = c_oracle.solve_batch(params, cmap, rows, st, wm)
+        return cm, x
+
+    def post(params, cmap, rows, st, wm, x, ok):
+        c_oracle.postprocess_batch(params, cmap, rows, st, wm, x, ok)
+    rows = util.p3w_random_sets(solve, post)
+    for r in rows:
+        print("G17 seed %d control_steps %2d: max f - f_ref %.2e, %d of %d calls above 1e-3, iterations %.2f" % r)
+    assert len(rows) == 16 and sum(r[3] for r in rows) == 0 and sum(r[4] for r in rows) == 16 * 4 * 30, rows

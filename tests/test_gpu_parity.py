@@ -1179,6 +1179,34 @@ def test_random_parameter_sets_have_no_misses(solver_mod, fixture):
     util.assert_random_sets(m, fixture)
 
 
+def test_g17_p3_on_warm_starts_at_random_parameter_sets(solver_mod):
+    """G17 (round 6) through the C-ABI on the GPU: P3w at 16 RANDOM parameter sets -- 4 episodes x 30 calls of the reference as
+    shipped on the costmap, every call solved by K1 from the reference's own state (the state advanced by the standalone K2
+    with the reference's raw x.x injected): f(build) <= f(reference's raw x.x) + 1e-3 on every one of the 1920 calls."""
+    from oracle import c_oracle
+    solvers = {}
+
+    def get(params, cmap):
+        key = tuple(sorted(params.items()))
+        if key not in solvers:
+            solvers[key] = _solver(solver_mod, params, cmap)
+        return solvers[key]
+
+    def solve(params, cmap, rows, st, wm):
+        return get(params, cmap).solve(rows, st, wm)
+
+    def post(params, cmap, rows, st, wm, x, ok):
+        c_oracle.postprocess_batch(params, cmap, rows, st, wm, x, ok)   # (the reference's next state: P5 pins K2 on it elsewhere)
+    try:
+        rows = util.p3w_random_sets(solve, post)
+    finally:
+        for s in solvers.values():
+            s.close()
+    for r in rows:
+        print("G17 seed %d control_steps %2d: max f - f_ref %.2e, %d of %d calls above 1e-3, iterations %.2f" % r)
+    assert len(rows) == 16 and sum(r[3] for r in rows) == 0 and sum(r[4] for r in rows) == 16 * 4 * 30, rows
+
+
 def test_direction_by_neighbourhood(solver_mod):
     """Round 6, AUTO at control_steps 3: one launch of k_solve_routed, every instance solved by the direction its neighbourhood
     asks for (solver_rules.h).  NEO_MPC_FLAG_WALL_IN_REACH equals the mirror's reach-tile test on every instance (the README

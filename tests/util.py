@@ -198,6 +198,51 @@ def warm_gate(solve, postprocess, fixture):
     return dv[ok], du[ok], its, g["settled"].astype(bool)[ok]
 
 
+def p3w_group(solve, postprocess, params, cmap, grp):
+    """P3w on one set of recorded episodes (`grp`: gen_golden.gen_g4's arrays): every call solved by the build from the
+    REFERENCE's own state on the real costmap; the states are advanced with the reference's raw x.x injected.  Returns
+    f(build) - f(reference's raw x.x) per (episode, call), the iteration counts and how many searches ran into the iteration cap.
+    `solve(params, cmap, rows, states, warm) -> (commands, x)`, `postprocess(params, cmap, rows, states, warm, x, success)`."""
+    from neo_mpc_planner2_amd import abi
+    from oracle import c_oracle
+    n = params["control_steps"]
+    probs = problems_from(grp["problems"])
+    n_ep, n_calls = probs.shape
+    states, warm = abi.new_states(n_ep, n)
+    worse, its, capped = [], [], 0
+    for k in range(n_calls):
+        fp = grp["footprint"][:, k]
+        rows = probs[:, k].copy()
+        has = ~np.isnan(fp).any(axis=(1, 2))
+        rows["footprint_cost"] = 0.0
+        if has.any():
+            rows["footprint_cost"][has] = c_oracle.footprint_cost_batch(cmap, fp[has])
+        cm, x = solve(params, cmap, rows, states.copy(), warm.copy())
+        capped += int((cm["status"] != 0).sum())
+        worse.append(cm["cost"] - c_oracle.objective_batch(params, cmap, rows, grp["raw_x"][:, k]))
+        its.append(cm["iterations"].copy())
+        postprocess(params, cmap, rows, states, warm, grp["raw_x"][:, k], grp["success"][:, k])
+        assert np.allclose(states["last_control"], grp["last_control"][:, k], rtol=0, atol=1e-13)
+    return np.array(worse).T, np.array(its).T, capped
+
+
+def p3w_random_sets(solve, postprocess, fixture="g17_warm_costmap_sets.npz"):
+    """G17: P3w at RANDOM parameter sets on the costmap (oracle/gen_golden.py gen_g17).  Returns per set (seed, control_steps,
+    largest f(build) - f(reference), calls more than 1e-3 above, calls, mean iterations)."""
+    g = load(fixture)
+    cmap = (g["cells"],) + tuple(g["map_meta"])
+    rows = []
+    for seed, n in zip(g["seeds"], g["steps"]):
+        pre = "s%d_" % seed
+        grp = {k[len(pre):]: g[k] for k in g.files if k.startswith(pre)}
+        params = params_from(g["param_keys"], grp["params"])
+        assert params["control_steps"] == n
+        worse, its, capped = p3w_group(solve, postprocess, params, cmap, grp)
+        assert capped == 0, seed
+        rows.append((int(seed), int(n), float(worse.max()), int((worse > 1e-3).sum()), int(worse.size), float(its.mean())))
+    return rows
+
+
 def assert_warm_gate(dv, settled, fixture):
     """The gate on warm_gate()'s command differences: >= 99.9 % of the SETTLED ticks within 1e-3 of the reference's
     converged command (which ticks are settled is the fixture's statement about the reference's own answers -- the build's
@@ -281,7 +326,7 @@ def check_stop_rule_regressions(solve):
     return out
 
 
-def random_sets_miss_rates(solve, fixture="g14_random_sets.npz"):
+def random_sets_miss_rates(solve, fixture="g14_random_sets.npz", only_steps=None, over=None):
     """G14 / G15: RANDOM parameter sets (oracle/fuzz_reference.py's draws) x 24 cold problems under G10's protocol.  Counts:
     P3 misses (objective more than 1e-3 above SLSQP as shipped) on all-free maps and on costmaps, cases where SLSQP as
     shipped is more than 1e-3 above the build, P2 misses (first control more than 1e-3 from SLSQP run to the end) over the
@@ -291,9 +336,11 @@ def random_sets_miss_rates(solve, fixture="g14_random_sets.npz"):
     out = dict(cases_free=0, cases_map=0, p3_miss_free=0, p3_miss_map=0, p3_worst=-1.0, ref_worse=0, p2_cases=0, p2_miss=0, p2_worst=0.0,
                not_unique=0, p2_not_unique_worst=0.0, misses=[])
     for seed, n in zip(g["seeds"], g["steps"]):
+        if only_steps is not None and n != only_steps:
+            continue
         pre = "s%d_" % seed
         grp = {k[len(pre):]: g[k] for k in g.files if k.startswith(pre)}
-        params = params_from(g["param_keys"], grp["params"])
+        params = dict(params_from(g["param_keys"], grp["params"]), **(over or {}))
         assert params["control_steps"] == n
         probs = problems_from(grp["problems"])
         hm = grp["has_map"].astype(bool)
