@@ -5,7 +5,10 @@
 // "multi-GPU fleets").  Checks the gathered buffer against the per-GPU results and prints one JSON line.
 //
 //   hipcc -O2 -I include examples/fleet_allgather.cpp -L neo_mpc_planner2_amd -lneo_mpc \
-//         -Wl,-rpath,$PWD/neo_mpc_planner2_amd -o fleet_allgather && ./fleet_allgather [instances per GPU]
+//         -Wl,-rpath,$PWD/neo_mpc_planner2_amd -o fleet_allgather && ./fleet_allgather [instances per GPU] [ranks]
+// `ranks` (default: the visible GPUs): with more ranks than GPUs, rank d runs on device d modulo the GPUs -- RCCL itself
+// refuses two ranks on one device; the tests run eight logical ranks on their one GPU against a stand-in library
+// (NEO_MPC_RCCL_LIBRARY, tests/standin_rccl) to execute this file's group bracketing, offsets and gathered layout.
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -35,9 +38,11 @@ struct Rank {
 
 int main(int argc, char** argv) {
   const size_t count = argc > 1 ? (size_t)std::atol(argv[1]) : 4096;
-  int ndev = 0;
-  CHECK_HIP(hipGetDeviceCount(&ndev));
-  if (ndev < 1) { std::fprintf(stderr, "no HIP device\n"); return 1; }
+  int ngpu = 0;
+  CHECK_HIP(hipGetDeviceCount(&ngpu));
+  if (ngpu < 1) { std::fprintf(stderr, "no HIP device\n"); return 1; }
+  const int ndev = argc > 2 ? std::atoi(argv[2]) : ngpu;   // ranks; rank d runs on device d % ngpu
+  if (ndev < 1 || ndev > 64) { std::fprintf(stderr, "ranks must be 1..64\n"); return 1; }
   if (!neo_mpc_rccl_available()) { std::fprintf(stderr, "RCCL not available: %s\n", neo_mpc_last_error()); return 4; }
 
   neo_mpc_params prm;
@@ -60,7 +65,7 @@ int main(int argc, char** argv) {
 
   std::vector<int> devices(ndev);
   std::vector<void*> comms(ndev);
-  for (int d = 0; d < ndev; ++d) devices[d] = d;
+  for (int d = 0; d < ndev; ++d) devices[d] = d % ngpu;
   CHECK_MPC(neo_mpc_comm_init_all(ndev, devices.data(), comms.data()));
 
   std::vector<Rank> ranks(ndev);
@@ -68,9 +73,9 @@ int main(int argc, char** argv) {
   std::vector<neo_mpc_state> hs(count);
   for (int d = 0; d < ndev; ++d) {
     Rank& r = ranks[d];
-    CHECK_HIP(hipSetDevice(d));
+    CHECK_HIP(hipSetDevice(devices[d]));
     r.comm = comms[d];
-    r.h = neo_mpc_create(&prm, d);
+    r.h = neo_mpc_create(&prm, devices[d]);
     if (!r.h) { std::fprintf(stderr, "create: %s\n", neo_mpc_last_error()); return 3; }
     CHECK_MPC(neo_mpc_set_costmap(r.h, cells.data(), S, S, 0.05, -12.5, -12.5));
     CHECK_HIP(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
@@ -107,7 +112,7 @@ int main(int argc, char** argv) {
   for (int tick = 0; tick < ticks; ++tick) {
     for (int d = 0; d < ndev; ++d) {   // every GPU solves its block
       Rank& r = ranks[d];
-      CHECK_HIP(hipSetDevice(d));
+      CHECK_HIP(hipSetDevice(devices[d]));
       neo_mpc_batch b;
       std::memset(&b, 0, sizeof(b));
       b.count = count; b.problems = r.problems; b.states = r.states; b.warm_start = r.warm; b.commands = r.commands;
@@ -120,11 +125,11 @@ int main(int argc, char** argv) {
     auto g0 = std::chrono::steady_clock::now();
     CHECK_MPC(neo_mpc_group_start());   // the single exchange step
     for (int d = 0; d < ndev; ++d) {
-      CHECK_HIP(hipSetDevice(d));
+      CHECK_HIP(hipSetDevice(devices[d]));
       CHECK_MPC(neo_mpc_allgather_velocities(ranks[d].vel, ranks[d].all, count, ranks[d].comm, ranks[d].stream));
     }
     CHECK_MPC(neo_mpc_group_end());
-    for (int d = 0; d < ndev; ++d) { CHECK_HIP(hipSetDevice(d)); CHECK_HIP(hipStreamSynchronize(ranks[d].stream)); }
+    for (int d = 0; d < ndev; ++d) { CHECK_HIP(hipSetDevice(devices[d])); CHECK_HIP(hipStreamSynchronize(ranks[d].stream)); }
     if (tick == ticks - 1) gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g0).count();
   }
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -133,21 +138,21 @@ int main(int argc, char** argv) {
   bool ok = true;
   std::vector<double> own(count * 3), got((size_t)ndev * count * 3);
   for (int d = 0; d < ndev && ok; ++d) {
-    CHECK_HIP(hipSetDevice(d));
+    CHECK_HIP(hipSetDevice(devices[d]));
     CHECK_HIP(hipMemcpy(got.data(), ranks[d].all, got.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (int s = 0; s < ndev && ok; ++s) {
-      CHECK_HIP(hipSetDevice(s));
+      CHECK_HIP(hipSetDevice(devices[s]));
       CHECK_HIP(hipMemcpy(own.data(), ranks[s].vel, own.size() * sizeof(double), hipMemcpyDeviceToHost));
       ok = std::memcmp(own.data(), got.data() + (size_t)s * count * 3, own.size() * sizeof(double)) == 0;
     }
   }
   double speed_max = 0.0;
   for (size_t b = 0; b < count; ++b) speed_max = std::fmax(speed_max, std::hypot(own[3 * b], own[3 * b + 1]));
-  std::printf("{\"n_gpus\": %d, \"instances_per_gpu\": %zu, \"ticks\": %d, \"solves_per_s\": %.4g, \"last_gather_ms\": %.3f, "
+  std::printf("{\"n_gpus\": %d, \"ranks\": %d, \"instances_per_gpu\": %zu, \"ticks\": %d, \"solves_per_s\": %.4g, \"last_gather_ms\": %.3f, "
               "\"gathered_equals_local\": %s, \"max_speed\": %.4f}\n",
-              ndev, count, ticks, (double)ndev * count * ticks / secs, gather_ms, ok ? "true" : "false", speed_max);
+              ngpu < ndev ? ngpu : ndev, ndev, count, ticks, (double)ndev * count * ticks / secs, gather_ms, ok ? "true" : "false", speed_max);
   for (int d = 0; d < ndev; ++d) {
-    CHECK_HIP(hipSetDevice(d));
+    CHECK_HIP(hipSetDevice(devices[d]));
     neo_mpc_destroy(ranks[d].h);
     CHECK_MPC(neo_mpc_comm_destroy(ranks[d].comm));
   }

@@ -53,6 +53,8 @@ struct NeoMpcPlannerSeam {
   };
   double control_frequency = 30.0;
   bool closer_to_goal = false;
+  bool withhold_hint_ = false;          // (test: a caller that rebuilds neo_mpc_state from the node's attributes every tick
+                                        // loses the build's own hint, has_prev_u0 / prev_u0 -- results must hold without it)
   neo_mpc_problem last_request_{};      // (diagnostics: what the last tick sent and got -- `--dump` records them)
   neo_mpc_command last_command_{};
 
@@ -125,6 +127,7 @@ struct NeoMpcPlannerSeam {
     req.footprint_cost = footprint_cost_raw >= 254.0 ? 1.0 : 0.0;
     req.switch_opt = closer_to_goal ? 1 : 0;   // cpp:245 request->switch_opt = closer_to_goal (stored by the node, py:354, never read)
 
+    if (withhold_hint_) { mpc_state_.has_prev_u0 = 0; mpc_state_.prev_u0[0] = mpc_state_.prev_u0[1] = mpc_state_.prev_u0[2] = 0.0; }
     last_request_ = req;
     neo_mpc_command out{};
     neo_mpc_batch batch{};
@@ -153,6 +156,7 @@ struct NeoMpcPlannerSeam {
 //                    tick 60 and is gone again at tick 260 -- the per-tick costmap hand-over (cpp:290-334's
 //                    costmap_, getCharMap()) is what makes the robot stop in front of it (collision latch,
 //                    py:312-347, 374-382) and move on afterwards
+//   --withhold-hint  the state record is handed over without the build's own hint (has_prev_u0 = 0) every tick
 //   --dump FILE      every tick's request, state and warm start before and after, command and costmap version
 //                    (tests replay them through the oracle, tick by tick)
 #include <algorithm>
@@ -168,16 +172,18 @@ int main(int argc, char** argv) {
     return neo_mpc_abi_version() == NEO_MPC_ABI_VERSION ? 0 : 1;
   }
   int ticks = 300;
-  bool fake_clock = false, obstacle = false;
+  bool fake_clock = false, obstacle = false, withhold_hint = false;
   const char* dump_path = nullptr;
   for (int k = 2; k < argc; ++k) {
     if (!std::strcmp(argv[k], "--ticks") && k + 1 < argc) ticks = std::atoi(argv[++k]);
     else if (!std::strcmp(argv[k], "--fake-clock")) fake_clock = true;
     else if (!std::strcmp(argv[k], "--obstacle")) obstacle = true;
     else if (!std::strcmp(argv[k], "--dump") && k + 1 < argc) dump_path = argv[++k];
+    else if (!std::strcmp(argv[k], "--withhold-hint")) withhold_hint = true;
     else { std::fprintf(stderr, "unknown option %s\n", argv[k]); return 64; }
   }
   NeoMpcPlannerSeam seam;
+  seam.withhold_hint_ = withhold_hint;
   seam.configureSolver([](const char* name, double dflt) {   // the README's YAML block
     const struct { const char* n; double v; } readme[] = {
         {"acc_x_limit", 2.5}, {"acc_y_limit", 2.5}, {"acc_theta_limit", 3.0}, {"min_vel_x", -0.7}, {"min_vel_y", -0.7},
@@ -234,7 +240,8 @@ int main(int argc, char** argv) {
     carrot.pose.position.x = std::cos(yaw) * dx + std::sin(yaw) * dy;
     carrot.pose.position.y = -std::sin(yaw) * dx + std::cos(yaw) * dy;
     carrot.pose.orientation.z = std::sin(-0.5 * yaw); carrot.pose.orientation.w = std::cos(-0.5 * yaw);
-    const neo_mpc_state state_before = seam.mpc_state_;
+    neo_mpc_state state_before = seam.mpc_state_;   // (what the solver is handed: without the hint when it is withheld)
+    if (seam.withhold_hint_) { state_before.has_prev_u0 = 0; state_before.prev_u0[0] = state_before.prev_u0[1] = state_before.prev_u0[2] = 0.0; }
     double warm_before[3 * NEO_MPC_MAX_CONTROL_STEPS];
     std::memcpy(warm_before, seam.mpc_warm_, sizeof(warm_before));
     fake_now += 1.0 / seam.control_frequency;

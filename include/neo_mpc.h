@@ -303,6 +303,9 @@ void neo_mpc_destroy(neo_mpc_handle* handle);
 /* Dynamic reconfigure (`cb_params`, py:405-439).  Unlike the reference every field takes effect. */
 int neo_mpc_set_params(neo_mpc_handle* handle, const neo_mpc_params* params);
 int neo_mpc_get_params(const neo_mpc_handle* handle, neo_mpc_params* params);
+/* (Cloning a live handle -- another GPU of a fleet server: neo_mpc_get_params returns what the caller SET, which may be a
+ * pinned LBFGS / NEWTON that a later reconfigure took across w_costmap = w_trans / 4 -- a combination neo_mpc_create refuses.
+ * Create the sibling with `method` = neo_mpc_effective_method(handle): that is the direction the live handle runs.) */
 /* The direction the handle's solves run: NEO_MPC_METHOD_LBFGS / _NEWTON / _RICCATI (never AUTO) -- what AUTO resolved to,
  * or the stage-wise direction in place of a pinned LBFGS / NEWTON above w_costmap = w_trans / 4 (see NEO_MPC_METHOD_*);
  * < 0 on a null handle.  AUTO at control_steps 3 below that threshold decides per instance (behaviour 6): NEWTON is the

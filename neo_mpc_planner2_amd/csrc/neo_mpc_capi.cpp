@@ -609,11 +609,14 @@ int neo_mpc_balance_dispatch_device(neo_mpc_handle* h, const neo_mpc_command* d_
   if (!d_previous_commands || count == 0) { h->order_count = 0; return NEO_MPC_OK; }
   if (count > 0xffffffffull) return fail(NEO_MPC_ERR_INVALID_ARGUMENT, "count too large");
   HIP_TRY(hipSetDevice(h->device));
+  // (the average is kept while calls of the same count follow one another; disarming or another count starts it afresh)
+  const bool fresh = h->order_count != count;
+  // disarmed until the new order is on its way: a reserve() that re-allocates for a larger count and then fails, or a launch
+  // that fails, must not leave an order armed that points at a buffer nobody has written
+  h->order_count = 0;
   int rc = h->order_buf.reserve(count * sizeof(uint32_t));
   if (rc) return rc;
   if ((rc = h->load_buf.reserve(count * sizeof(float)))) return rc;
-  // (the average is kept while calls of the same count follow one another; disarming or another count starts it afresh)
-  const bool fresh = h->order_count != count;
   launch_dispatch_order(d_previous_commands, (float*)h->load_buf.ptr, (uint32_t*)h->order_buf.ptr, (uint32_t)count, fresh, stream);
   HIP_TRY(hipGetLastError());
   h->order_count = count;

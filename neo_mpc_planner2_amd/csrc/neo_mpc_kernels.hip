@@ -836,7 +836,15 @@ __device__ __forceinline__ bool solve_search(double* L, uint32_t b, SolveCarry& 
     ctx_from_lds<false>(as, L, cs);
     int ls = lane_again();
     NEO_SEGMENT_SCAN_BEGIN();
-    const bool won = cell_scan<kSteps, kTame, kCovered>(as, cs, L, f, kNewton ? &u_term : nullptr, nfev, ls, kSteps ? kSteps : as.p.n);
+    // (round 6) ... and again from where a scan has put the iterate, until a scan finds nothing: the returned point is a
+    // fixed point of the scan (solved again from its own answer an instance used to get a second look and move)
+    bool won = false;
+#pragma nounroll
+    for (int k = 0; k < NEO_RULE_SCAN_REPEATS; ++k) {
+      const bool w = cell_scan<kSteps, kTame, kCovered>(as, cs, L, f, kNewton ? &u_term : nullptr, nfev, ls, kSteps ? kSteps : as.p.n);
+      won = won || w;
+      if (!w) break;
+    }
     NEO_SEGMENT_SCAN_END();
     resume = won && f_before - f > as.p.scan_resume_gain && it < as.p.max_it;
     if (kFew && resume) {
@@ -850,6 +858,9 @@ __device__ __forceinline__ bool solve_search(double* L, uint32_t b, SolveCarry& 
   }
   NEO_SEGMENT(1);
   NEO_SEGMENT_DUMP();
+  // (a search taken up again behind a scan that runs into the iteration cap HAD converged, and the scan only improved its
+  // point: it is reported converged -- status 1 would hand the warm start back un-shifted, py:399-400, for a better answer)
+  if (scanned && status == NEO_MPC_STATUS_MAX_ITER) status = NEO_MPC_STATUS_CONVERGED;
   sc.f = f; sc.it = it; sc.nfev = nfev; sc.status = status;
   return false;
 }
@@ -894,6 +905,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve(const SolveA
   // (balanced dispatch, neo_mpc_balance_dispatch_device: which instance this workgroup solves -- instances are independent,
   // every result is bit for bit what it is in launch order; only which of them share a SIMD changes)
   const uint32_t b = args.order ? (uint32_t)__builtin_amdgcn_readfirstlane((int)args.order[blockIdx.x]) : blockIdx.x;
+  if (b >= args.count) return;   // (an order the caller launched this solve ahead of, on another stream: never out of range)
   NEO_WAVE_START;
   SolveCarry sc;
   if (!solve_setup<kSteps, kTame, kStaticTile, kLayoutSteps>(L, b, lane, sc)) return;
@@ -922,6 +934,7 @@ __global__ __launch_bounds__(kLanes, kMinWavesPerSimd) void k_solve_routed(const
   const int lane = threadIdx.x;
   if (blockIdx.x >= args.count) return;
   const uint32_t b = args.order ? (uint32_t)__builtin_amdgcn_readfirstlane((int)args.order[blockIdx.x]) : blockIdx.x;
+  if (b >= args.count) return;
   NEO_WAVE_START;
   SolveCarry sc;
   if (!solve_setup<kSteps, kTame, kStaticTile, kSteps>(L, b, lane, sc)) return;

@@ -10,6 +10,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 
 #include "neo_mpc_device.h"
@@ -39,11 +40,16 @@ Rccl& rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    // NEO_MPC_RCCL_LIBRARY=<path>: the library to bind instead of the system's librccl.so (read here, once) -- a site build
+    // of RCCL, or the tests' stand-in (tests/standin_rccl: several logical ranks on the one device a build box has)
+    const char* forced = getenv("NEO_MPC_RCCL_LIBRARY");
+    for (const char* name : {forced, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      if (!name || !*name) continue;
       r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
       if (r.lib) break;
       const char* e = dlerror();
       if (e) snprintf(r.why, sizeof(r.why), "%s", e);
+      if (name == forced) return;   // (the caller asked for THAT library: no silent fallback to another)
     }
     if (!r.lib) return;
 #define NEO_SYM(field, sym) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, sym))

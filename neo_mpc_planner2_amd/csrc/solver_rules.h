@@ -39,6 +39,7 @@
 /* ---- cell scan (cell_scan.h): what a search that has ended does about cheaper cells further away than a hop */
 #define NEO_RULE_SCAN_CELLS 3           /* the scan looks at the (2 x this + 1)^2 - 1 cells around every stage ... */
 #define NEO_RULE_SCAN_RESUME_GAIN 1.0   /* ... and the search is taken up again behind a scan that gained more than this x opt_tolerance */
+#define NEO_RULE_SCAN_REPEATS 8         /* a scan that found a cheaper cell is followed by another from the new point, at most this many in a row */
 
 /* search direction of lanes 32-63 */
 #define NEO_DIRECTION_LBFGS 0

@@ -124,9 +124,6 @@ class BatchSolver:
         n = self.control_steps
         problems = np.ascontiguousarray(problems, dtype=abi.PROBLEM_DTYPE)
         count = problems.shape[0]
-        if self._abi < 2 and problems["skip"].any():
-            # (an ABI-1 build under NEO_MPC_LIB knows no `skip`: it would solve robots K4 took out of the tick)
-            raise ValueError("the library under NEO_MPC_LIB is ABI 1 and ignores neo_mpc_problem.skip: batch refused")
         assert states.dtype == abi.STATE_DTYPE and states.shape == (count,) and states.flags.c_contiguous
         assert warm.dtype == np.float64 and warm.shape == (count, 3 * n) and warm.flags.c_contiguous
         if commands is None:

@@ -526,12 +526,13 @@ def test_c2_full_size_properties(solver_mod):
         st2 = st0.copy()
         cm2, x2 = s.solve(probs, st2, x.copy())
         assert (cm2["cost"] <= cmds["cost"] + 1e-12).all()
-        # (round 5: a search that has ended looks ONCE at the costmap cells around every stage (cell_scan.h) -- a restart from
-        # the solution is a second search and gets a second look: 5.5 % of the instances move by more than 1e-3, each to a
-        # LOWER objective, median gain 1.4e-4; a third solve moves 1.2 %.  Round 4, exit hop only: 2.1 %)
+        # (round 5: a search that has ended looks at the costmap cells around every stage (cell_scan.h) -- ONCE, and a restart
+        # from the solution, a second search, got a second look: 5.5 % of the instances moved by more than 1e-3, each to a
+        # LOWER objective.  Round 6: the scan is repeated from where it has put the iterate until it finds nothing -- the
+        # answer is a fixed point of the scan: 2.3 % move (mirror: 0.977 / 0.9565 within 1e-3 / 1e-4))
         moved = np.abs(x2 - x).max(axis=1)
-        assert (moved <= 1e-3).mean() >= 0.93     # the north-star tolerance
-        assert (moved <= 1e-4).mean() >= 0.91
+        assert (moved <= 1e-3).mean() >= 0.97     # the north-star tolerance
+        assert (moved <= 1e-4).mean() >= 0.95
         assert (cm2["cost"][moved > 1e-3] < cmds["cost"][moved > 1e-3]).all()
         # sharding: two half batches == the whole batch, bit for bit
         h = len(probs) // 2
@@ -863,7 +864,8 @@ def test_plugin_seam_example_runs_a_control_loop(tmp_path):
     print(rec)
 
 
-def test_plugin_seam_ticks_replayed_through_the_oracle(tmp_path):
+@pytest.mark.parametrize("withhold_hint", [False, True])
+def test_plugin_seam_ticks_replayed_through_the_oracle(tmp_path, withhold_hint):
     """f-3: the C++ seam (cpp:240-252 replacement) against the oracle, TICK BY TICK.  `--dump` records what every one
     of 520 control ticks sent (the Optimizer request incl. delta_t), held (state, warm start) and got; the local
     costmap handed over through a getCharMap()-shaped buffer CHANGES while the robot drives (cpp:290-334's
@@ -877,8 +879,10 @@ def test_plugin_seam_ticks_replayed_through_the_oracle(tmp_path):
     from oracle import c_oracle
     exe = _build_seam(tmp_path)
     dump = tmp_path / "seam.bin"
-    out = subprocess.run([str(exe), "--run", "--ticks", "520", "--fake-clock", "--obstacle", "--dump", str(dump)],
-                         capture_output=True, text=True, timeout=300)
+    # (withhold_hint: a caller that rebuilds neo_mpc_state from the node's attributes every tick loses the build's one
+    # addition to them, has_prev_u0 / prev_u0 -- the same replay, the same tolerances, without it)
+    out = subprocess.run([str(exe), "--run", "--ticks", "520", "--fake-clock", "--obstacle", "--dump", str(dump)] +
+                         (["--withhold-hint"] if withhold_hint else []), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, (out.returncode, out.stdout[-500:], out.stderr[-500:])
     summary = json.loads(out.stdout.strip().splitlines()[-1])
     params, geom, maps, ticks = util.load_seam_dump(str(dump))
@@ -1113,6 +1117,38 @@ def test_fleet_allgather_example_through_the_c_abi(tmp_path):
     assert out.returncode == 0, (out.returncode, out.stdout[-500:], out.stderr[-800:])
     rec = json.loads(out.stdout.strip().splitlines()[-1])
     assert rec["gathered_equals_local"] is True and rec["n_gpus"] >= 1 and rec["max_speed"] <= 0.7 + 1e-9
+    print(rec)
+
+
+def test_fleet_allgather_with_eight_logical_ranks_against_the_stand_in_library(tmp_path):
+    """The multi-rank path of the C-ABI EXECUTED on the hardware there is -- functional, not RCCL: RCCL refuses two ranks on
+    one device and the lease refuses to partition the GPU, so examples/fleet_allgather.cpp runs 8 logical ranks x 8192
+    instances on device 0 against tests/standin_rccl (the eight nccl* entry points as HIP copies on one device, bound through
+    NEO_MPC_RCCL_LIBRARY where neo_mpc_rccl.cpp opens librccl.so).  What runs for the first time with more than one rank:
+    neo_mpc_comm_init_all(8), the group bracketing, per-rank handles / streams / communicators, the offsets and the layout of
+    the gathered buffer -- every rank's slice of every rank's buffer equals that rank's own commands, bit for bit."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = tmp_path / "libstandin_rccl.so"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-fPIC", "-shared", os.path.join(root, "tests", "standin_rccl", "standin_rccl.cpp"),
+                           "-o", str(lib)])
+    exe = tmp_path / "fleet"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "fleet_allgather.cpp"),
+                           "-L", os.path.join(root, "neo_mpc_planner2_amd"), "-lneo_mpc",
+                           "-Wl,-rpath," + os.path.join(root, "neo_mpc_planner2_amd"), "-o", str(exe)])
+    env = dict(os.environ, NEO_MPC_RCCL_LIBRARY=str(lib))
+    out = subprocess.run([str(exe), "8192", "8"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, (out.returncode, out.stdout[-500:], out.stderr[-800:])
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["gathered_equals_local"] is True and rec["ranks"] == 8 and rec["instances_per_gpu"] == 8192
+    assert rec["max_speed"] <= 0.7 + 1e-9
+    # a library that is asked for by name and cannot be loaded is an error, not a silent fallback to the system's RCCL
+    bad = subprocess.run([str(exe), "64", "2"], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, NEO_MPC_RCCL_LIBRARY=str(tmp_path / "no_such_library.so")))
+    assert bad.returncode == 4 and "could not be loaded" in bad.stderr
     print(rec)
 
 
