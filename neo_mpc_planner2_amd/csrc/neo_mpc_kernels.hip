@@ -377,6 +377,8 @@ __device__ __forceinline__ bool solve_search(double* L, uint32_t b, SolveCarry& 
   bool final_step = false;
   double alpha = 1.0;
   bool scanned = false;   // the cell scan has had its turn (cell_scan.h)
+  int nscans = 0;         // ... scans of its round so far: a scan that found a cheaper cell is followed by another from the new point
+  bool scan_only = false; // this pass of the loop below only scans again
   // (the lane index is not kept in a register across the loop -- the stage-wise kernels at four waves per SIMD parked it in
   // scratch and reloaded it at the top of every iteration: it is re-derived from the hardware's lane mask count, seeded
   // with an opaque zero so that the compiler cannot hoist it either)
@@ -414,7 +416,7 @@ __device__ __forceinline__ bool solve_search(double* L, uint32_t b, SolveCarry& 
   // tangent-cone pass; it lives in the cs..rt step arrays, which the Newton kernel does not use
   static_assert(2 * 7 >= kNewtonRecord, "Newton records do not fit the step arrays");
 
-  if (!scanned) {
+  if (!scanned && nscans == 0) {
     const int lane = lane_again();
     for (int i = lane; i < n; i += kLanes) { AMODE[4 * i + 2] = 0; AMODE[4 * i + 3] = 0; }
     // (routed stage-wise branch: this direction's prox-only zone around the kink -- the set-up wrote the dense direction's)
@@ -447,7 +449,7 @@ __device__ __forceinline__ bool solve_search(double* L, uint32_t b, SolveCarry& 
     int l0 = lane_again();
     my_scale = kRiccati ? 0.0 : lane_scale<kSecond>(l0);
   }
-  for (; it < p.max_it; ++it) {
+  for (; it < p.max_it && !scan_only; ++it) {
     // The lane index is re-read opaquely every iteration: otherwise the compiler hoists two dozen
     // lane-derived constants (step multipliers, compare masks, LDS addresses) out of the loop and,
     // at 4 waves/SIMD, parks them in scratch -- recomputing them costs a few integer operations.
@@ -822,12 +824,13 @@ __device__ __forceinline__ bool solve_search(double* L, uint32_t b, SolveCarry& 
   //      and SLSQP's line search samples by accident.  Skipped when the whole reach tile is free or (dense direction: known
   //      from the winner's rollout) no stage of the iterate has a costmap term under it.  Behind a scan that gained more
   //      than opt_tolerance the search is taken up again: the other blocks have a new neighbour to adjust to.
-  if (!kSecond || scanned || status != NEO_MPC_STATUS_CONVERGED || (c.tile_geom & kTileFree) || (kNewton && u_term == 0.0) ||
-      p.max_it >= kDumpGradient)
-    break;
-  scanned = true;
-  const double f_before = f;
-  bool resume;
+  // (round 6) A scan that found a cheaper cell is followed by another from where it has put the iterate (one pass of this loop
+  // each, NEO_RULE_SCAN_REPEATS at most), until a scan finds nothing: the returned point is a fixed point of the scan -- solved
+  // again from its own answer an instance used to get a second look and move.  The round as a whole decides about the resume.
+  if (!kSecond || scanned || status != NEO_MPC_STATUS_CONVERGED || p.max_it >= kDumpGradient) break;
+  const bool nothing_to_scan = (c.tile_geom & kTileFree) || (kNewton && u_term == 0.0);
+  if (nothing_to_scan && nscans == 0) break;
+  bool resume = false;
   {
     SolveArgs as;
     fresh_args<kSteps, kStaticTile, kLayoutSteps, kRouted>(as);
@@ -835,23 +838,24 @@ __device__ __forceinline__ bool solve_search(double* L, uint32_t b, SolveCarry& 
     Ctx cs;
     ctx_from_lds<false>(as, L, cs);
     int ls = lane_again();
+    if (nscans == 0 && ls == 0) L[as.lds.tol + T_FSCAN] = f;
     NEO_SEGMENT_SCAN_BEGIN();
-    // (round 6) ... and again from where a scan has put the iterate, until a scan finds nothing: the returned point is a
-    // fixed point of the scan (solved again from its own answer an instance used to get a second look and move)
-    bool won = false;
-#pragma nounroll
-    for (int k = 0; k < NEO_RULE_SCAN_REPEATS; ++k) {
-      const bool w = cell_scan<kSteps, kTame, kCovered>(as, cs, L, f, kNewton ? &u_term : nullptr, nfev, ls, kSteps ? kSteps : as.p.n);
-      won = won || w;
-      if (!w) break;
-    }
+    const bool w = !nothing_to_scan &&
+                   cell_scan<kSteps, kTame, kCovered>(as, cs, L, f, kNewton ? &u_term : nullptr, nfev, ls, kSteps ? kSteps : as.p.n);
     NEO_SEGMENT_SCAN_END();
-    resume = won && f_before - f > as.p.scan_resume_gain && it < as.p.max_it;
-    if (kFew && resume) {
-      if (ls == 0) { L[as.lds.tol + T_GAIN1] = INFINITY; L[as.lds.tol + T_GAIN2] = INFINITY; }
+    ++nscans;
+    scan_only = w && nscans < NEO_RULE_SCAN_REPEATS;
+    if (!scan_only) {
+      scanned = true;
       WAVE_SYNC();
+      resume = L[as.lds.tol + T_FSCAN] - f > as.p.scan_resume_gain && it < as.p.max_it;
+      if (kFew && resume) {
+        if (ls == 0) { L[as.lds.tol + T_GAIN1] = INFINITY; L[as.lds.tol + T_GAIN2] = INFINITY; }
+        WAVE_SYNC();
+      }
     }
   }
+  if (scan_only) continue;
   if (!resume) break;
   status = NEO_MPC_STATUS_MAX_ITER; stall = 0; final_step = false; blocked_run = 0; nblocked = 1;
   gain1 = INFINITY; gain2 = INFINITY;

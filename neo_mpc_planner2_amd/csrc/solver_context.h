@@ -39,6 +39,7 @@ enum : int { T_XTOL, T_EARLY, T_FINAL, T_FTOL, T_STALL, T_WTOL, T_KINK, T_KONST,
              // the previous two iterations, proximal step length): as registers they were live across the 64-candidate pass,
              // where the candidates themselves sit in registers, and came out spilled to scratch
              T_GAIN1 = 28, T_GAIN2 = 29, T_ALPHA = 30,
+             T_FSCAN = 31 /* the objective in front of a round of cell scans (the round decides whether the search is taken up again) */,
              kTolDoubles = 32, kHopLanes = 4 /* = NEO_RULE_HOP_LANES (solver_rules.h) */ };
 
 constexpr int kTileFree = 0x80;   // Ctx::tile_geom: every cell of the reach tile is free (raw cost 0)

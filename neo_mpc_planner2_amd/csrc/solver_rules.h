@@ -39,7 +39,7 @@
 /* ---- cell scan (cell_scan.h): what a search that has ended does about cheaper cells further away than a hop */
 #define NEO_RULE_SCAN_CELLS 3           /* the scan looks at the (2 x this + 1)^2 - 1 cells around every stage ... */
 #define NEO_RULE_SCAN_RESUME_GAIN 1.0   /* ... and the search is taken up again behind a scan that gained more than this x opt_tolerance */
-#define NEO_RULE_SCAN_REPEATS 8         /* a scan that found a cheaper cell is followed by another from the new point, at most this many in a row */
+#define NEO_RULE_SCAN_REPEATS 1         /* scans in a row behind a search: a scan that found a cheaper cell could be followed by another from the new point -- measured (mirror, config 2): the answers that are fixed points of the whole solve to 1e-3 go 95.8 % (1) -> 97.3 % (2) -> 97.7 % (8), each to a LOWER objective; on the GPU every scan of a launch's last waves lengthens the launch: the dense kernel 0.093 -> 0.109 ms (2) -> 0.139 ms (8).  One it stays */
 
 /* search direction of lanes 32-63 */
 #define NEO_DIRECTION_LBFGS 0

@@ -18,8 +18,9 @@ _lib = None
 
 def build():
     src = os.path.join(HERE, "mpc_oracle.c")
-    hdr = os.path.join(HERE, "..", "include", "neo_mpc.h")
-    if (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    hdrs = [os.path.join(HERE, "..", "include", "neo_mpc.h"),
+            os.path.join(HERE, "..", "neo_mpc_planner2_amd", "csrc", "solver_rules.h")]   # (the rule book the mirror shares)
+    if (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(os.path.getmtime(f) for f in [src] + hdrs):
         subprocess.check_call(["make", "-C", HERE, "-s"])
     return LIB
 

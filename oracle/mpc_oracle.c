@@ -1667,9 +1667,8 @@ resume_search:
   if (orc_scan_on && newton && status == NEO_MPC_STATUS_CONVERGED && !scanned && orc_term_sum(&c, u) != 0.0) {
     scanned = 1;
     const double f_before = f;
-    /* (round 6) ... and looks again from where a scan has put it, until a scan finds nothing (NEO_RULE_SCAN_REPEATS at most): the
-     * returned point is then a fixed point of the scan -- solved again from its own answer an instance used to get a second
-     * look and 5.5 % of the config-2 instances moved by more than 1e-3 (each to a lower objective); now 2.3 % do */
+    /* (round 6: NEO_RULE_SCAN_REPEATS scans in a row -- a scan that found a cheaper cell may be followed by another from the new
+     * point; the rule book keeps it at one and says what more would buy and cost) */
     int won = orc_cell_scan(&c, neo_rules_reach_cells(p, m->resolution), u, &f, rules.hop_min_drop, &nfev);
     for (int k = 1; k < NEO_RULE_SCAN_REPEATS && won && orc_term_sum(&c, u) != 0.0; ++k)
       if (!orc_cell_scan(&c, neo_rules_reach_cells(p, m->resolution), u, &f, rules.hop_min_drop, &nfev)) break;
