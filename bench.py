@@ -314,6 +314,8 @@ def roofline(workload, batch, n, k_ms, launches_timed=None, params_over=None):
     launch from the committed PMC passes, CORRECTED with the calibration of the counters on K1's own access shapes
     (tools/mb_k1_traffic.hip; raw FETCH_SIZE / WRITE_SIZE beside it).  Without a PMC pass of this build (stale sources, other
     parameter set) there is no instruction count to price: `bound` falls back to "hbm" and the HBM figures are the object."""
+    # (control_steps 3 under AUTO: the routed kernel -- direction by neighbourhood; a pinned method: the one-direction kernel)
+    kernel_name = "k_solve_routed" if n == 3 and not (params_over or {}).get("method") else "k_solve"
     algo = ALGO_BYTES.get(n, (17 + 3 * n) * 4 + (3 + 3 * n + 1) * 4 + 729)
     achieved = algo * batch / (k_ms * 1e-3) / 1e9
     entry, note = pmc_entry(workload, batch) if not params_over else (None, "other parameter set")
@@ -335,7 +337,7 @@ def roofline(workload, batch, n, k_ms, launches_timed=None, params_over=None):
     else:
         r = {k: h[k] for k in ("bound", "achieved", "peak", "unit", "frac")}
         r["what"] = "no PMC pass of this build and workload to price the instruction stream with (%s): HBM figures" % note
-    r.update({"traffic": h["traffic"], "traffic_note": h["traffic_note"], "kernel": "k_solve", "kernel_ms": k_ms, "hbm": h})
+    r.update({"traffic": h["traffic"], "traffic_note": h["traffic_note"], "kernel": kernel_name, "kernel_ms": k_ms, "hbm": h})
     if launches_timed is not None:
         r["kernel_ms_launches_timed"] = launches_timed
     return r, entry

@@ -196,3 +196,35 @@ def test_bench_cpu_worker_and_cpu_count_without_a_gpu():
     import bench
     n = bench.usable_cpus()
     assert 1 <= n <= (os.cpu_count() or 1)
+
+
+def test_baseline_kernels_are_scratch_free():
+    """The kernels of the BASELINE configs -- k_solve_routed<4, tame, static tile> (config 2 / 4: control_steps 3, AUTO) and
+    k_solve<4, 0, stage-wise, tame> (configs 3 and 5) -- spill no vector register: 0 bytes of scratch per lane at their four
+    waves per SIMD (round 5's config-3 / 5 kernel had picked up 24 bytes per lane unnoticed: its HBM writes doubled).  The
+    compiler's own resource remarks for the translation unit both live in, with the flags of the Makefile; no GPU needed."""
+    import os
+    import re
+    import subprocess
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "neo_mpc_planner2_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    flags = re.search(r"^RICCATI_FLAGS := (.*)$", mk, re.M).group(1).split()
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function",
+                          "-Wno-pass-failed"] + flags + ["-Rpass-analysis=kernel-resource-usage", "-x", "hip", "-c",
+                          "neo_mpc_riccati.hip", "-o", os.devnull], cwd=csrc, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows, cur = {}, None
+    for line in out.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1)
+            rows[cur] = {}
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+)(?: \[[^\]]*\])?: (\d+)", line)
+        if m and cur:
+            rows[cur][m.group(1).strip()] = int(m.group(2))
+    wanted = {"k_solve_routedILi4ELb1ELi1024E": "config 2 / 4", "7k_solveILi4ELi0ELi2ELb1ELi0E": "configs 3, 5"}
+    for key, what in wanted.items():
+        hit = [v for k, v in rows.items() if key in k]
+        assert len(hit) == 1, (key, list(rows))
+        assert hit[0]["ScratchSize"] == 0 and hit[0]["VGPRs Spill"] == 0 and hit[0]["VGPRs"] <= 128 and hit[0]["Occupancy"] >= 4, (what, hit[0])

@@ -6,7 +6,7 @@ import collections, os, re, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 key = sys.argv[1]
 # the Riccati variants of K1 (k_solve<*, 0, 2, *>: "...ELi0ELi2E...") live in neo_mpc_riccati.hip, built without SLP
-riccati = "ELi0ELi2E" in key
+riccati = "ELi0ELi2E" in key or "k_solve_routed" in key
 src = os.path.join(root, "neo_mpc_planner2_amd/csrc", "neo_mpc_riccati.hip" if riccati else "neo_mpc_kernels.hip")
 out = "/tmp/asm_profile.s"
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-pass-failed"] +
@@ -25,7 +25,7 @@ for l in text[start:end]:
     if m:
         chain = re.findall(r"neo_mpc_kernels\.hip:(\d+):\d+", l)
         if chain:
-            cur = int(chain[-1])        # outermost frame = the line inside the kernel
+            cur = int(chain[-2]) if len(chain) >= 2 else int(chain[-1])   # the frame under the kernel's call site: the line in solve_search (K1 is split into solve_setup / solve_search / solve_finish)
             inner = int(chain[0]) if "neo_mpc_kernels.hip:%s:" % chain[0] in l.split("@[")[0] else -int(m.group(2))
         elif int(m.group(1)) <= 1:
             cur = int(m.group(2))       # not inlined: the kernel's own line

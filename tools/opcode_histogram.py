@@ -3,7 +3,9 @@
 static opcode histogram of the solver loop of k_solve<4,3,1,true,1024> next to the PMC type mix; name the top
 non-arithmetic opcodes").
 
-usage: opcode_histogram.py [kernel-mangled-substring] [--top N] [--by-line]
+usage: opcode_histogram.py [kernel-mangled-substring] [--top N] [--by-line] [--branch dense|stagewise]
+(K1's solver loop lives in solve_search, inlined into the kernels: an instruction is attributed to its line THERE -- the
+frame under the kernel's own call site; --branch keeps one branch of k_solve_routed, whose two branches inline it twice)
 Compiles the translation unit with -gline-tables-only -S (device only), attributes every instruction to the kernel's own
 source line through the .loc inlining chain (like tools/asm_profile.py) and counts opcodes for the lines of the solver loop
 (`for (it = 0; ...` to the exit block).  Static counts: a straight-line count of the code, not of what a wave executes."""
@@ -13,7 +15,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 key = args[0] if args else "k_solveILi4ELi3ELi1ELb1ELi1024E"
 top = int(sys.argv[sys.argv.index("--top") + 1]) if "--top" in sys.argv else 40
-riccati = "ELi0ELi2E" in key
+riccati = "ELi0ELi2E" in key or "k_solve_routed" in key
 csrc = os.path.join(root, "neo_mpc_planner2_amd/csrc")
 src = os.path.join(csrc, "neo_mpc_riccati.hip" if riccati else "neo_mpc_kernels.hip")
 out = "/tmp/opcode_histogram.s"
@@ -22,7 +24,11 @@ subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++
                ["-gline-tables-only", "-x", "hip", "--cuda-device-only", "-S", src, "-o", out],
                check=True, stderr=subprocess.DEVNULL)
 ksrc = open(os.path.join(csrc, "neo_mpc_kernels.hip")).read().split("\n")
-loop_lo = next(i + 1 for i, l in enumerate(ksrc) if "for (it = 0; it < p.max_it; ++it)" in l or "for (; it < p.max_it; ++it) {" in l)
+loop_lo = next(i + 1 for i, l in enumerate(ksrc) if "for (; it < p.max_it && !scan_only; ++it) {" in l)
+branch = sys.argv[sys.argv.index("--branch") + 1] if "--branch" in sys.argv else None
+# (the two call sites of solve_search in k_solve_routed: direction 2 = stage-wise, 1 = dense)
+site = {"stagewise": next(i + 1 for i, l in enumerate(ksrc) if "solve_search<kMinWavesPerSimd, kSteps, 2, kTame" in l),
+        "dense": next(i + 1 for i, l in enumerate(ksrc) if "solve_search<kMinWavesPerSimd, kSteps, 1, kTame" in l)}
 # (the loop ends where the exit-hop block of the dense direction, or the epilogue, begins)
 loop_hi = next(i for i, l in enumerate(ksrc) if ("a search that has ENDED" in l or "NEO_SEGMENT(1);" in l or "phase 2, second-order directions" in l) and i + 1 > loop_lo)
 text = open(out).read().split("\n")
@@ -71,20 +77,24 @@ def klass(op):
 by_line_prefix = sys.argv[sys.argv.index("--by-line") + 1].split(",") if "--by-line" in sys.argv else None
 line_hits = collections.defaultdict(collections.Counter)
 cur = 0
+skip = False
 ops_loop, ops_rest = collections.Counter(), collections.Counter()
 cls_loop, cls_rest = collections.Counter(), collections.Counter()
 dpp_loop = 0
 for l in text[start:end]:
     m = re.match(r"\s*\.loc\s+(\d+)\s+(\d+)\s+\d+", l)
     if m:
-        chain = re.findall(r"neo_mpc_kernels\.hip:(\d+):\d+", l)
-        if chain:
-            cur = int(chain[-1])
-        elif int(m.group(1)) <= 1:
-            cur = int(m.group(2))
+        chain = [int(x) for x in re.findall(r"neo_mpc_kernels\.hip:(\d+):\d+", l)]
+        own = int(m.group(2)) if int(m.group(1)) <= 1 else None    # (the .loc's own line when it is in neo_mpc_kernels.hip)
+        frames = ([own] if own is not None and not chain else []) + chain   # innermost ... outermost (the kernel's call site)
+        if own is not None and chain:
+            frames = [own] + chain
+        skip = branch is not None and site[branch] not in frames
+        # the line in solve_search: the frame under the kernel-level call site (a plain kernel: its own line)
+        cur = frames[-2] if len(frames) >= 2 else (frames[-1] if frames else cur)
         continue
     t = l.strip()
-    if not t or t[0] in ".;_" or t.endswith(":"):
+    if not t or t[0] in ".;_" or t.endswith(":") or skip:
         continue
     op = t.split()[0]
     if not op.startswith(("v_", "s_", "ds_", "global_", "scratch_", "buffer_", "flat_")):

@@ -1,6 +1,6 @@
 #!/bin/bash
-# copy the summaries of `bash tools/r5_profile.sh <tag>` (gpurun_out/) into profiles/ as <prefix>_*
-# usage: bash tools/r5_install.sh <tag, e.g. r04a> <prefix, e.g. r04_a> [old prefix to remove]
+# copy the summaries of `bash tools/r6_profile.sh <tag>` (gpurun_out/) into profiles/ as <prefix>_*
+# usage: bash tools/r6_install.sh <tag, e.g. r04a> <prefix, e.g. r04_a> [old prefix to remove]
 set -e
 TAG=$1; T=$2; OLD=${3:-}
 F=gpurun_out/final_$TAG; P=gpurun_out/prof_$TAG
@@ -24,6 +24,9 @@ cp $F/split_call.json profiles/${T}_split_call.json
 cp $F/balanced_dispatch.json profiles/${T}_balanced_dispatch.json
 cp $F/soak_fleet.json profiles/${T}_soak_fleet.json
 cp $F/opcodes_c2.txt profiles/${T}_opcodes_c2.txt
+cp $F/opcodes_c2_dense_only.txt profiles/${T}_opcodes_c2_dense_only.txt
+cp $F/bench_c2_dense_only.json profiles/${T}_bench_c2_dense_only.json
+grep -v amdgpu.ids $F/phase_timing_routed.txt > profiles/${T}_phase_timing_routed.txt
 cp $F/opcodes_riccati.txt profiles/${T}_opcodes_riccati.txt
 cp gpurun_out/prof_${TAG}_k1cal/calibration.json profiles/${T}_k1_traffic_calibration.json
 python - <<PY

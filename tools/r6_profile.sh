@@ -1,8 +1,8 @@
 #!/bin/bash
 # one gpurun call: GPU tests, rocprofv3 evidence for C2 / C3 / C5 (kernel stats + PMC in separate passes) and K3, the default
 # bench line (other_workloads, warm_tick, pcie variants ride in it), parity report, closed loop, tick latency
-# usage: bash tools/r5_profile.sh <tag>      then: bash tools/r5_install.sh <tag> <prefix>
-TAG=${1:-r05a}
+# usage: bash tools/r6_profile.sh <tag>      then: bash tools/r6_install.sh <tag> <prefix>
+TAG=${1:-r06a}
 O=gpurun_out/final_$TAG
 mkdir -p $O
 timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -15 > $O/gpu_tests.log
@@ -21,6 +21,9 @@ for d in ("gpurun_out/prof_$TAG", "gpurun_out/prof_${TAG}_C3", "gpurun_out/prof_
 json.dump(out, open("profiles/hbm_traffic.json", "w"), indent=1)
 PY
 timeout 900 python bench.py > $O/bench_c2.log 2>&1; tail -1 $O/bench_c2.log > $O/bench_c2.json
+# (the A/B partner of the routed headline kernel: the dense direction for every instance, round 5's AUTO)
+timeout 300 python bench.py --no-cpu-baseline --no-pcie --no-others --method 2 2>/dev/null | tail -1 > $O/bench_c2_dense_only.json
+NEO_MPC_LIB=neo_mpc_planner2_amd/libneo_mpc_timing.so timeout 300 python tools/phase_timing_routed.py > $O/phase_timing_routed.txt 2>&1
 timeout 600 bash tools/profile_k3.sh $TAG > $O/profile_k3.txt 2>&1
 timeout 900 python tools/parity_report.py > $O/parity_report.txt 2>&1
 timeout 300 python tools/bench_fleet_loop.py 2>/dev/null | tail -1 > $O/fleet_loop.json
@@ -30,6 +33,8 @@ timeout 600 python tools/bench_host_path.py 2>/dev/null | tail -1 > $O/host_path
 timeout 300 python tools/bench_split_call.py 2>/dev/null | tail -1 > $O/split_call.json
 timeout 300 python tools/bench_balance.py 2>/dev/null | tail -1 > $O/balanced_dispatch.json
 timeout 600 python tools/soak_fleet.py 2>/dev/null | tail -1 > $O/soak_fleet.json
-python tools/opcode_histogram.py k_solveILi4ELi3ELi1ELb1ELi1024E > $O/opcodes_c2.txt 2>&1
+{ echo "== stage-wise branch (instances with a wall in reach)"; python tools/opcode_histogram.py k_solve_routedILi4ELb1ELi1024E --branch stagewise;
+  echo; echo "== dense branch"; python tools/opcode_histogram.py k_solve_routedILi4ELb1ELi1024E --branch dense; } > $O/opcodes_c2.txt 2>&1
+python tools/opcode_histogram.py k_solveILi4ELi3ELi1ELb1ELi1024E > $O/opcodes_c2_dense_only.txt 2>&1
 python tools/opcode_histogram.py k_solveILi4ELi0ELi2ELb1ELi0E > $O/opcodes_riccati.txt 2>&1
 cat $O/gpu_tests.log; cut -c1-1500 $O/bench_c2.json; grep -v amdgpu $O/parity_report.txt | tail -30; cat $O/fleet_loop.json | cut -c1-400; cat $O/tick_latency.json

@@ -14,8 +14,9 @@ for l in sys.stdin:
     if m and cur: rows[cur][m.group(1).strip()]=int(m.group(2))
 for k,v in rows.items():
     if 'k_solve' not in k: continue
-    name=re.sub(r'.*k_solveI','k_solve<',k).replace('EEEvNS_9SolveArgsE','>').replace('ELi',',').replace('ELb',',b').replace('Li','')
-    if ('$tu'=='neo_mpc_riccati.hip') != (',0,2,' in name): continue
+    name=re.sub(r'.*k_solve_routedI','k_solve_routed<',k) if 'k_solve_routed' in k else re.sub(r'.*k_solveI','k_solve<',k)
+    name=name.replace('EEEvNS_9SolveArgsE','>').replace('ELi',',').replace('ELb',',b').replace('Li','').replace('Lb','b')
+    if ('$tu'=='neo_mpc_riccati.hip') != (',0,2,' in name or 'routed' in name): continue
     print('%-34s VGPR %3d SGPR %3d sgpr-spill %3d vgpr-spill %3d scratch %3d occ %d' % (name, v.get('VGPRs',0), v.get('SGPRs',0), v.get('SGPRs Spill',0), v.get('VGPRs Spill',0), v.get('ScratchSize',0), v.get('Occupancy',0)))
 " | grep "${1:-.}"
 done

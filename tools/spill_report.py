@@ -10,7 +10,7 @@ text = open("/tmp/asm_profile.s").read().split("\n")
 start = next(i for i, l in enumerate(text) if l.startswith("_Z") and key in l and ":" in l)
 end = next(i for i in range(start, len(text)) if ".amdhsa_kernel" in text[i])
 src = open(os.path.join(root, "neo_mpc_planner2_amd/csrc/neo_mpc_kernels.hip")).read().split("\n")
-lo = next(i for i, l in enumerate(src, 1) if "for (; it < p.max_it; ++it)" in l)
+lo = next(i for i, l in enumerate(src, 1) if "for (; it < p.max_it && !scan_only; ++it)" in l)
 hi = next(i for i, l in enumerate(src, 1) if i > lo and "a search that has ENDED" in l)
 body = text[start:end]
 spill_regs = collections.Counter(re.search(r"v_writelane_b32 (v\d+),", l).group(1) for l in body if "v_writelane_b32" in l)
@@ -21,7 +21,7 @@ for l in body:
     m = re.match(r"\s*\.loc\s+(\d+)\s+(\d+)\s+\d+", l)
     if m:
         chain = re.findall(r"neo_mpc_kernels\.hip:(\d+):\d+", l)
-        cur = int(chain[-1]) if chain else (int(m.group(2)) if int(m.group(1)) <= 1 else cur)
+        cur = (int(chain[-2]) if len(chain) >= 2 else int(chain[-1])) if chain else (int(m.group(2)) if int(m.group(1)) <= 1 else cur)
         continue
     t = l.strip()
     where = "loop" if lo <= cur <= hi else "outside"
