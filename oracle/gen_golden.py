@@ -505,6 +505,17 @@ def gen_g16(mod):
     _random_sets(G16_SEEDS, "g16_judge_sets_r5.npz", "G16")
 
 
+#: G18 (round 6): HELD OUT from the direction-by-neighbourhood rule -- the first 48 of the 200 seeds 70000-70199, drawn for this
+#: purpose; the reference's answers were generated while the rule was being built, the build ran on them ONCE, with the final
+#: rules (profiles/r06_fuzz_reference.txt: no miss on any of the 200)
+G18_SEEDS = range(70000, 70048)
+
+
+def gen_g18(mod):
+    """G18: G14's protocol on seeds 70000-70047."""
+    _random_sets(G18_SEEDS, "g18_held_out_sets.npz", "G18")
+
+
 #: G17 (round 6): the deployed mode on costmaps away from the four recorded episode files -- P3w's protocol at RANDOM parameter
 #: sets: fuzz_reference.draw(seed), 4 optimizer() episodes x 30 calls of the reference AS SHIPPED (the set's own opt_tolerance)
 #: on the 200 x 200 costmap of G4 (episode 2 starts in front of a lethal disc, episode 1 carries a footprint), robots moved by
@@ -830,6 +841,7 @@ def main():
     gen_g15(mod)
     gen_g16(mod)
     gen_g17(mod)
+    gen_g18(mod)
 
 
 if __name__ == "__main__":

@@ -24,7 +24,7 @@ SLOW = {"g3": ["g3_solves.npz"], "g8": ["g8_solves_params.npz"], "g8mid": ["g8_m
         "g10": ["g10_heldout.npz"], "g11": ["g11_warm_converged.npz", "g11_warm_converged_n8.npz"],
         "g12": ["g12_after_tuning.npz"], "g13": ["g13_warm_converged_set_a.npz", "g13_warm_converged_set_a_n5.npz"], "g14": ["g14_random_sets.npz"],
         "g15": ["g15_judge_sets.npz"], "g16": ["g16_judge_sets_r5.npz"],
-        "g17": ["g17_warm_costmap_sets.npz"]}
+        "g17": ["g17_warm_costmap_sets.npz"], "g18": ["g18_held_out_sets.npz"]}
 
 
 def _regenerate_and_compare(name, files, tmp_path):

@@ -126,7 +126,13 @@ def closed_loop_on_the_mirror(params, cmap, probs, ticks, hz=30.0):
 orc = orc  # re-export: tests use util.orc.make_params
 
 
-def check_held_out_group(solve, name, n_steps, p2_bar=3e-4, fixture="g10_heldout.npz", min_ok=8):
+#: how many all-free-map cases of a held-out group have to count for the first-control gate: 16 of the 24 (round 4's bar),
+#: except where the REFERENCE's own sixteen answers leave fewer unique -- set "a" (heavy control weight: SLSQP at ftol 1e-12
+#: stops up to 1.7e-2 apart in a valley that flat) and "d" at control_steps 10: there the fixture's own count is the bar
+MIN_UNIQUE = {("a", 5): 15, ("a", 8): 10, ("a", 12): 9, ("d", 10): 12}
+
+
+def check_held_out_group(solve, name, n_steps, p2_bar=3e-4, fixture="g10_heldout.npz", min_ok=None):
     """G10 gates for one (set, control_steps) group.  `solve(params, cmap, problems) -> (commands, x)` is the build's cold
     solve (GPU through the C-ABI, or the CPU mirror).  P3 on every case: f <= f(SLSQP as shipped, ftol = the set's
     opt_tolerance) + 1e-3, feasible, converged.  P2 on the all-free-map cases the FIXTURE flags `unique` -- the reference's
@@ -152,7 +158,7 @@ def check_held_out_group(solve, name, n_steps, p2_bar=3e-4, fixture="g10_heldout
         if tag == "free":
             unique = grp["unique"][mask].astype(bool)
             others = (grp["status_tight"][mask] == 0) & ~unique
-            assert unique.sum() >= min_ok, (name, n_steps, int(unique.sum()))
+            assert unique.sum() >= (MIN_UNIQUE.get((name, n_steps), 16) if min_ok is None else min_ok), (name, n_steps, int(unique.sum()))
             du0 = np.abs(x[:, :3] - grp["x_tight"][mask][:, :3]).max(axis=1)
             assert du0[unique].max() <= p2_bar, (name, n_steps, du0[unique].max())                          # P2
             assert (cmds["cost"] <= grp["f_tight"][mask] + 1e-4).all()
@@ -367,7 +373,8 @@ def random_sets_miss_rates(solve, fixture="g14_random_sets.npz", only_steps=None
 
 
 #: fixture -> (random parameter sets, all-free-map cases the reference's own answers flag unique at least)
-RANDOM_SETS = {"g14_random_sets.npz": 48, "g15_judge_sets.npz": 64, "g16_judge_sets_r5.npz": 106}
+RANDOM_SETS = {"g14_random_sets.npz": 48, "g15_judge_sets.npz": 64, "g16_judge_sets_r5.npz": 106,
+               "g18_held_out_sets.npz": 48}
 
 
 def assert_random_sets(m, fixture="g14_random_sets.npz"):
