@@ -88,7 +88,7 @@ def load():
     lib.neo_mpc_set_host_path.argtypes = [C.c_void_p, C.c_int]
     lib.neo_mpc_kernel_info.argtypes = [C.c_void_p, P(C.c_uint32), P(C.c_uint32), P(C.c_uint32)]
     if os.environ.get("NEO_MPC_LIB"):
-        # development A/B against an older build of the same library (tools/ab_libs.sh): the record layouts have not
+        # development A/B against an older build of the same library (tools/ab_many.sh): the record layouts have not
         # changed since ABI 1, so only the entry points a tool actually calls have to exist
         if lib.neo_mpc_abi_version() not in (1, abi.ABI_VERSION):
             raise ImportError("%s: ABI version %d" % (LIB_PATH, lib.neo_mpc_abi_version()))
