@@ -292,10 +292,8 @@ int neo_mpc_default_params(neo_mpc_params* params);
 /* Replaces `MpcOptimizationServer.__init__` (py:45-152) + the service client creation at
  * cpp:308.  `device` is the HIP device ordinal.  NULL on failure.
  * The A/B switches of the measurement tools are environment variables READ HERE, ONCE (never on the solve path; a tool
- * that flips one re-creates its handle): NEO_MPC_SOLVE_WAVES=2|3|4, NEO_MPC_GENERIC_STEPS, NEO_MPC_NO_TAME_SPECIALISATION,
- * NEO_MPC_DYNAMIC_LDS (kernel variant), NEO_MPC_LDS_PAD=bytes (fewer resident waves: occupancy study), NEO_MPC_NO_EARLY
- * (Newton step tests off), NEO_MPC_INGEST_CHUNKS=n (K3),
- * NEO_MPC_NO_CHUNKS (large staged host batches in one piece), NEO_MPC_HOST_PATH=staged|zerocopy|zerocopy_out (what
+ * that flips one re-creates its handle): NEO_MPC_SOLVE_WAVES=2|3|4, NEO_MPC_NO_TAME_SPECIALISATION, NEO_MPC_DYNAMIC_LDS (kernel
+ * variant), NEO_MPC_NO_CHUNKS (large staged host batches in one piece), NEO_MPC_HOST_PATH=staged|zerocopy|zerocopy_out (what
  * NEO_MPC_HOST_PATH_AUTO means).  None changes a result beyond rounding. */
 neo_mpc_handle* neo_mpc_create(const neo_mpc_params* params, int device);
 void neo_mpc_destroy(neo_mpc_handle* handle);

@@ -107,7 +107,6 @@ struct neo_mpc_handle {
   int host_path = NEO_MPC_HOST_PATH_AUTO;   // neo_mpc_set_host_path
   // the environment's A/B switches, read once by neo_mpc_create (include/neo_mpc.h)
   LaunchTuning tuning;
-  bool no_early = false;      // NEO_MPC_NO_EARLY: the Newton step tests of K1 are off
   bool no_chunks = false;     // NEO_MPC_NO_CHUNKS: large staged host batches go through in one piece
   int auto_host_path = NEO_MPC_HOST_PATH_ZEROCOPY;   // what NEO_MPC_HOST_PATH_AUTO means (NEO_MPC_HOST_PATH)
   // neo_mpc_solve_batch_begin / _wait: page-locked batches in flight, each on a stream of its own
@@ -220,8 +219,8 @@ void derive(neo_mpc_handle* h) {
   // elsewhere (solver_rules.h neo_rules_routes_by_neighbourhood; method = NEO_MPC_METHOD_NEWTON is the dense direction for
   // every instance: round 5's AUTO, the A/B partner)
   d.routed = (neo_rules_routes_by_neighbourhood(&p) && r.direction == NEO_DIRECTION_DENSE) ? 1 : 0;
-  d.early_tol = h->no_early ? 0.0 : r.xtol;
-  d.final_tol = h->no_early ? 0.0 : r.final_tol;
+  d.early_tol = r.xtol;
+  d.final_tol = r.final_tol;
   d.ftol = r.ftol;
   d.wtol = r.wtol;
   d.wtol_late = r.wtol_late;
@@ -488,14 +487,8 @@ neo_mpc_handle* neo_mpc_create(const neo_mpc_params* params, int device) {
   {  // the A/B switches of the measurement tools: the only place the library looks at the environment
     const char* e = getenv("NEO_MPC_SOLVE_WAVES");
     h->tuning.solve_waves = (e && atoi(e) >= 2 && atoi(e) <= 4) ? atoi(e) : 0;
-    h->tuning.generic_steps = getenv("NEO_MPC_GENERIC_STEPS") != nullptr;
     h->tuning.no_tame = getenv("NEO_MPC_NO_TAME_SPECIALISATION") != nullptr;
     h->tuning.dynamic_lds = getenv("NEO_MPC_DYNAMIC_LDS") != nullptr;
-    e = getenv("NEO_MPC_INGEST_CHUNKS");
-    h->tuning.ingest_chunks = e ? atoi(e) : 0;
-    e = getenv("NEO_MPC_LDS_PAD");
-    h->tuning.lds_pad = (e && atoi(e) > 0 && atoi(e) <= 65536) ? atoi(e) : 0;
-    h->no_early = getenv("NEO_MPC_NO_EARLY") != nullptr;
     h->no_chunks = getenv("NEO_MPC_NO_CHUNKS") != nullptr;
     e = getenv("NEO_MPC_HOST_PATH");
     h->auto_host_path = !e ? NEO_MPC_HOST_PATH_ZEROCOPY : !strcmp(e, "staged") ? NEO_MPC_HOST_PATH_STAGED

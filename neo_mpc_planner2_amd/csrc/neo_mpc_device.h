@@ -198,11 +198,8 @@ struct CarrotArgs {
 // the handle -- nothing on the solve path looks at the environment.
 struct LaunchTuning {
   int solve_waves = 0;         // NEO_MPC_SOLVE_WAVES=2|3|4: occupancy variant of K1 (0: what was measured fastest)
-  bool generic_steps = false;  // NEO_MPC_GENERIC_STEPS: the run-time-sized L-BFGS kernel at control_steps 3 too
   bool no_tame = false;        // NEO_MPC_NO_TAME_SPECIALISATION: the general kernels for README-like parameters too
   bool dynamic_lds = false;    // NEO_MPC_DYNAMIC_LDS: the dynamic-LDS build of the control_steps specialisations
-  int ingest_chunks = 0;       // NEO_MPC_INGEST_CHUNKS: 16-byte chunks per thread of K3 (0: kIngestUnroll)
-  int lds_pad = 0;             // NEO_MPC_LDS_PAD: extra dynamic LDS bytes per K1 workgroup (occupancy study: fewer resident waves)
 };
 
 void launch_solve(const SolveArgs& a, const LaunchTuning& t, void* stream, void* ev_start = nullptr, void* ev_stop = nullptr);

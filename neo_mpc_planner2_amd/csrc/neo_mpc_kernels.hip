@@ -1230,7 +1230,7 @@ void launch_solve(const SolveArgs& a, const LaunchTuning& tuning, void* stream, 
   if (a.count == 0) return;
   const dim3 grid(a.count), block(kLanes);
   hipStream_t st = (hipStream_t)stream;
-  const bool generic = tuning.generic_steps || a.p.mem != 4;  // A/B: LDS-only path
+  const bool generic = a.p.mem != 4;  // (the control_steps-3 L-BFGS specialisation carves LDS for four pairs)
   const bool disc = a.p.tame != 0 && !tuning.no_tame;
   const size_t lds = a.lds.total_bytes;
   // (the static-tile kernels count on the tile being there: no tile at all -- a reach of 60 cells and more -- is not "small")
@@ -1240,14 +1240,14 @@ void launch_solve(const SolveArgs& a, const LaunchTuning& tuning, void* stream, 
   hipEvent_t e0 = (hipEvent_t)ev_start, e1 = (hipEvent_t)ev_stop;
 #define NEO_LAUNCH_LDS(bytes, ...)                                                                       \
   do {                                                                                                   \
-    if (e0 || e1) hipExtLaunchKernelGGL((k_solve<__VA_ARGS__>), grid, block, (bytes) + tuning.lds_pad, st, e0, e1, 0, a);   \
-    else hipLaunchKernelGGL((k_solve<__VA_ARGS__>), grid, block, (bytes) + tuning.lds_pad, st, a);                          \
+    if (e0 || e1) hipExtLaunchKernelGGL((k_solve<__VA_ARGS__>), grid, block, (bytes), st, e0, e1, 0, a);   \
+    else hipLaunchKernelGGL((k_solve<__VA_ARGS__>), grid, block, (bytes), st, a);                          \
   } while (0)
 #define NEO_LAUNCH(...) NEO_LAUNCH_LDS(lds, __VA_ARGS__)
 #define NEO_LAUNCH_ROUTED(bytes, ...)                                                                    \
   do {                                                                                                   \
-    if (e0 || e1) hipExtLaunchKernelGGL((k_solve_routed<__VA_ARGS__>), grid, block, (bytes) + tuning.lds_pad, st, e0, e1, 0, a);   \
-    else hipLaunchKernelGGL((k_solve_routed<__VA_ARGS__>), grid, block, (bytes) + tuning.lds_pad, st, a);                          \
+    if (e0 || e1) hipExtLaunchKernelGGL((k_solve_routed<__VA_ARGS__>), grid, block, (bytes), st, e0, e1, 0, a);   \
+    else hipLaunchKernelGGL((k_solve_routed<__VA_ARGS__>), grid, block, (bytes), st, a);                          \
   } while (0)
 #define NEO_LAUNCH_ROUTED_W(w, tame)                                                                     \
   do {                                                                                                   \
@@ -1383,7 +1383,7 @@ void launch_dispatch_order(const neo_mpc_command* commands, float* load, uint32_
 void launch_ingest(const IngestArgs& a, const LaunchTuning& tuning, void* stream) {
   const long total = (long)a.rows * (a.pitch >> 4);
   // a few 16-byte chunks per thread: one-chunk threads make the launch dispatch-bound for pools of small maps
-  const int per_thread = tuning.ingest_chunks > 0 ? tuning.ingest_chunks : kIngestUnroll;
+  const int per_thread = kIngestUnroll;
   int blocks = (int)((total + 256L * per_thread - 1) / (256L * per_thread));
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(k_ingest, dim3(blocks, a.maps > 0 ? a.maps : 1), dim3(256), 0, (hipStream_t)stream, a);
